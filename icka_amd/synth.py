@@ -1,0 +1,82 @@
+"""Seeded synthetic weights and Twitter-2015-shaped batches.
+
+Weights are generated **by state_dict key** (seed = crc32(key)) so that the reference modules (dev container
+only), the CPU oracle and the HIP product all see bit-identical fp32 parameters without any checkpoint
+travelling to the GPU box.  Everything is generated on the CPU generator and then moved, so values do not
+depend on the device.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterable, Mapping, Optional, Tuple
+
+import torch
+
+REFERENCE_SEED = 19260817  # My_cross_attention.py:577-580 (reference default --seed)
+
+
+def seeded_tensor(key: str, shape: Tuple[int, ...], std: float = 0.02) -> torch.Tensor:
+    """normal(0, std) from a per-key generator; LayerNorm scales are 1 + normal(0, std) so they are exercised."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(zlib.crc32(key.encode("utf-8")))
+    t = torch.empty(shape, dtype=torch.float32).normal_(0.0, std, generator=g)
+    if key.endswith("LayerNorm.weight") or key.endswith("proj_norm.weight"):
+        t += 1.0
+    return t
+
+
+def seeded_state_dict(shapes: Mapping[str, Tuple[int, ...]], std: float = 0.02) -> Dict[str, torch.Tensor]:
+    return {k: seeded_tensor(k, tuple(shapes[k]), std) for k in sorted(shapes)}
+
+
+def fill_module_(module: torch.nn.Module, std: float = 0.02, only: Optional[Iterable[str]] = None) -> None:
+    """In-place seeded fill of every parameter of ``module`` (keyed by its state_dict names)."""
+    sd = module.state_dict()
+    names = set(only) if only is not None else None
+    with torch.no_grad():
+        for k, v in sd.items():
+            if names is not None and k not in names:
+                continue
+            if not torch.is_floating_point(v):
+                continue
+            v.copy_(seeded_tensor(k, tuple(v.shape), std).to(v.dtype))
+
+
+def synthetic_batch(batch: int, seq_len: int, regions: int, num_labels: int = 13, vocab_size: int = 30522,
+                    seed: int = REFERENCE_SEED, layout: str = "BRC", ragged: bool = True,
+                    min_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """One (sentence, image)-pair batch in the reference's tensor conventions.
+
+    input_ids [B,S] int64 ~ U[1,vocab) with pad id 0 past the length; lengths ~ U[S/4,S] (``ragged``);
+    segment_ids zeros (My_cross_attention.py:362); input_mask = pos < len; added_attention_mask =
+    ones[R] || input_mask (My_cross_attention.py:373); region features ~ N(0,1) either as ``[B,R,2048]``
+    (layout "BRC", BASELINE synthetic layout) or as ``[B,2048,7,7]`` (layout "BCHW", the reference's
+    myResnet output, only for R=49); labels ~ U[1,C) on valid tokens, 0 elsewhere.
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    lo = max(1, seq_len // 4) if min_len is None else min_len
+    if ragged:
+        lengths = torch.randint(lo, seq_len + 1, (batch,), generator=g)
+    else:
+        lengths = torch.full((batch,), seq_len, dtype=torch.long)
+    pos = torch.arange(seq_len)[None, :]
+    input_mask = (pos < lengths[:, None]).long()
+    ids = torch.randint(1, vocab_size, (batch, seq_len), generator=g) * input_mask
+    segment_ids = torch.zeros_like(ids)
+    labels = torch.randint(1, num_labels, (batch, seq_len), generator=g) * input_mask
+    if layout == "BRC":
+        vis = torch.empty(batch, regions, 2048).normal_(0.0, 1.0, generator=g)
+    elif layout == "BCHW":
+        if regions != 49:
+            raise ValueError("BCHW layout is the reference's 7x7 grid: regions must be 49")
+        vis = torch.empty(batch, 2048, 7, 7).normal_(0.0, 1.0, generator=g)
+    else:
+        raise ValueError(layout)
+    vis_mean = torch.empty(batch, 2048).normal_(0.0, 1.0, generator=g)
+    added = torch.cat([torch.ones(batch, regions, dtype=torch.long), input_mask], dim=1)
+    return {
+        "input_ids": ids, "segment_ids": segment_ids, "input_mask": input_mask,
+        "added_attention_mask": added, "visual_embeds_mean": vis_mean, "visual_embeds_att": vis,
+        "labels": labels, "lengths": lengths,
+    }
