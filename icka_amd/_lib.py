@@ -1,0 +1,101 @@
+"""ctypes binding of libicka_hip.so (C-ABI declared in include/icka_hip.h).
+
+The library is built in-tree by ``icka_amd/csrc/Makefile`` (``python -c 'import __graft_entry__ as g; g.build()'``).
+There is NO fallback: if the shared object is missing, ``load()`` raises.  Nothing in this package computes on
+the CPU or through eager PyTorch ops in place of a missing kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
+
+c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH = 0, 1, 2, 3, 4, 5
+
+
+class GemmDesc(C.Structure):
+    """Mirror of ``icka_gemm_desc`` (include/icka_hip.h)."""
+    _fields_ = [
+        ("op", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("K1", c_i32),
+        ("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64),
+        ("A2", c_vp), ("lda2", c_i64), ("B2", c_vp), ("ldb2", c_i64),
+        ("C", c_vp), ("ldc", c_i64), ("c_is_f32", c_i32),
+        ("C2", c_vp), ("ldc2", c_i64),
+        ("aux", c_vp), ("ldaux", c_i64),
+        ("bias", c_vp),
+        ("alpha", c_f32), ("beta", c_f32),
+        ("epilogue", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); must list every function declared in include/icka_hip.h
+PROTOTYPES = {
+    "icka_abi_version": (c_i32, []),
+    "icka_build_arch": (C.c_char_p, []),
+    "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                            c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_ln_bwd_workspace_floats": (c_i64, [c_i32]),
+    "icka_ln_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+                            c_vp, c_i32, c_i32, c_f32, c_u64, c_vp]),
+    "icka_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                               c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                               c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp]),
+    "icka_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
+                              c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                              c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
+                              c_vp]),
+    "icka_cast_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "icka_cast_bf16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "icka_additive_mask": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),
+    "icka_dropout": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_u64, c_vp]),
+    "icka_regions_to_tokens": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_colsum": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_colsum_workspace_floats": (c_i64, [c_i32]),
+    "icka_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "icka_add_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "icka_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "icka_scale_by_inv": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "icka_dropout_mask": (c_i32, [c_vp, c_i64, c_f32, c_u64, c_vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class IckaLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libicka_hip.so (once) and attach prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IckaLibraryError(
+            "libicka_hip.so not found at %s: build it with `make -C icka_amd/csrc` "
+            "(or __graft_entry__.build()).  icka_amd has no CPU / eager fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "ICKA_E_SHAPE (dimension out of supported range)", -2: "ICKA_E_ALIGN (pointer / leading dimension "
+        "alignment)", -3: "ICKA_E_ARG (null pointer or inconsistent descriptor)"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))

@@ -1,0 +1,117 @@
+// Shared device helpers for the ICKA MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes; MFMA = v_mfma_f32_16x16x32_bf16; LDS images and the counter-hash dropout RNG live here so that
+// forward and backward kernels regenerate identical masks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/icka_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define ICKA_WAVE 64
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+#define ICKA_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-preserving
+
+// NOTE: register arrays use clang ext_vector types (u32x4 ...), never HIP's uint4/float4 structs: arrays of the
+// struct types are not always scalarised and end up in scratch / promoted to LDS.
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+__device__ __forceinline__ bf16x4 as_bf16x4(u32x2 v) { return __builtin_bit_cast(bf16x4, v); }
+__device__ __forceinline__ u32x2 as_u32x2(bf16x4 v) { return __builtin_bit_cast(u32x2, v); }
+
+__device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+    bf16x4 v = {f2bf(a), f2bf(b), f2bf(c), f2bf(d)};
+    return as_u32x2(v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Counter-hash dropout RNG.  keep(idx) is a pure function of (seed, element index) so that the backward kernels
+// regenerate the forward mask in whatever register layout they hold the element (rows on lanes or in-lane).
+struct DropCfg {
+    uint32_t s0, s1;   // 64-bit seed halves
+    uint32_t thr;      // drop if hash < thr ; thr = p * 2^32
+    float scale;       // 1 / (1 - p)
+};
+__host__ __device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed) {
+    DropCfg d;
+    d.s0 = (uint32_t)seed;
+    d.s1 = (uint32_t)(seed >> 32);
+    if (p <= 0.f) { d.thr = 0u; d.scale = 1.f; }
+    else {
+        double t = (double)p * 4294967296.0;
+        d.thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+        d.scale = 1.f / (1.f - p);
+    }
+    return d;
+}
+__host__ __device__ __forceinline__ uint32_t icka_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + s0;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x = x * 0x846ca68bu + s1;
+    x ^= x >> 16;
+    return x;
+}
+// multiplier applied to a kept element: scale if kept, 0 if dropped
+__device__ __forceinline__ float drop_mul(const DropCfg& d, uint32_t idx) {
+    return (d.thr == 0u || icka_hash(d.s0, d.s1, idx) >= d.thr) ? d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// erf-GELU (Cross_Modal_Interaction_Module.py:31-37) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA: D[i][j] += sum_k a[i][k] * b[k][j], 16x16x32 bf16.
+//   lane l holds a[i = l&15][k = 8*(l>>4) + e], b[k = 8*(l>>4) + e][j = l&15], e = 0..7,
+//   and D[i = 4*(l>>4) + r][j = l&15], r = 0..3.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// LDS reads
+__device__ __forceinline__ bf16x8 lds_read_b128(const char* base, uint32_t off) {
+    return *reinterpret_cast<const bf16x8*>(base + off);
+}
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements is delivered column-major:
+// lane 4q+p supplies the address of row q, cols 4p..4p+3; lane i receives column i, rows 0..3.
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* base, uint32_t off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, base + off));
+}
+__device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}

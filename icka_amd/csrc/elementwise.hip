@@ -1,0 +1,317 @@
+// Element-wise / layout / reduction helpers of the ICKA hot path (gfx950).  All are HBM/L2-bound: every thread
+// moves 16-byte chunks (8 bf16 or 4+4 f32), consecutive lanes touch consecutive chunks.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+}
+
+__global__ void cast_f2b_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t nch = n >> 3;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + c * 8), b = *reinterpret_cast<const f32x4*>(src + c * 8 + 4);
+        bf16x8 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+        *reinterpret_cast<u32x4*>(dst + c * 8) = as_u32x4(o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nch << 3) + threadIdx.x] = f2bf(src[(nch << 3) + threadIdx.x]);
+}
+__global__ void cast_b2f_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf2f(src[i]);
+}
+
+__global__ void additive_mask_kernel(const int64_t* __restrict__ mask, int64_t ld, float* __restrict__ out, int B, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i - b * T;
+    out[i] = (1.0f - (float)mask[(int64_t)b * ld + t]) * -10000.0f;
+}
+
+__global__ void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
+                               bf16_t* __restrict__ y2, int64_t ldy2, int M, int H, DropCfg d) {
+    const int cpr = H >> 3;
+    const int64_t total = (int64_t)M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        float v[8];
+        ld8(x + row * ldx + c * 8, v);
+        const uint32_t base = (uint32_t)row * (uint32_t)H + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= drop_mul(d, base + e);
+        st8(y + row * ldy + c * 8, v);
+        if (y2) st8(y2 + row * ldy2 + c * 8, v);
+    }
+}
+
+__global__ void dropout_mask_kernel(float* out, int64_t n, DropCfg d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = drop_mul(d, (uint32_t)i);
+}
+
+// layout 1: src f32 [B, C, R] -> dst bf16 [B, R, C]; one block per (b, 64-channel strip), transposed through LDS
+__global__ __launch_bounds__(256) void regions_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B,
+                                                        int R, int C) {
+    extern __shared__ float tile[];  // [64][R+1]
+    const int strips = (C + 63) / 64;
+    const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 64;
+    const int nc = (C - c0) < 64 ? (C - c0) : 64;
+    const float* s = src + ((int64_t)b * C + c0) * R;
+    for (int i = threadIdx.x; i < nc * R; i += 256) {
+        const int c = i / R, r = i - c * R;
+        tile[c * (R + 1) + r] = s[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (c < nc) dst[((int64_t)b * R + r) * C + c0 + c] = f2bf(tile[c * (R + 1) + r]);
+    }
+}
+
+constexpr int CS_GROUPS = 64;
+// partial[group][N] = sum over the group's rows; block = 64 chunk-lanes x 4 row-lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ partial,
+                                                     int M, int N, int rows_per_group, int vec) {
+    __shared__ float red[4][64][8];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + cx) * 8;
+    const int r0 = blockIdx.y * rows_per_group;
+    int r1 = r0 + rows_per_group; r1 = r1 > M ? M : r1;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        const int nv = (N - col) < 8 ? (N - col) : 8;
+        for (int r = r0 + ry; r < r1; r += 4) {
+            const bf16_t* p = x + (int64_t)r * ldx + col;
+            if (nv == 8 && vec) {
+                float v[8];
+                ld8(p, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            } else {
+                for (int e = 0; e < nv; ++e) acc[e] += bf2f(p[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ry][cx][e] = acc[e];
+    __syncthreads();
+    if (ry == 0 && col < N) {
+        for (int e = 0; e < 8 && col + e < N; ++e)
+            partial[(int64_t)blockIdx.y * N + col + e] = red[0][cx][e] + red[1][cx][e] + red[2][cx][e] + red[3][cx][e];
+    }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int N,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += partial[(int64_t)g * N + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ void gate_bwd_kernel(const bf16_t* __restrict__ dout, int64_t lddout, const bf16_t* __restrict__ g,
+                                const bf16_t* __restrict__ cross, int64_t ldcross, const bf16_t* __restrict__ dci,
+                                int64_t lddci, bf16_t* __restrict__ du, bf16_t* __restrict__ dcross, int64_t lddc, int M,
+                                int H) {
+    const int cpr = H >> 3;
+    const int64_t total = (int64_t)M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i - row * cpr) * 8;
+        float d[8], gg[8], cr[8], u[8], dc[8];
+        ld8(dout + row * lddout + c, d);
+        ld8(g + row * H + c, gg);
+        ld8(cross + row * ldcross + c, cr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { u[e] = d[e] * cr[e] * gg[e] * (1.f - gg[e]); dc[e] = d[e] * gg[e]; }
+        if (dci) {
+            float t[8];
+            ld8(dci + row * lddci + c, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dc[e] += t[e];
+        }
+        st8(du + row * H + c, u);
+        st8(dcross + row * lddc + c, dc);
+    }
+}
+
+__global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ c, int64_t n) {
+    const int64_t nch = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nch; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        ld8(a + i * 8, x); ld8(b + i * 8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        st8(c + i * 8, x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const int64_t j = (nch << 3) + threadIdx.x;
+        c[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+    }
+}
+
+__global__ __launch_bounds__(256) void token_ce_kernel(const float* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ labels, const int64_t* __restrict__ mask,
+                                                       float* loss_sum, float* count, bf16_t* __restrict__ dl, int64_t ldd,
+                                                       int M, int C) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f, cnt = 0.f;
+    if (row < M) {
+        const float* p = logits + (int64_t)row * ld;
+        const bool valid = mask[row] != 0;
+        const int64_t y = labels[row];
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+        const float lse = mx + logf(se);
+        bf16_t* d = dl + (int64_t)row * ldd;
+        for (int c = 0; c < (int)ldd; ++c) {
+            float gval = 0.f;
+            if (valid && c < C) gval = expf(p[c] - lse) - (c == (int)y ? 1.f : 0.f);
+            d[c] = f2bf(gval);
+        }
+        if (valid && y >= 0 && y < C) { loss = lse - p[y]; cnt = 1.f; }
+    }
+    loss = wave_sum(loss);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt > 0.f) { atomicAdd(loss_sum, loss); atomicAdd(count, cnt); }
+}
+
+__global__ void scale_inv_kernel(bf16_t* x, const float* denom, int64_t n) {
+    const float s = 1.f / fmaxf(denom[0], 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = f2bf(bf2f(x[i]) * s);
+}
+
+}  // namespace
+
+extern "C" int icka_abi_version(void) { return 1; }
+extern "C" const char* icka_build_arch(void) { return "gfx950"; }
+
+extern "C" int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    if (!al16(src) || !al16(dst)) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for((n + 7) / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_additive_mask(const int64_t* mask, int64_t ld, float* out, int32_t B, int32_t T, void* stream) {
+    if (!mask || !out) return ICKA_E_ARG;
+    if (B <= 0 || T <= 0 || ld < T) return ICKA_E_SHAPE;
+    hipLaunchKernelGGL(additive_mask_kernel, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream, mask, ld, out, B, T);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, void* y2, int64_t ldy2, int32_t M,
+                            int32_t H, float p_drop, uint64_t seed, void* stream) {
+    if (!x || !y) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8) return ICKA_E_SHAPE;
+    if (ldx % 8 || ldy % 8 || (y2 && ldy2 % 8) || !al16(x) || !al16(y) || (y2 && !al16(y2))) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((int64_t)M * (H / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (bf16_t*)y2, ldy2, M, H, make_drop(p_drop, seed));
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t seed, void* stream) {
+    if (!out) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       make_drop(p_drop, seed));
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_regions_to_tokens(const float* src, void* dst, int32_t B, int32_t R, int32_t C, int32_t layout,
+                                      void* stream) {
+    if (!src || !dst) return ICKA_E_ARG;
+    if (B <= 0 || R <= 0 || C <= 0 || R > 256) return ICKA_E_SHAPE;
+    if (layout == 0) return icka_cast_f32_to_bf16(src, dst, (int64_t)B * R * C, stream);
+    if (layout != 1) return ICKA_E_ARG;
+    hipLaunchKernelGGL(regions_t_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 64 * (R + 1) * sizeof(float),
+                       (hipStream_t)stream, src, (bf16_t*)dst, B, R, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int64_t icka_colsum_workspace_floats(int32_t N) { return (int64_t)CS_GROUPS * N; }
+extern "C" int icka_colsum(const void* x, int64_t ldx, float* out, float* partials, int32_t M, int32_t N,
+                           int32_t accumulate, void* stream) {
+    if (!x || !out || !partials) return ICKA_E_ARG;
+    if (M <= 0 || N <= 0) return ICKA_E_SHAPE;
+    const int vec = (ldx % 8 == 0) && al16(x);
+    int groups = (M + 63) / 64; groups = groups > CS_GROUPS ? CS_GROUPS : groups;
+    const int rpg = (M + groups - 1) / groups;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, groups), dim3(256), 0, st, (const bf16_t*)x, ldx, partials, M,
+                       N, rpg, vec);
+    ICKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partials, out, groups, N, accumulate);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_gate_bwd(const void* dout, int64_t lddout, const void* g, const void* cross, int64_t ldcross,
+                             const void* dcross_in, int64_t lddci, void* du, void* dcross, int64_t lddc, int32_t M,
+                             int32_t H, void* stream) {
+    if (!dout || !g || !cross || !du || !dcross) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8) return ICKA_E_SHAPE;
+    if (lddout % 8 || ldcross % 8 || lddc % 8 || (dcross_in && lddci % 8)) return ICKA_E_ALIGN;
+    if (!al16(dout) || !al16(g) || !al16(cross) || !al16(du) || !al16(dcross) || (dcross_in && !al16(dcross_in)))
+        return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for((int64_t)M * (H / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, lddout, (const bf16_t*)g, (const bf16_t*)cross, ldcross,
+                       (const bf16_t*)dcross_in, lddci, (bf16_t*)du, (bf16_t*)dcross, lddc, M, H);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, void* stream) {
+    if (!a || !b || !c) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    if (!al16(a) || !al16(b) || !al16(c)) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)c, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask,
+                             float* loss_sum, float* count, void* dlogits, int64_t ldd, int32_t M, int32_t C,
+                             void* stream) {
+    if (!logits || !labels || !mask || !loss_sum || !count || !dlogits) return ICKA_E_ARG;
+    if (M <= 0 || C <= 0 || ldd < C || ld < C) return ICKA_E_SHAPE;
+    hipLaunchKernelGGL(token_ce_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ld, labels,
+                       mask, loss_sum, count, (bf16_t*)dlogits, ldd, M, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_scale_by_inv(void* x, const float* denom, int64_t n, void* stream) {
+    if (!x || !denom) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scale_inv_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, denom, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,299 @@
+// MFMA GEMM for the ICKA hot path (gfx950).  One kernel template, three operand layouts:
+//   NT: C = A[M,K] . B[N,K]^T   (both operands k-contiguous: fragments by ds_read_b128)
+//   NN: C = A[M,K] . B[K,N]     (B k-major in memory: fragments by ds_read_b64_tr_b16)
+//   TN: C = A[K,M]^T . B[K,N]   (both k-major: weight gradients, K = tokens)
+// Block = 256 threads (4 waves, 2x2), tile 128x128x64, v_mfma_f32_16x16x32_bf16, wave tile 64x64 (4x4 MFMA tiles).
+// Global -> registers -> LDS staging (next k-tile's loads are issued before the MFMAs of the current one), LDS
+// double-buffered (one barrier per k-tile).  LDS images are XOR-swizzled per layout (off_kc / off_km).
+// The MFMA is issued as D^T: a-operand = B-tile rows (n), b-operand = A-tile rows (m), so each lane ends up with
+// FOUR CONSECUTIVE n of one output row m -> 8-byte (bf16) / 16-byte (f32) row-major stores and vector epilogues.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, either layout
+
+struct GemmArgs {
+    int M, N, K, K1;
+    const bf16_t* A;  int64_t lda;
+    const bf16_t* B;  int64_t ldb;
+    const bf16_t* A2; int64_t lda2;
+    const bf16_t* B2; int64_t ldb2;
+    void* C;  int64_t ldc;
+    bf16_t* C2; int64_t ldc2;
+    const bf16_t* aux; int64_t ldaux;
+    const float* bias;
+    float alpha, beta;
+    int epi, c_f32;
+    int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
+};
+
+// k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
+// of a fragment read land on 16 distinct 16-B slots of the 256-B bank row.
+__device__ __forceinline__ uint32_t off_kc(int row, int ch) { return row * 128 + (((ch ^ (row >> 1)) & 7) << 4); }
+// k-major tile image [64 k][128 rows]: 256-B rows; chunk XOR per cdna guide T10 image (b), serves the transposed read.
+__device__ __forceinline__ uint32_t off_km(int kr, int ch) {
+    return kr * 256 + ((ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ u32x4 load_partial(const bf16_t* p, int nvalid) {
+    const unsigned short* ps = reinterpret_cast<const unsigned short*>(p);
+    u32x4 v = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t x = e < nvalid ? (uint32_t)ps[e] : 0u;
+        v[e >> 1] |= x << (16 * (e & 1));
+    }
+    return v;
+}
+
+// global -> registers: 4 x 16-byte chunks per thread cover the 128x64 (or 64x128) tile.
+template <bool KM, bool ALIGNED>
+__device__ __forceinline__ void g2r(u32x4 (&r)[4], const bf16_t* __restrict__ P, int64_t ld, int row0, int nrows,
+                                    int k0, int K, int tid, int vec) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        const bf16_t* p;
+        bool ok;
+        int rem;
+        if (!KM) {
+            const int rr = q >> 3, c = q & 7;
+            const int grow = row0 + rr, gk = k0 + 8 * c;
+            p = P + (int64_t)grow * ld + gk;
+            ok = grow < nrows;
+            rem = K - gk;
+        } else {
+            const int kr = q >> 4, c = q & 15;
+            const int gk = k0 + kr, gcol = row0 + 8 * c;
+            p = P + (int64_t)gk * ld + gcol;
+            ok = gk < K;
+            rem = nrows - gcol;
+        }
+        if (ALIGNED) {
+            r[i] = *reinterpret_cast<const u32x4*>(p);
+        } else {
+            if (ok && rem >= 8 && vec) r[i] = *reinterpret_cast<const u32x4*>(p);
+            else if (ok && rem > 0) r[i] = load_partial(p, rem < 8 ? rem : 8);
+            else r[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ void r2s(const u32x4 (&r)[4], char* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        const uint32_t off = KM ? off_km(q >> 4, q & 15) : off_kc(q >> 3, q & 7);
+        *reinterpret_cast<u32x4*>(tile + off) = r[i];
+    }
+}
+
+// MFMA operand fragment for the 16 tile-rows starting at rbase, k-step ks (32 k each) of the 64-deep tile:
+// lane l gets element e = operand[row rbase + (l&15)][k = 32*ks + 8*(l>>4) + e].
+template <bool KM>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int ks, int lane) {
+    if (!KM) {
+        return lds_read_b128(tile, off_kc(rbase + (lane & 15), ks * 4 + (lane >> 4)));
+    } else {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const int c = (rbase >> 3) + (p >> 1);
+        const int kr = ks * 32 + 8 * g + q;
+        const bf16x4 lo = lds_read_tr(tile, off_km(kr, c) + 8 * (p & 1));
+        const bf16x4 hi = lds_read_tr(tile, off_km(kr + 4, c) + 8 * (p & 1));
+        return join8(lo, hi);
+    }
+}
+
+__device__ __forceinline__ void load4(const bf16_t* base, int64_t ld, int m, int n, int nvalid, float (&o)[4]) {
+    const bf16_t* p = base + (int64_t)m * ld + n;
+    if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) {
+        const bf16x4 v = as_bf16x4(*reinterpret_cast<const u32x2*>(p));
+        o[0] = bf2f(v[0]); o[1] = bf2f(v[1]); o[2] = bf2f(v[2]); o[3] = bf2f(v[3]);
+    } else {
+        for (int r = 0; r < 4; ++r) o[r] = r < nvalid ? bf2f(p[r]) : 0.f;
+    }
+}
+__device__ __forceinline__ void store4_bf16(bf16_t* base, int64_t ld, int m, int n, int nvalid, const float (&v)[4]) {
+    bf16_t* p = base + (int64_t)m * ld + n;
+    if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) {
+        *reinterpret_cast<u32x2*>(p) = pack4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) p[r] = f2bf(v[r]);
+    }
+}
+
+__device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4 acc) {
+    const int nvalid = (g.N - n) < 4 ? (g.N - n) : 4;
+    float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
+    if (g.bias) {
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) v[r] += g.bias[n + r];
+    }
+    float a[4];
+    switch (g.epi) {
+        case ICKA_EPI_GELU:
+            store4_bf16(g.C2, g.ldc2, m, n, nvalid, v);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            break;
+        case ICKA_EPI_DGELU:
+            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(a[r]);
+            break;
+        case ICKA_EPI_ADD:
+            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            for (int r = 0; r < 4; ++r) v[r] += a[r];
+            break;
+        case ICKA_EPI_GATE:
+            for (int r = 0; r < 4; ++r) v[r] = sigmoid_f(v[r]);
+            if (g.C2) store4_bf16(g.C2, g.ldc2, m, n, nvalid, v);
+            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            for (int r = 0; r < 4; ++r) v[r] *= a[r];
+            break;
+        case ICKA_EPI_TANH:
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            break;
+        default: break;
+    }
+    if (g.c_f32) {
+        float* p = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
+        if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (g.beta != 0.f) o += g.beta * *reinterpret_cast<const f32x4*>(p);
+            *reinterpret_cast<f32x4*>(p) = o;
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (r < nvalid) p[r] = v[r] + (g.beta != 0.f ? g.beta * p[r] : 0.f);
+        }
+    } else {
+        bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+        if (g.beta != 0.f) {
+            load4(C, g.ldc, m, n, nvalid, a);
+            for (int r = 0; r < 4; ++r) v[r] += g.beta * a[r];
+        }
+        store4_bf16(C, g.ldc, m, n, nvalid, v);
+    }
+}
+
+// Issue the global loads of k-tile kt for both operands (second reduction segment after K1, if any).
+template <bool A_KM, bool B_KM, bool ALIGNED>
+__device__ __forceinline__ void fetch_tiles(const GemmArgs& g, int kt, int m0, int n0, int tid, u32x4 (&ra)[4],
+                                            u32x4 (&rb)[4]) {
+    int k0 = kt * BK;
+    const bf16_t* Ap = g.A; int64_t la = g.lda;
+    const bf16_t* Bp = g.B; int64_t lb = g.ldb;
+    int klim = g.K1 > 0 ? g.K1 : g.K;
+    if (g.K1 > 0 && k0 >= g.K1) {
+        Ap = g.A2; la = g.lda2; Bp = g.B2; lb = g.ldb2;
+        k0 -= g.K1; klim = g.K - g.K1;
+    }
+    g2r<A_KM, ALIGNED>(ra, Ap, la, m0, g.M, k0, klim, tid, g.a_vec);
+    g2r<B_KM, ALIGNED>(rb, Bp, lb, n0, g.N, k0, klim, tid, g.b_vec);
+}
+
+template <bool A_KM, bool B_KM, bool ALIGNED>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;  // local copy: lets SROA scalarise the descriptor instead of spilling the kernarg struct
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [2 buffers][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
+    // run of tiles (same A row panel, neighbouring B panels) -> its private L2 sees the panel re-use.
+    const int nbn = (g.N + BN - 1) / BN;
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
+    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (g.K + BK - 1) / BK;
+    u32x4 ra[4], rb[4];
+
+    fetch_tiles<A_KM, B_KM, ALIGNED>(g, 0, m0, n0, tid, ra, rb);
+    r2s<A_KM>(ra, smem, tid);
+    r2s<B_KM>(rb, smem + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sA = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+        if (kt + 1 < nk) fetch_tiles<A_KM, B_KM, ALIGNED>(g, kt + 1, m0, n0, tid, ra, rb);  // in flight under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = read_frag<A_KM>(sA, wr + 16 * t, ks, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+        }
+        if (kt + 1 < nk) {
+            char* dA = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            r2s<A_KM>(ra, dA, tid);
+            r2s<B_KM>(rb, dA + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // D^T layout: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr + 16 * mi + (lane & 15);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc + 16 * ni + 4 * (lane >> 4);
+            if (m < g.M && n < g.N) epilogue4(g, m, n, acc[mi][ni]);
+        }
+    }
+}
+
+template <bool A_KM, bool B_KM>
+int launch(const GemmArgs& g, bool aligned, hipStream_t st) {
+    const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    if (aligned) hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, true>), dim3(nb), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, false>), dim3(nb), dim3(256), 0, st, g);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+inline bool vec_ok(const void* p, int64_t ld) { return (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
+
+}  // namespace
+
+extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) return ICKA_E_ARG;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return ICKA_E_SHAPE;
+    if (d->op < ICKA_GEMM_NT || d->op > ICKA_GEMM_TN) return ICKA_E_ARG;
+    if (d->K1 != 0 && (d->K1 < 0 || d->K1 >= d->K || d->K1 % BK != 0 || !d->A2 || !d->B2)) return ICKA_E_ARG;
+    if ((d->epilogue == ICKA_EPI_GELU) && !d->C2) return ICKA_E_ARG;
+    if ((d->epilogue == ICKA_EPI_DGELU || d->epilogue == ICKA_EPI_ADD || d->epilogue == ICKA_EPI_GATE) && !d->aux)
+        return ICKA_E_ARG;
+    GemmArgs g;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.K1 = d->K1;
+    g.A = (const bf16_t*)d->A; g.lda = d->lda; g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
+    g.A2 = (const bf16_t*)d->A2; g.lda2 = d->lda2; g.B2 = (const bf16_t*)d->B2; g.ldb2 = d->ldb2;
+    g.C = d->C; g.ldc = d->ldc; g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
+    g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux; g.bias = d->bias;
+    g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
+    g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
+    g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
+    const bool aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec;
+    hipStream_t st = (hipStream_t)stream;
+    switch (d->op) {
+        case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st);
+        case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
+        default: return launch<true, true>(g, aligned, st);
+    }
+}

@@ -1,0 +1,445 @@
+// Fused bias + dropout + residual + LayerNorm (forward / backward) and the BertEmbeddings gather + LayerNorm +
+// dropout (forward / backward) for gfx950.  HBM/L2-bound row kernels: one 64-lane wave per row, every lane owns
+// 16-byte chunks (8 bf16) of the row -> coalesced 1-KiB wave accesses, statistics by wave-level shuffles in fp32.
+// Column reductions of the backward (dgamma, dbeta, dbias, token-type rows) are kept in per-lane registers over the
+// rows a wave visits, combined per block through LDS and written as per-block partial slabs that a tiny finalize
+// kernel sums: no global float atomics on hot addresses, bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_CH = 4;           // chunks of 8 per lane -> H <= 2048
+constexpr int BWD_BLOCKS = 256;     // partial slabs per backward launch
+constexpr int SLOTS = 4;            // column-sum slots per slab
+
+struct LnFwdArgs {
+    const bf16_t* x; int64_t ldx; const float* bias; const bf16_t* res; int64_t ldr;
+    const float* gamma; const float* beta;
+    bf16_t* y; int64_t ldy; bf16_t* y2; int64_t ldy2; bf16_t* xhat; float* rstd;
+    int M, H; float eps; DropCfg drop;
+};
+
+__device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+}
+__device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nchunk = a.H >> 3;
+    const float inv_h = 1.f / (float)a.H;
+    for (int row = wid; row < a.M; row += nw) {
+        float s[NCH][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                load8(a.x + (int64_t)row * a.ldx + c * 8, s[i]);
+                if (a.bias) {
+                    float b[8];
+                    load8f(a.bias + c * 8, b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[i][e] += b[e];
+                }
+                if (a.drop.thr) {
+                    const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[i][e] *= drop_mul(a.drop, base + e);
+                }
+                if (a.res) {
+                    float r[8];
+                    load8(a.res + (int64_t)row * a.ldr + c * 8, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[i][e] += r[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += s[i][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[i][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(sum) * inv_h;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane + 64 * i < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = s[i][e] - mean; sq += d * d; }
+            }
+        const float var = wave_sum(sq) * inv_h;
+        const float rstd = 1.f / sqrtf(var + a.eps);
+        if (lane == 0 && a.rstd) a.rstd[row] = rstd;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float g[8], b[8], xh[8], o[8];
+                load8f(a.gamma + c * 8, g);
+                load8f(a.beta + c * 8, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] = (s[i][e] - mean) * rstd; o[e] = g[e] * xh[e] + b[e]; }
+                store8(a.y + (int64_t)row * a.ldy + c * 8, o);
+                if (a.y2) store8(a.y2 + (int64_t)row * a.ldy2 + c * 8, o);
+                if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
+            }
+        }
+    }
+}
+
+struct LnBwdArgs {
+    const bf16_t* dy; int64_t lddy; const bf16_t* dy2; int64_t lddy2; const bf16_t* xhat; const float* rstd;
+    const float* gamma; bf16_t* dres; int64_t lddres; bf16_t* dx; int64_t lddx; float* partials;
+    int M, H; DropCfg drop;
+};
+
+// Combine the 4 waves' per-lane column sums through LDS and write this block's slab: partials[blk][slot][H].
+template <int NCH, int NS>
+__device__ __forceinline__ void flush_columns(float (&acc)[NS][NCH][8], float* lds, float* partials, int H) {
+    const int lane = threadIdx.x & 63, nchunk = H >> 3;
+    for (int i = threadIdx.x; i < NS * H; i += 256) lds[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(&lds[s * H + c * 8 + e], acc[s][i][e]);
+            }
+        }
+    __syncthreads();
+    float* slab = partials + (int64_t)blockIdx.x * SLOTS * H;
+    for (int i = threadIdx.x; i < NS * H; i += 256) slab[i] = lds[i];
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nchunk = a.H >> 3;
+    const float inv_h = 1.f / (float)a.H;
+    float acc[3][NCH][8];  // dgamma, dbeta, dbias
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[s][i][e] = 0.f;
+
+    for (int row = wid; row < a.M; row += nw) {
+        float dy[NCH][8], xh[NCH][8], gd[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                load8(a.dy + (int64_t)row * a.lddy + c * 8, dy[i]);
+                if (a.dy2) {
+                    float t[8];
+                    load8(a.dy2 + (int64_t)row * a.lddy2 + c * 8, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dy[i][e] += t[e];
+                }
+                load8(a.xhat + (int64_t)row * a.H + c * 8, xh[i]);
+                float g[8];
+                load8f(a.gamma + c * 8, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gd[i][e] = g[e] * dy[i][e];
+                    s1 += gd[i][e];
+                    s2 += gd[i][e] * xh[i][e];
+                    acc[0][i][e] += dy[i][e] * xh[i][e];
+                    acc[1][i][e] += dy[i][e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_h, c2 = wave_sum(s2) * inv_h;
+        const float rstd = a.rstd[row];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float ds[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds[e] = rstd * (gd[i][e] - c1 - xh[i][e] * c2);
+                if (a.dres) store8(a.dres + (int64_t)row * a.lddres + c * 8, ds);
+                if (a.drop.thr) {  // gradient of the dense output: through the (re-generated) dropout mask
+                    const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ds[e] *= drop_mul(a.drop, base + e);
+                }
+                if (a.dx) store8(a.dx + (int64_t)row * a.lddx + c * 8, ds);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[2][i][e] += ds[e];
+            }
+        }
+    }
+    flush_columns<NCH, 3>(acc, lds_f, a.partials, a.H);
+}
+
+// out[slot][c] += sum over slabs; slot s of the slab goes to outs[s] (skipped when NULL).
+__global__ void finalize_kernel(const float* __restrict__ partials, int nslab, int H, float* o0, float* o1, float* o2,
+                                float* o3) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= SLOTS * H) return;
+    const int slot = idx / H, c = idx - slot * H;
+    float* out = slot == 0 ? o0 : slot == 1 ? o1 : slot == 2 ? o2 : o3;
+    if (!out) return;
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) s += partials[((int64_t)b * SLOTS + slot) * H + c];
+    out[c] += s;
+}
+
+// ------------------------------------------------------------------------------------------------- embeddings
+struct EmbFwdArgs {
+    const int64_t* ids; const int64_t* tt; const float* word; const float* pos; const float* type;
+    const float* gamma; const float* beta; bf16_t* y; bf16_t* xhat; float* rstd;
+    int M, S, H, vocab, n_type; float eps; DropCfg drop;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nchunk = a.H >> 3;
+    const float inv_h = 1.f / (float)a.H;
+    for (int row = wid; row < a.M; row += nw) {
+        int64_t id = a.ids[row];
+        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+        int64_t t = a.tt ? a.tt[row] : 0;
+        t = t < 0 ? 0 : (t >= a.n_type ? a.n_type - 1 : t);
+        const int sp = row % a.S;
+        float s[NCH][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float w[8], p[8], ty[8];
+                load8f(a.word + id * a.H + c * 8, w);
+                load8f(a.pos + (int64_t)sp * a.H + c * 8, p);
+                load8f(a.type + t * a.H + c * 8, ty);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[i][e] = (w[e] + p[e]) + ty[e]; sum += s[i][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[i][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(sum) * inv_h;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane + 64 * i < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = s[i][e] - mean; sq += d * d; }
+            }
+        const float rstd = 1.f / sqrtf(wave_sum(sq) * inv_h + a.eps);
+        if (lane == 0 && a.rstd) a.rstd[row] = rstd;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float g[8], b[8], xh[8], o[8];
+                load8f(a.gamma + c * 8, g);
+                load8f(a.beta + c * 8, b);
+                const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[e] = (s[i][e] - mean) * rstd;
+                    o[e] = (g[e] * xh[e] + b[e]) * drop_mul(a.drop, base + e);
+                }
+                store8(a.y + (int64_t)row * a.H + c * 8, o);
+                if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
+            }
+        }
+    }
+}
+
+struct EmbBwdArgs {
+    const bf16_t* dy; const int64_t* ids; const int64_t* tt; const bf16_t* xhat; const float* rstd;
+    const float* gamma; float* dword; float* dpos; float* dtype; float* partials;
+    int M, S, H, vocab, n_type, padding_idx; DropCfg drop;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nchunk = a.H >> 3;
+    const float inv_h = 1.f / (float)a.H;
+    float acc[4][NCH][8];  // dgamma, dbeta, type row 0, type row 1
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[s][i][e] = 0.f;
+
+    for (int row = wid; row < a.M; row += nw) {
+        int64_t id = a.ids[row];
+        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+        int64_t t = a.tt ? a.tt[row] : 0;
+        t = t < 0 ? 0 : (t >= a.n_type ? a.n_type - 1 : t);
+        const int sp = row % a.S;
+        float xh[NCH][8], gd[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float dy[8], g[8];
+                load8(a.dy + (int64_t)row * a.H + c * 8, dy);
+                load8(a.xhat + (int64_t)row * a.H + c * 8, xh[i]);
+                load8f(a.gamma + c * 8, g);
+                const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dl = dy[e] * drop_mul(a.drop, base + e);  // gradient at the LayerNorm output
+                    gd[i][e] = g[e] * dl;
+                    s1 += gd[i][e];
+                    s2 += gd[i][e] * xh[i][e];
+                    acc[0][i][e] += dl * xh[i][e];
+                    acc[1][i][e] += dl;
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_h, c2 = wave_sum(s2) * inv_h;
+        const float rstd = a.rstd[row];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ds = rstd * (gd[i][e] - c1 - xh[i][e] * c2);
+                    // word rows: random rows, 256-B contiguous per wave-instruction -> full-rate f32 atomics
+                    if (id != a.padding_idx) atomicAdd(a.dword + id * a.H + c * 8 + e, ds);
+                    atomicAdd(a.dpos + (int64_t)sp * a.H + c * 8 + e, ds);
+                    if (a.n_type <= 2) {
+                        acc[2][i][e] += t == 0 ? ds : 0.f;
+                        acc[3][i][e] += t == 1 ? ds : 0.f;
+                    } else {
+                        atomicAdd(a.dtype + t * a.H + c * 8 + e, ds);
+                    }
+                }
+            }
+        }
+    }
+    flush_columns<NCH, 4>(acc, lds_f, a.partials, a.H);
+}
+
+inline int pick_nch(int H) { return (H / 8 + 63) / 64; }
+inline int row_grid(int M) { int g = (M + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+inline int bwd_grid(int M) { int g = (M + 3) / 4; return g > BWD_BLOCKS ? BWD_BLOCKS : (g < 1 ? 1 : g); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define DISPATCH_NCH(nch, KERNEL, grid, shmem, st, args)                                                 \
+    switch (nch) {                                                                                       \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(256), shmem, st, args); break;          \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), shmem, st, args); break;          \
+        case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(256), shmem, st, args); break;          \
+        default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), shmem, st, args); break;         \
+    }
+
+}  // namespace
+
+extern "C" int64_t icka_ln_bwd_workspace_floats(int32_t H) { return (int64_t)BWD_BLOCKS * SLOTS * H; }
+
+extern "C" int icka_ln_fwd(const void* x, int64_t ldx, const float* bias, const void* residual, int64_t ldr,
+                           const float* gamma, const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2,
+                           void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop, uint64_t seed,
+                           void* stream) {
+    if (!x || !gamma || !beta || !y) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
+    if (ldx % 8 || ldy % 8 || (residual && ldr % 8) || (y2 && ldy2 % 8)) return ICKA_E_ALIGN;
+    if (!al16(x) || !al16(y) || (residual && !al16(residual)) || (y2 && !al16(y2)) || (xhat && !al16(xhat)) ||
+        (bias && !al16(bias)) || !al16(gamma) || !al16(beta))
+        return ICKA_E_ALIGN;
+    LnFwdArgs a{(const bf16_t*)x, ldx, bias, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)y, ldy,
+                (bf16_t*)y2, ldy2, (bf16_t*)xhat, rstd, M, H, eps, make_drop(p_drop, seed)};
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_NCH(pick_nch(H), ln_fwd_kernel, row_grid(M), 0, st, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat,
+                           const float* rstd, const float* gamma, void* dres, int64_t lddres, void* dx, int64_t lddx,
+                           float* dgamma, float* dbeta, float* dbias, float* partials, int32_t M, int32_t H,
+                           float p_drop, uint64_t seed, void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !partials) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
+    if (lddy % 8 || (dy2 && lddy2 % 8) || (dres && lddres % 8) || (dx && lddx % 8)) return ICKA_E_ALIGN;
+    if (!al16(dy) || (dy2 && !al16(dy2)) || !al16(xhat) || (dres && !al16(dres)) || (dx && !al16(dx)) || !al16(gamma))
+        return ICKA_E_ALIGN;
+    LnBwdArgs a{(const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2, (const bf16_t*)xhat, rstd, gamma,
+                (bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partials, M, H, make_drop(p_drop, seed)};
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = bwd_grid(M);
+    DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, grid, 3 * H * sizeof(float), st, a);
+    ICKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 255) / 256), dim3(256), 0, st, partials, grid, H, dgamma,
+                       dbeta, dbias, (float*)nullptr);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                              const float* type, const float* gamma, const float* beta, void* y, void* xhat,
+                              float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps,
+                              float p_drop, uint64_t seed, void* stream) {
+    if (!ids || !word || !pos || !type || !gamma || !beta || !y) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || n_type <= 0)
+        return ICKA_E_SHAPE;
+    if (!al16(word) || !al16(pos) || !al16(type) || !al16(gamma) || !al16(beta) || !al16(y) || (xhat && !al16(xhat)))
+        return ICKA_E_ALIGN;
+    EmbFwdArgs a{ids, token_type, word, pos, type, gamma, beta, (bf16_t*)y, (bf16_t*)xhat, rstd,
+                 B * S, S, H, vocab, n_type, eps, make_drop(p_drop, seed)};
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_NCH(pick_nch(H), embed_fwd_kernel, row_grid(B * S), 0, st, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
+                              const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype,
+                              float* dgamma, float* dbeta, float* partials, int32_t B, int32_t S, int32_t H,
+                              int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop, uint64_t seed,
+                              void* stream) {
+    if (!dy || !ids || !xhat || !rstd || !gamma || !dword || !dpos || !dtype || !dgamma || !dbeta || !partials)
+        return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || n_type <= 0)
+        return ICKA_E_SHAPE;
+    if (!al16(dy) || !al16(xhat) || !al16(gamma)) return ICKA_E_ALIGN;
+    EmbBwdArgs a{(const bf16_t*)dy, ids, token_type, (const bf16_t*)xhat, rstd, gamma, dword, dpos, dtype, partials,
+                 B * S, S, H, vocab, n_type, padding_idx, make_drop(p_drop, seed)};
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = bwd_grid(B * S);
+    DISPATCH_NCH(pick_nch(H), embed_bwd_kernel, grid, 4 * H * sizeof(float), st, a);
+    ICKA_CHECK_LAUNCH();
+    float* t0 = n_type <= 2 ? dtype : nullptr;
+    float* t1 = n_type == 2 ? dtype + H : nullptr;
+    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 255) / 256), dim3(256), 0, st, partials, grid, H, dgamma,
+                       dbeta, t0, t1);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,256 @@
+"""Tensor-level launchers over the C-ABI (include/icka_hip.h).
+
+PyTorch is used here only for device memory and the current HIP stream: each function checks device / dtype /
+contiguity on the host, then hands raw device pointers + sizes + the stream to libicka_hip.so.  Tensors must live
+on a ROCm device; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ADD, EPI_DGELU, EPI_GATE, EPI_GELU, EPI_NONE, EPI_TANH, GEMM_NN, GEMM_NT, GEMM_TN,
+                   GemmDesc, check)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise TypeError("%s must be a ROCm device tensor (icka_amd has no CPU path), got %s" % (name, t.device))
+
+
+def _mat(t: torch.Tensor, name: str, dtype=BF16) -> None:
+    _dev(t, name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("%s must be a 2-D row-major view (stride(1)==1), got shape %s strides %s"
+                         % (name, tuple(t.shape), t.stride()))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------------- GEMM
+def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+         alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
+         B2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(alpha * op(A,B) [+ op(A2,B2)] + bias) + beta*out.   op: GEMM_NT / GEMM_NN / GEMM_TN."""
+    lib = _lib.load()
+    _mat(A, "A"); _mat(B, "B")
+    if op == GEMM_NT:
+        M, K = A.shape; N, Kb = B.shape
+    elif op == GEMM_NN:
+        M, K = A.shape; Kb, N = B.shape
+    elif op == GEMM_TN:
+        K, M = A.shape; Kb, N = B.shape
+    else:
+        raise ValueError("bad op")
+    if K != Kb:
+        raise ValueError("reduction mismatch: %s vs %s" % (tuple(A.shape), tuple(B.shape)))
+    K1 = 0
+    if A2 is not None or B2 is not None:
+        if A2 is None or B2 is None:
+            raise ValueError("A2 and B2 go together")
+        _mat(A2, "A2"); _mat(B2, "B2")
+        K2 = A2.shape[0] if op == GEMM_TN else A2.shape[1]
+        K1, K = K, K + K2
+    _dev(out, "out")
+    if out.dtype not in (BF16, F32) or out.dim() != 2 or tuple(out.shape) != (M, N) or (N > 1 and out.stride(1) != 1):
+        raise ValueError("out must be [%d,%d] bf16/f32 row-major, got %s %s" % (M, N, tuple(out.shape), out.dtype))
+    d = GemmDesc()
+    d.op, d.M, d.N, d.K, d.K1 = op, M, N, K, K1
+    d.A, d.lda, d.B, d.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
+    d.A2, d.lda2, d.B2, d.ldb2 = _ptr(A2), _ld(A2), _ptr(B2), _ld(B2)
+    d.C, d.ldc, d.c_is_f32 = out.data_ptr(), out.stride(0), int(out.dtype == F32)
+    if out2 is not None:
+        _mat(out2, "out2")
+    d.C2, d.ldc2 = _ptr(out2), _ld(out2)
+    if aux is not None:
+        _mat(aux, "aux")
+    d.aux, d.ldaux = _ptr(aux), _ld(aux)
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.dtype != F32 or bias.numel() != N or not bias.is_contiguous():
+            raise ValueError("bias must be contiguous f32 [N]")
+    d.bias = _ptr(bias)
+    d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
+    check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- LayerNorm
+def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, xhat=None, rstd=None, eps=1e-12, p_drop=0.0, seed=0):
+    lib = _lib.load()
+    _mat(x, "x"); _mat(y, "y")
+    M, H = x.shape
+    check(lib.icka_ln_fwd(x.data_ptr(), x.stride(0), _ptr(bias), _ptr(residual), _ld(residual), gamma.data_ptr(),
+                          beta.data_ptr(), y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), _ptr(xhat), _ptr(rstd),
+                          M, H, eps, p_drop, seed, _stream()), "icka_ln_fwd")
+    return y
+
+
+def ln_bwd_workspace(H: int, device) -> torch.Tensor:
+    return torch.empty(_lib.load().icka_ln_bwd_workspace_floats(H), dtype=F32, device=device)
+
+
+def ln_bwd(dy, xhat, rstd, gamma, *, dy2=None, dres=None, dx=None, dgamma=None, dbeta=None, dbias=None,
+           partials=None, p_drop=0.0, seed=0):
+    lib = _lib.load()
+    _mat(dy, "dy"); _mat(xhat, "xhat")
+    M, H = dy.shape
+    check(lib.icka_ln_bwd(dy.data_ptr(), dy.stride(0), _ptr(dy2), _ld(dy2), xhat.data_ptr(), rstd.data_ptr(),
+                          gamma.data_ptr(), _ptr(dres), _ld(dres), _ptr(dx), _ld(dx), _ptr(dgamma), _ptr(dbeta),
+                          _ptr(dbias), partials.data_ptr(), M, H, p_drop, seed, _stream()), "icka_ln_bwd")
+
+
+# ------------------------------------------------------------------------------------------------- embeddings
+def embed_fwd(ids, token_type, word, pos, typ, gamma, beta, y, *, xhat=None, rstd=None, eps=1e-12, p_drop=0.0,
+              seed=0):
+    lib = _lib.load()
+    _dev(ids, "ids")
+    B, S = ids.shape
+    H = word.shape[1]
+    check(lib.icka_embed_fwd(ids.data_ptr(), _ptr(token_type), word.data_ptr(), pos.data_ptr(), typ.data_ptr(),
+                             gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(xhat), _ptr(rstd), B, S, H,
+                             word.shape[0], typ.shape[0], eps, p_drop, seed, _stream()), "icka_embed_fwd")
+    return y
+
+
+def embed_bwd(dy, ids, token_type, xhat, rstd, gamma, dword, dpos, dtype_, dgamma, dbeta, partials, *,
+              padding_idx=0, p_drop=0.0, seed=0):
+    lib = _lib.load()
+    B, S = ids.shape
+    H = dword.shape[1]
+    check(lib.icka_embed_bwd(dy.data_ptr(), ids.data_ptr(), _ptr(token_type), xhat.data_ptr(), rstd.data_ptr(),
+                             gamma.data_ptr(), dword.data_ptr(), dpos.data_ptr(), dtype_.data_ptr(),
+                             dgamma.data_ptr(), dbeta.data_ptr(), partials.data_ptr(), B, S, H, dword.shape[0],
+                             dtype_.shape[0], padding_idx, p_drop, seed, _stream()), "icka_embed_bwd")
+
+
+# ------------------------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None):
+    """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection)."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        _mat(t, n)
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    check(lib.icka_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                            add_mask.data_ptr(), out.data_ptr(), out.stride(0), _ptr(lse), B, heads, Sq, Skv,
+                            scale, p_drop, seed, _stream()), "icka_attn_fwd")
+    return out
+
+
+def attn_bwd(q, k, v, add_mask, out, dout, lse, delta, dq, dk, dv, B, heads, Sq, Skv, *, p_drop=0.0, seed=0,
+             scale=None):
+    lib = _lib.load()
+    for n, t in (("q", q), ("k", k), ("v", v), ("out", out), ("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
+        _mat(t, n)
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    check(lib.icka_attn_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                            add_mask.data_ptr(), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0),
+                            lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
+                            dk.stride(0), dv.data_ptr(), dv.stride(0), B, heads, Sq, Skv, scale, p_drop, seed,
+                            _stream()), "icka_attn_bwd")
+
+
+# ------------------------------------------------------------------------------------------------- helpers
+def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    _dev(src, "src"); _dev(dst, "dst")
+    check(_lib.load().icka_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "icka_cast")
+    return dst
+
+
+def cast_bf16_to_f32(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    _dev(src, "src"); _dev(dst, "dst")
+    check(_lib.load().icka_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "icka_cast")
+    return dst
+
+
+def additive_mask(mask: torch.Tensor, T: int, out: torch.Tensor) -> torch.Tensor:
+    """mask int64 [B, >=T] (row-major) -> out f32 [B,T] = (1 - mask[:, :T]) * -10000."""
+    _dev(mask, "mask")
+    if mask.dtype != torch.int64 or mask.stride(1) != 1:
+        raise TypeError("mask must be int64 row-major")
+    check(_lib.load().icka_additive_mask(mask.data_ptr(), mask.stride(0), out.data_ptr(), mask.shape[0], T,
+                                         _stream()), "icka_additive_mask")
+    return out
+
+
+def dropout(x, y, *, y2=None, p_drop=0.0, seed=0):
+    _mat(x, "x"); _mat(y, "y")
+    M, H = x.shape
+    check(_lib.load().icka_dropout(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), M, H,
+                                   p_drop, seed, _stream()), "icka_dropout")
+    return y
+
+
+def dropout_mask(n: int, p_drop: float, seed: int, device) -> torch.Tensor:
+    out = torch.empty(n, dtype=F32, device=device)
+    check(_lib.load().icka_dropout_mask(out.data_ptr(), n, p_drop, seed, _stream()), "icka_dropout_mask")
+    return out
+
+
+def regions_to_tokens(src: torch.Tensor, dst: torch.Tensor, B: int, R: int, Cc: int, layout: int) -> torch.Tensor:
+    _dev(src, "src")
+    if src.dtype != F32 or not src.is_contiguous():
+        raise TypeError("region features must be contiguous f32")
+    check(_lib.load().icka_regions_to_tokens(src.data_ptr(), dst.data_ptr(), B, R, Cc, layout, _stream()),
+          "icka_regions_to_tokens")
+    return dst
+
+
+def colsum_workspace(N: int, device) -> torch.Tensor:
+    return torch.empty(_lib.load().icka_colsum_workspace_floats(N), dtype=F32, device=device)
+
+
+def colsum(x, out, partials, accumulate=True):
+    _mat(x, "x")
+    M, N = x.shape
+    check(_lib.load().icka_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), partials.data_ptr(), M, N,
+                                  int(accumulate), _stream()), "icka_colsum")
+    return out
+
+
+def gate_bwd(dout, g, cross, du, dcross, dcross_in=None):
+    _mat(dout, "dout"); _mat(cross, "cross")
+    M, H = dout.shape
+    check(_lib.load().icka_gate_bwd(dout.data_ptr(), dout.stride(0), g.data_ptr(), cross.data_ptr(), cross.stride(0),
+                                    _ptr(dcross_in), _ld(dcross_in), du.data_ptr(), dcross.data_ptr(),
+                                    dcross.stride(0), M, H, _stream()), "icka_gate_bwd")
+
+
+def add_bf16(a, b, out):
+    check(_lib.load().icka_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "icka_add")
+    return out
+
+
+def token_ce(logits, labels, mask, loss_sum, count, dlogits):
+    """logits f32 [M,C]; labels/mask int64 [M]; dlogits bf16 [M, ldd>=C] (unscaled, see scale_by_inv)."""
+    M, Cn = logits.shape
+    check(_lib.load().icka_token_ce(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
+                                    loss_sum.data_ptr(), count.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
+                                    M, Cn, _stream()), "icka_token_ce")
+
+
+def scale_by_inv(x, denom):
+    check(_lib.load().icka_scale_by_inv(x.data_ptr(), denom.data_ptr(), x.numel(), _stream()), "icka_scale_by_inv")
+    return x

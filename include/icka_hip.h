@@ -1,0 +1,157 @@
+/* icka_hip.h -- C-ABI of libicka_hip.so: the MI355X (gfx950) kernels behind the ICKA MNER hot path.
+ *
+ * The reference (buctcurry/ICKA) has no FFI / plugin layer: its hot path is PyTorch nn.Module code that lowers to
+ * ATen kernels.  Each entry point below therefore names the reference *Python* interface
+ * (file:line under /root/reference) whose ATen kernel sequence it replaces.  Plain pointers and sizes only; no
+ * torch types.  Every pointer is a DEVICE pointer unless stated; `stream` is a hipStream_t passed as void*.
+ * bf16 tensors are passed as `const void*` to 2-byte elements; "f32" means float.
+ *
+ * Return value: 0 on success, a positive hipError_t from the launch, or a negative ICKA_E_* argument error.
+ * Nothing here allocates, frees or synchronises: every call is stream-ordered and hipGraph-capturable.
+ */
+#ifndef ICKA_HIP_H
+#define ICKA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICKA_E_SHAPE (-1)   /* dimension out of the supported range */
+#define ICKA_E_ALIGN (-2)   /* pointer / leading dimension not 16-byte aligned where vector access needs it */
+#define ICKA_E_ARG (-3)     /* null pointer or inconsistent descriptor */
+
+/* library / ABI version, and the code-object architecture it was built for ("gfx950") */
+int icka_abi_version(void);
+const char* icka_build_arch(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GEMM on MFMA (v_mfma_f32_16x16x32_bf16), bf16 operands, fp32 accumulate.
+ *   op NT :  C[M,N] = A[M,K]   . B[N,K]^T      (nn.Linear forward: x @ W^T, W is [out,in])
+ *   op NN :  C[M,N] = A[M,K]   . B[K,N]        (input gradient: dY @ W)
+ *   op TN :  C[M,N] = A[K,M]^T . B[K,N]        (weight gradient: dY^T @ X, K = tokens)
+ * Replaces nn.Linear / torch.matmul call sites: Cross_Modal_Interaction_Module.py:479-481 (Q,K,V), :533,:549,:562
+ * (dense layers), :958 (vismap2text), my_bert/cl_modeling.py:1363,:1371 (gates, classifier) and their autograd.
+ * The reduction may be split in two segments read from different buffers (k < K1 from A/B, k >= K1 from A2/B2):
+ * that is how cat(seq, cross) operands (cl_modeling.py:1363-1370) are consumed without materialising the concat.
+ */
+enum { ICKA_GEMM_NT = 0, ICKA_GEMM_NN = 1, ICKA_GEMM_TN = 2 };
+enum {
+    ICKA_EPI_NONE = 0,  /* C = alpha*acc (+bias) (+beta*C)                                                  */
+    ICKA_EPI_GELU = 1,  /* z = acc+bias ; C2 = z ; C = z*0.5*(1+erf(z/sqrt2))   (BertIntermediate, :548-551)   */
+    ICKA_EPI_DGELU = 2, /* C = acc * gelu'(aux)                                  (its backward)                */
+    ICKA_EPI_ADD = 3,   /* C = acc (+bias) + aux                                 (gradient fan-in)             */
+    ICKA_EPI_GATE = 4,  /* g = sigmoid(acc+bias) ; C2 = g ; C = g*aux            (cl_modeling.py:1363-1367)    */
+    ICKA_EPI_TANH = 5   /* C = tanh(acc+bias)                                    (BertPooler, :675-681)        */
+};
+typedef struct icka_gemm_desc {
+    int32_t op;            /* ICKA_GEMM_* */
+    int32_t M, N, K;
+    int32_t K1;            /* 0 = single segment; else multiple of 64, 0 < K1 < K */
+    const void* A;  int64_t lda;    /* bf16 */
+    const void* B;  int64_t ldb;    /* bf16 */
+    const void* A2; int64_t lda2;   /* second-segment operands (K1 > 0) */
+    const void* B2; int64_t ldb2;
+    void* C;  int64_t ldc;  int32_t c_is_f32;   /* output bf16 (0) or f32 (1) */
+    void* C2; int64_t ldc2;                     /* bf16 second output (GELU: z, GATE: g) */
+    const void* aux; int64_t ldaux;             /* bf16 epilogue operand */
+    const float* bias;                          /* f32 [N] or NULL */
+    float alpha, beta;
+    int32_t epilogue;      /* ICKA_EPI_* */
+} icka_gemm_desc;
+int icka_gemm(const icka_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused  y = LayerNorm(dropout(x + bias) + residual)   (BertSelfOutput.forward :561-565, BertOutput.forward
+ * :532-536, BertLayerNorm.forward :518-522: biased variance, eps inside the sqrt).  One wave per row.
+ *   x [M,H] bf16 (row stride ldx), bias f32[H] or NULL, residual [M,H] bf16 (ldr) or NULL, gamma/beta f32[H];
+ *   y [M,H] bf16 (ldy); y2 optional second copy of y (ldy2); xhat [M,H] bf16 contiguous and rstd f32[M] are the
+ *   saved statistics for backward (may be NULL in inference).
+ */
+int icka_ln_fwd(const void* x, int64_t ldx, const float* bias, const void* residual, int64_t ldr,
+                const float* gamma, const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2,
+                void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop, uint64_t seed, void* stream);
+/* Backward of the above.  dy (+ optional dy2) are the incoming gradients of y.  Outputs: dres = gradient of the
+ * residual input (bf16, may be NULL), dx = gradient of x (dropout mask re-generated from seed; may be NULL),
+ * and f32 accumulations (+=) dgamma[H], dbeta[H], dbias[H] (dbias may be NULL).  `partials` is f32 workspace of
+ * icka_ln_bwd_workspace_floats(H) floats. */
+int64_t icka_ln_bwd_workspace_floats(int32_t H);
+int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat, const float* rstd,
+                const float* gamma, void* dres, int64_t lddres, void* dx, int64_t lddx, float* dgamma, float* dbeta,
+                float* dbias, float* partials, int32_t M, int32_t H, float p_drop, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BertEmbeddings.forward (:398-412): y = dropout(LayerNorm(word[ids] + pos[arange(S)] + type[tt])).
+ * Tables are the fp32 master parameters (gathered directly, no shadow copy).  ids/tt are int64 [B*S].
+ */
+int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                   const float* type, const float* gamma, const float* beta, void* y, void* xhat, float* rstd,
+                   int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps, float p_drop,
+                   uint64_t seed, void* stream);
+/* Backward: accumulates (+=) into the f32 gradient tables.  Row `padding_idx` of the word table receives no
+ * gradient (nn.Embedding(padding_idx=0), :387).  partials: icka_ln_bwd_workspace_floats(H) floats. */
+int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
+                   const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma,
+                   float* dbeta, float* partials, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type,
+                   int32_t padding_idx, float p_drop, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused multi-head attention, head size 64 (bert-base 768/12, bert-large 1024/16).
+ * BertSelfAttention.forward (:478-506) and BertCoAttention.forward (:590-624):
+ *   scores = Q.K^T ; scores *= scale ; scores += add_mask[b, key] ; P = softmax ; P = dropout(P) ; O = P.V
+ * Q/K/V/O are bf16 token-major matrices: element (b, s, head, e) at  ptr[(b*S + s)*ld + head*64 + e], so the
+ * fused [M,3H] QKV projection output is consumed in place and O is written head-merged ([M,H], :503-505).
+ * add_mask f32 [B,Skv] is the additive mask (1-mask)*-10000 (:364-372, :962-965).  lse f32 [B,heads,Sq] is saved
+ * for the backward, which recomputes P instead of storing the [B,h,Sq,Skv] probabilities.
+ */
+int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                  const float* add_mask, void* O, int64_t ldo, float* lse, int32_t B, int32_t heads, int32_t Sq,
+                  int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
+/* delta f32 [B,heads,Sq] is workspace (rowsum(dO*O)). */
+int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                  const float* add_mask, const void* O, int64_t ldo, const void* dO, int64_t lddo, const float* lse,
+                  float* delta, void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int32_t B,
+                  int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Element-wise / layout helpers.
+ */
+/* fp32 -> bf16 cast of a flat buffer (parameter shadow refresh); n elements. */
+int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int icka_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* int64 0/1 mask [B, T] (row stride ld, first T columns used) -> additive f32 [B,T] = (1-m)*-10000  (:364-372). */
+int icka_additive_mask(const int64_t* mask, int64_t ld, float* out, int32_t B, int32_t T, void* stream);
+/* y = dropout(x) with the counter-hash mask; the same call with the same seed is its own backward (nn.Dropout,
+ * Cross_Modal_Interaction_Module.py:953).  x,y bf16, row strides ldx/ldy; y2 optional second copy. */
+int icka_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, void* y2, int64_t ldy2, int32_t M, int32_t H,
+                 float p_drop, uint64_t seed, void* stream);
+/* Region features -> bf16 region tokens [B*R, C]:  layout 0: src f32 [B,R,C];  layout 1: src f32 [B,C,R]
+ * (myResnet 'att' output [B,2048,7,7] viewed [B,2048,49] and permuted, :956). */
+int icka_regions_to_tokens(const float* src, void* dst, int32_t B, int32_t R, int32_t C, int32_t layout,
+                           void* stream);
+/* out[N] (+)= column sums of x[M,N] bf16 (bias gradients). */
+int icka_colsum(const void* x, int64_t ldx, float* out, float* partials, int32_t M, int32_t N, int32_t accumulate,
+                void* stream);
+int64_t icka_colsum_workspace_floats(int32_t N);
+/* Gate backward (cl_modeling.py:1363-1367): given dout = d(g*cross), g, cross:
+ *   du = dout*cross*g*(1-g) ;  dcross = dout*g (+ dcross_in if not NULL).  All bf16 [M,H]. */
+int icka_gate_bwd(const void* dout, int64_t lddout, const void* g, const void* cross, int64_t ldcross,
+                  const void* dcross_in, int64_t lddci, void* du, void* dcross, int64_t lddc, int32_t M, int32_t H,
+                  void* stream);
+/* c = a + b (bf16, contiguous n elements; gradient fan-in). */
+int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, void* stream);
+/* Token-level cross-entropy over valid tokens (benchmark loss), fused forward + backward:
+ * logits f32 [M,C] (ld), labels/mask int64 [M]; loss_sum f32[1] += sum of -log p ; count f32[1] += #valid ;
+ * dlogits bf16 [M, ldd] (ldd >= C, pad columns zeroed) = (softmax - onehot) * valid  (caller scales by 1/count). */
+int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* loss_sum,
+                  float* count, void* dlogits, int64_t ldd, int32_t M, int32_t C, void* stream);
+/* x *= s[0] (device scalar reciprocal) for bf16 [n]; used to apply 1/count to dlogits without a host sync. */
+int icka_scale_by_inv(void* x, const float* denom, int64_t n, void* stream);
+/* Debug/test helper: materialise the dropout keep-multiplier (0 or 1/(1-p)) for element indices [0,n) as f32. */
+int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICKA_HIP_H */

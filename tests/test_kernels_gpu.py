@@ -1,0 +1,341 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 evaluation of the same op on the same (bf16-rounded) inputs.
+The end-to-end parity against the CPU oracle / golden fixtures lives in test_model_gpu.py."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _k():
+    from icka_amd import kernels
+    return kernels
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+# --------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (4096, 768, 768), (100, 13, 1536), (77, 200, 72),
+                                   (64, 40, 13), (1152, 768, 2048)])
+def test_gemm_nt(M, N, K):
+    k = _k()
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias = rnd(N, seed=3, dtype=F32)
+    out = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, out, bias=bias)
+    ref = A.float() @ B.float().t() + bias
+    assert rel_err(out, ref) < 1e-2
+    outf = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, outf)
+    assert rel_err(outf, A.float() @ B.float().t()) < 1e-4
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric B catches a transposed / permuted C write (cdna guide section 3)."""
+    k = _k()
+    n = 128
+    A = torch.eye(n, dtype=BF16, device="cuda")
+    B = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).to(BF16)
+    out = torch.empty(n, n, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, out)
+    assert torch.equal(out, B.float().t())
+    k.gemm(k.GEMM_NN, A, B, out)
+    assert torch.equal(out, B.float())
+    k.gemm(k.GEMM_TN, A, B, out)
+    assert torch.equal(out, B.float())
+    k.gemm(k.GEMM_TN, B, A, out)
+    assert torch.equal(out, B.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (4096, 768, 2304), (100, 1536, 13), (200, 72, 77), (256, 3072, 768)])
+def test_gemm_nn(M, N, K):
+    k = _k()
+    A, B = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    if K % 8:   # k-contiguous operand rows must be 16-byte aligned: pad the leading dimension like the callers do
+        Kp = (K + 7) // 8 * 8
+        Ap = torch.zeros(M, Kp, dtype=BF16, device="cuda")
+        Ap[:, :K] = A
+        A = Ap[:, :K]
+    out = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NN, A, B, out)
+    assert rel_err(out, A.float() @ B.float()) < 1e-4
+
+
+@pytest.mark.parametrize("Kt,M,N", [(64, 128, 128), (4096, 768, 768), (4096, 2304, 768), (300, 13, 1536), (1000, 72, 200),
+                                    (4096, 768, 3072)])
+def test_gemm_tn(Kt, M, N):
+    k = _k()
+    A, B = rnd(Kt, M if M % 8 == 0 else 16, seed=1), rnd(Kt, N, seed=2)
+    A = A[:, :M]
+    out = torch.full((M, N), 1.0, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_TN, A, B, out, beta=1.0)   # accumulate into existing gradient
+    ref = A.float().t() @ B.float() + 1.0
+    assert rel_err(out, ref) < 1e-4
+
+
+def test_gemm_epilogues_and_dual_k():
+    k = _k()
+    M, N, K = 256, 384, 128
+    A, B = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5)
+    bias = rnd(N, seed=3, dtype=F32)
+    acc = A.float() @ B.float().t() + bias
+    # GELU (two outputs)
+    g = torch.empty(M, N, dtype=BF16, device="cuda"); z = torch.empty_like(g)
+    k.gemm(k.GEMM_NT, A, B, g, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    assert rel_err(z, acc) < 1e-2
+    assert rel_err(g, torch.nn.functional.gelu(acc)) < 1e-2
+    # DGELU
+    aux = rnd(M, N, seed=4)
+    o = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(o, (A.float() @ B.float().t()) * x.grad) < 1e-2
+    # ADD
+    k.gemm(k.GEMM_NT, A, B, o, bias=bias, epilogue=k.EPI_ADD, aux=aux)
+    assert rel_err(o, acc + aux.float()) < 1e-2
+    # GATE
+    gate = torch.empty_like(o)
+    k.gemm(k.GEMM_NT, A, B, o, bias=bias, epilogue=k.EPI_GATE, aux=aux, out2=gate)
+    assert rel_err(gate, torch.sigmoid(acc)) < 1e-2
+    assert rel_err(o, torch.sigmoid(acc) * aux.float()) < 1e-2
+    # TANH
+    k.gemm(k.GEMM_NT, A, B, o, bias=bias, epilogue=k.EPI_TANH)
+    assert rel_err(o, torch.tanh(acc)) < 1e-2
+    # dual K segment (cat along K without materialising it); A halves live in a wider buffer (strided views)
+    wide = rnd(M, 4 * K, seed=5, scale=0.5)
+    A1, A2 = wide[:, :K], wide[:, 2 * K:3 * K]
+    B1, B2 = rnd(N, K, seed=6, scale=0.5), rnd(N, K, seed=7, scale=0.5)
+    of = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NT, A1, B1, of, A2=A2, B2=B2)
+    ref = A1.float() @ B1.float().t() + A2.float() @ B2.float().t()
+    assert rel_err(of, ref) < 1e-4
+    # bf16 accumulate (beta) and alpha
+    o.fill_(1.0)
+    k.gemm(k.GEMM_NT, A, B, o, alpha=0.5, beta=1.0)
+    assert rel_err(o, 0.5 * (A.float() @ B.float().t()) + 1.0) < 1e-2
+
+
+def test_gemm_bad_args():
+    k = _k()
+    A, B = rnd(64, 64), rnd(64, 64)
+    with pytest.raises(TypeError):
+        k.gemm(k.GEMM_NT, A.cpu(), B, torch.empty(64, 64, dtype=BF16, device="cuda"))
+    with pytest.raises(ValueError):
+        k.gemm(k.GEMM_NT, A, rnd(64, 32), torch.empty(64, 64, dtype=BF16, device="cuda"))
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+def _ln_ref(x, bias, res, gamma, beta, mask, eps):
+    s = (x + bias) * mask + res
+    mu = s.mean(-1, keepdim=True)
+    var = ((s - mu) ** 2).mean(-1, keepdim=True)
+    xh = (s - mu) / torch.sqrt(var + eps)
+    return gamma * xh + beta, xh
+
+
+@pytest.mark.parametrize("M,H,p", [(64, 128, 0.0), (4096, 768, 0.0), (1000, 1024, 0.1), (33, 768, 0.1)])
+def test_ln_fwd_bwd(M, H, p):
+    k = _k()
+    x, res = rnd(M, H, seed=1), rnd(M, H, seed=2)
+    bias, gamma, beta = rnd(H, seed=3, dtype=F32), rnd(H, seed=4, dtype=F32) + 1.0, rnd(H, seed=5, dtype=F32)
+    seed = 0x1234_5678_9abc
+    mask = k.dropout_mask(M * H, p, seed, "cuda").view(M, H)
+    if p > 0:
+        keep = (mask > 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 0.01
+        assert torch.all((mask == 0) | ((mask - 1 / (1 - p)).abs() < 1e-6))
+    y = torch.empty(M, H, dtype=BF16, device="cuda"); y2 = torch.empty(M, 2 * H, dtype=BF16, device="cuda")
+    xhat = torch.empty_like(y); rstd = torch.empty(M, dtype=F32, device="cuda")
+    k.ln_fwd(x, bias, res, gamma, beta, y, y2=y2[:, H:], xhat=xhat, rstd=rstd, eps=1e-12, p_drop=p, seed=seed)
+    xf = x.float().requires_grad_(True); rf = res.float().requires_grad_(True)
+    bf = bias.clone().requires_grad_(True); gf = gamma.clone().requires_grad_(True); b2 = beta.clone().requires_grad_(True)
+    yref, xhref = _ln_ref(xf, bf, rf, gf, b2, mask, 1e-12)
+    assert rel_err(y, yref) < 1e-2
+    assert torch.equal(y2[:, H:], y)
+    assert rel_err(xhat, xhref) < 1e-2
+    dy = rnd(M, H, seed=6)
+    yref.backward(dy.float())
+    dres = torch.empty_like(y); dx = torch.empty_like(y)
+    dg = torch.zeros(H, dtype=F32, device="cuda"); db = torch.zeros_like(dg); dbias = torch.zeros_like(dg)
+    ws = k.ln_bwd_workspace(H, "cuda")
+    k.ln_bwd(dy, xhat, rstd, gamma, dres=dres, dx=dx, dgamma=dg, dbeta=db, dbias=dbias, partials=ws, p_drop=p, seed=seed)
+    assert rel_err(dres, rf.grad) < 2e-2
+    assert rel_err(dx, xf.grad) < 2e-2
+    assert rel_err(dg, gf.grad) < 2e-2
+    assert rel_err(db, b2.grad) < 2e-2
+    assert rel_err(dbias, bf.grad) < 2e-2
+    # accumulate semantics (+=) and the dy2 fan-in
+    k.ln_bwd(dy, xhat, rstd, gamma, dy2=dy, dres=dres, dgamma=dg, dbeta=db, partials=ws, p_drop=p, seed=seed)
+    assert rel_err(db, 3 * b2.grad) < 2e-2
+    assert rel_err(dres, 2 * rf.grad) < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k_, v, add_mask, dmask, B, h, Sq, Skv):
+    """q [B*Sq, h*64] etc. (fp32, requires_grad) -> out [B*Sq, h*64]"""
+    qh = q.view(B, Sq, h, 64).permute(0, 2, 1, 3)
+    kh = k_.view(B, Skv, h, 64).permute(0, 2, 1, 3)
+    vh = v.view(B, Skv, h, 64).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / 8.0 + add_mask[:, None, None, :]
+    p = torch.softmax(s, -1) * dmask
+    o = p @ vh
+    return o.permute(0, 2, 1, 3).reshape(B * Sq, h * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,h,Sq,Skv,p", [(2, 2, 64, 64, 0.0), (2, 12, 128, 128, 0.0), (3, 2, 100, 49, 0.0),
+                                          (2, 4, 128, 36, 0.1), (2, 3, 128, 128, 0.1), (1, 2, 32, 200, 0.0),
+                                          (1, 16, 256, 256, 0.1)])
+def test_attention_fwd_bwd(B, h, Sq, Skv, p):
+    k = _k()
+    H = h * 64
+    fused = rnd(B * Sq, 3 * H, seed=1)          # q lives inside a fused [M,3H] buffer (strided view)
+    q = fused[:, H:2 * H]
+    kk, v = rnd(B * Skv, H, seed=2), rnd(B * Skv, H, seed=3)
+    lens = torch.randint(1, Skv + 1, (B,), generator=torch.Generator().manual_seed(4))
+    m01 = (torch.arange(Skv)[None, :] < lens[:, None]).long().cuda()
+    add_mask = torch.empty(B, Skv, dtype=F32, device="cuda")
+    k.additive_mask(m01, Skv, add_mask)
+    assert torch.equal(add_mask, (1.0 - m01.float()) * -10000.0)
+    seed = 0xabcdef12345
+    dmask = k.dropout_mask(B * h * Sq * Skv, p, seed, "cuda").view(B, h, Sq, Skv)
+    out = torch.empty(B * Sq, H, dtype=BF16, device="cuda")
+    lse = torch.empty(B, h, Sq, dtype=F32, device="cuda")
+    k.attn_fwd(q, kk, v, add_mask, out, lse, B, h, Sq, Skv, p_drop=p, seed=seed)
+    qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, kk, v))
+    oref, lref = _attn_ref(qf, kf, vf, add_mask, dmask, B, h, Sq, Skv)
+    assert rel_err(out, oref) < 1.5e-2
+    assert (lse - lref).abs().max().item() < 2e-2
+    dout = rnd(B * Sq, H, seed=5)
+    oref.backward(dout.float())
+    dq = torch.empty(B * Sq, H, dtype=BF16, device="cuda")
+    dkv = torch.empty(B * Skv, 2 * H, dtype=BF16, device="cuda")
+    delta = torch.empty(B, h, Sq, dtype=F32, device="cuda")
+    k.attn_bwd(q, kk, v, add_mask, out, dout, lse, delta, dq, dkv[:, :H], dkv[:, H:], B, h, Sq, Skv, p_drop=p, seed=seed)
+    assert rel_err(dq, qf.grad) < 3e-2
+    assert rel_err(dkv[:, :H], kf.grad) < 3e-2
+    assert rel_err(dkv[:, H:], vf.grad) < 3e-2
+
+
+def test_attention_fully_masked_row_matches_reference_softmax():
+    """all keys masked (-10000 everywhere): the reference's softmax degenerates to softmax of the raw scores."""
+    k = _k()
+    B, h, S = 1, 1, 64
+    q, kk, v = rnd(S, 64, seed=1), rnd(S, 64, seed=2), rnd(S, 64, seed=3)
+    add_mask = torch.full((B, S), -10000.0, dtype=F32, device="cuda")
+    out = torch.empty(S, 64, dtype=BF16, device="cuda"); lse = torch.empty(B, h, S, dtype=F32, device="cuda")
+    k.attn_fwd(q, kk, v, add_mask, out, lse, B, h, S, S)
+    s = q.float() @ kk.float().t() / 8.0 - 10000.0
+    ref = torch.softmax(s, -1) @ v.float()
+    assert rel_err(out, ref) < 1.5e-2
+
+
+# ----------------------------------------------------------------------------------------------- embeddings
+@pytest.mark.parametrize("B,S,H,p", [(2, 32, 128, 0.0), (8, 128, 768, 0.1)])
+def test_embeddings(B, S, H, p):
+    k = _k()
+    V = 1000
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, V, (B, S), generator=g).cuda()
+    ids[0, :5] = 0          # padding rows
+    ids[1, :4] = 7          # repeated id
+    tt = torch.randint(0, 2, (B, S), generator=g).cuda()
+    word, pos, typ = rnd(V, H, seed=2, dtype=F32), rnd(512, H, seed=3, dtype=F32), rnd(2, H, seed=4, dtype=F32)
+    gamma, beta = rnd(H, seed=5, dtype=F32) + 1.0, rnd(H, seed=6, dtype=F32)
+    seed = 991
+    mask = k.dropout_mask(B * S * H, p, seed, "cuda").view(B, S, H)
+    y = torch.empty(B * S, H, dtype=BF16, device="cuda"); xhat = torch.empty_like(y)
+    rstd = torch.empty(B * S, dtype=F32, device="cuda")
+    k.embed_fwd(ids, tt, word, pos, typ, gamma, beta, y, xhat=xhat, rstd=rstd, p_drop=p, seed=seed)
+    w, po, ty, ga, be = (t.clone().requires_grad_(True) for t in (word, pos, typ, gamma, beta))
+    e = torch.nn.functional.embedding(ids, w, padding_idx=0) + po[:S][None] + ty[tt]
+    mu = e.mean(-1, keepdim=True); var = ((e - mu) ** 2).mean(-1, keepdim=True)
+    ref = (ga * ((e - mu) / torch.sqrt(var + 1e-12)) + be) * mask
+    assert rel_err(y.view(B, S, H), ref) < 1e-2
+    dy = rnd(B * S, H, seed=7)
+    ref.backward(dy.float().view(B, S, H))
+    dw, dp, dt = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+    ws = k.ln_bwd_workspace(H, "cuda")
+    k.embed_bwd(dy, ids, tt, xhat, rstd, gamma, dw, dp, dt, dg, db, ws, padding_idx=0, p_drop=p, seed=seed)
+    assert dw[0].abs().max().item() == 0.0
+    assert rel_err(dw, w.grad) < 2e-2
+    assert rel_err(dp, po.grad) < 2e-2
+    assert rel_err(dt, ty.grad) < 2e-2
+    assert rel_err(dg, ga.grad) < 2e-2
+    assert rel_err(db, be.grad) < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------- helpers
+def test_elementwise_helpers():
+    k = _k()
+    x = torch.randn(1000003, device="cuda")
+    xb = torch.empty(x.numel() + 5, dtype=BF16, device="cuda")[:x.numel()]
+    k.cast_f32_to_bf16(x, xb)
+    assert torch.equal(xb, x.to(BF16))
+    back = torch.empty_like(x)
+    k.cast_bf16_to_f32(xb, back)
+    assert torch.equal(back, xb.float())
+    # regions: both layouts
+    B, R, Cc = 3, 49, 2048
+    feats = torch.randn(B, Cc, 7, 7, device="cuda")
+    tok = torch.empty(B * R, Cc, dtype=BF16, device="cuda")
+    k.regions_to_tokens(feats, tok, B, R, Cc, 1)
+    assert torch.equal(tok.view(B, R, Cc), feats.view(B, Cc, R).permute(0, 2, 1).to(BF16))
+    f2 = torch.randn(B, 36, Cc, device="cuda")
+    tok2 = torch.empty(B * 36, Cc, dtype=BF16, device="cuda")
+    k.regions_to_tokens(f2, tok2, B, 36, Cc, 0)
+    assert torch.equal(tok2.view(B, 36, Cc), f2.to(BF16))
+    # colsum (bias gradients), incl. ragged N with a padded leading dimension
+    for M, N, ld in [(4096, 768, 768), (4096, 2304, 2304), (300, 13, 16), (65, 3072, 3072)]:
+        buf = rnd(M, ld, seed=M)
+        xs = buf[:, :N]
+        out = torch.ones(N, dtype=F32, device="cuda")
+        k.colsum(xs, out, k.colsum_workspace(N, "cuda"), accumulate=True)
+        assert rel_err(out, xs.float().sum(0) + 1.0) < 1e-4
+    # dropout is its own backward; add; gate backward
+    M, H = 513, 768
+    a = rnd(M, H, seed=1); y = torch.empty_like(a); y2 = torch.empty_like(a)
+    k.dropout(a, y, y2=y2, p_drop=0.1, seed=5)
+    mask = k.dropout_mask(M * H, 0.1, 5, "cuda").view(M, H)
+    assert rel_err(y, a.float() * mask) < 1e-2 and torch.equal(y, y2)
+    b = rnd(M, H, seed=2); c = torch.empty_like(a)
+    k.add_bf16(a, b, c)
+    assert torch.equal(c, (a.float() + b.float()).to(BF16))
+    dout, gte, cross, dci = rnd(M, H, seed=3), torch.sigmoid(rnd(M, H, seed=4).float()).to(BF16), rnd(M, H, seed=5), rnd(M, H, seed=6)
+    du = torch.empty_like(a); dc = torch.empty_like(a)
+    k.gate_bwd(dout, gte, cross, du, dc, dcross_in=dci)
+    gf = gte.float()
+    assert rel_err(du, dout.float() * cross.float() * gf * (1 - gf)) < 1e-2
+    assert rel_err(dc, dout.float() * gf + dci.float()) < 1e-2
+
+
+def test_token_ce():
+    k = _k()
+    M, Cn = 4096, 13
+    logits = torch.randn(M, Cn, device="cuda") * 3
+    labels = torch.randint(0, Cn, (M,), device="cuda")
+    mask = (torch.rand(M, device="cuda") > 0.4).long()
+    loss_sum = torch.zeros(1, device="cuda"); count = torch.zeros(1, device="cuda")
+    dl = torch.empty(M, 16, dtype=BF16, device="cuda")
+    k.token_ce(logits, labels, mask, loss_sum, count, dl)
+    k.scale_by_inv(dl, count)
+    lg = logits.clone().requires_grad_(True)
+    tgt = torch.where(mask.bool(), labels, torch.full_like(labels, -100))
+    ref = torch.nn.functional.cross_entropy(lg, tgt, ignore_index=-100)
+    ref.backward()
+    assert abs((loss_sum / count).item() - ref.item()) < 1e-4
+    assert count.item() == mask.sum().item()
+    assert rel_err(dl[:, :Cn], lg.grad) < 1e-2
+    assert dl[:, Cn:].abs().max().item() == 0.0
