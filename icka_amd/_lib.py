@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("C", c_vp), ("ldc", c_i64), ("c_is_f32", c_i32),
         ("C2", c_vp), ("ldc2", c_i64),
         ("aux", c_vp), ("ldaux", c_i64),
-        ("bias", c_vp),
+        ("bias", c_vp), ("bias2", c_vp),
         ("alpha", c_f32), ("beta", c_f32),
         ("epilogue", c_i32),
     ]
@@ -39,15 +39,15 @@ PROTOTYPES = {
     "icka_abi_version": (c_i32, []),
     "icka_build_arch": (C.c_char_p, []),
     "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
-    "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
-                            c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
+                            c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_ln_bwd_workspace_floats": (c_i64, [c_i32]),
     "icka_ln_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
-                            c_vp, c_i32, c_i32, c_f32, c_u64, c_vp]),
-    "icka_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
-                               c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+                            c_vp, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
+    "icka_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                               c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
-                               c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp]),
+                               c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
     "icka_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
@@ -55,6 +55,7 @@ PROTOTYPES = {
                               c_vp]),
     "icka_cast_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "icka_cast_bf16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "icka_cast_pad_f32_to_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "icka_additive_mask": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),
     "icka_dropout": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_u64, c_vp]),
     "icka_regions_to_tokens": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -63,7 +64,8 @@ PROTOTYPES = {
     "icka_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "icka_add_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "icka_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
-    "icka_scale_by_inv": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "icka_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "icka_scalar_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "icka_dropout_mask": (c_i32, [c_vp, c_i64, c_f32, c_u64, c_vp]),
 }
 

@@ -1,0 +1,238 @@
+"""ParamArena: one flat HBM allocation for all parameters of a module tree.
+
+MI355X-first memory layout (288 GB HBM3E per GPU): instead of ~200 small parameter tensors we keep
+  * ``flat``    fp32 master copy  -- the nn.Parameters are *views* into it (state_dict keys/shapes unchanged),
+  * ``shadow``  bf16 copy of the same layout -- what the MFMA GEMMs read; refreshed by ONE cast launch when any
+                parameter's version counter moved (optimizer step, load_state_dict),
+  * ``gflat``   fp32 gradients      -- ``p.grad`` are views into it; backward kernels write straight into it
+                (GEMM beta = 0/1), so data-parallel all-reduce runs over a few large contiguous slices.
+Parameters are laid out in registration (= execution) order, each slot aligned to 8 elements (16 B in bf16), so the
+reference's separate query/key/value Linear layers are physically one [3H,H] matrix (fused QKV GEMM) while their
+state_dict entries stay separate.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+ALIGN = 8
+
+
+class Slot(object):
+    __slots__ = ("name", "off", "numel", "shape", "param", "live")
+
+    def __init__(self, name, off, numel, shape, param):
+        self.name, self.off, self.numel, self.shape, self.param = name, off, numel, tuple(shape), param
+        self.live = False   # gflat slot holds a valid (accumulating) gradient for the current cycle
+
+
+class ParamArena(object):
+    def __init__(self, root: nn.Module):
+        named = []
+        seen = set()
+        for name, p in _collect(root, ""):
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            named.append((name, p))
+        if not named:
+            raise ValueError("module has no parameters")
+        dev = named[0][1].device
+        for name, p in named:
+            if p.device != dev:
+                raise ValueError("all parameters must be on one device (%s is on %s, expected %s)" % (name, p.device, dev))
+            if p.dtype != torch.float32:
+                raise TypeError("parameters are fp32 masters (bf16 shadows are derived); %s is %s" % (name, p.dtype))
+        off = 0
+        self.slots: Dict[int, Slot] = {}
+        self.order: List[Slot] = []
+        for name, p in named:
+            s = Slot(name, off, p.numel(), p.shape, p)
+            self.slots[id(p)] = s
+            self.order.append(s)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.device = dev
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        with torch.no_grad():
+            for s in self.order:
+                view = self.flat[s.off:s.off + s.numel].view(s.shape)
+                view.copy_(s.param.data)
+                s.param.data = view
+        self._synced = None
+        self._touched: List[Slot] = []
+        self._ws: Dict[Tuple[str, int], torch.Tensor] = {}
+        # autograd anchor: a leaf that requires grad, passed to every Function so that backward runs even when
+        # no *tensor input* requires grad (parameters are read from the arena, not passed through autograd)
+        self.anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+        self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        self._seed_ctr = 0
+
+    # ------------------------------------------------------------------------------------------ dropout seeds
+    def set_seed(self, seed: int) -> None:
+        self._seed_base, self._seed_ctr = seed & 0xFFFFFFFFFFFFFFFF, 0
+
+    def next_seed(self) -> int:
+        """splitmix64 stream: a fresh 64-bit seed per dropout site call; forward stores it for its backward."""
+        self._seed_ctr += 1
+        z = (self._seed_base + self._seed_ctr * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    # ------------------------------------------------------------------------------------------ validity
+    def valid_for(self, root: nn.Module) -> bool:
+        """False when a parameter was re-allocated behind our back (.to(), .cuda(), new Parameter objects).
+        Cheap by design (runs in every module forward): .to()/.cuda() move ALL parameters, so checking the first
+        one of the sub-tree is enough."""
+        for p in root.parameters():
+            s = self.slots.get(id(p))
+            return s is not None and p.data_ptr() == self.flat.data_ptr() + 4 * s.off
+        return False
+
+    # ------------------------------------------------------------------------------------------ views
+    def slot(self, p: nn.Parameter) -> Slot:
+        return self.slots[id(p)]
+
+    def w(self, p: nn.Parameter) -> torch.Tensor:
+        """bf16 shadow view of a parameter."""
+        s = self.slots[id(p)]
+        return self.shadow[s.off:s.off + s.numel].view(s.shape)
+
+    def w_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
+        """bf16 view of several 2-D [o_i, in] parameters as ONE [sum o_i, in] matrix (must be adjacent slots)."""
+        first, rows = self._adjacent(ps)
+        return self.shadow[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+
+    def f_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
+        """fp32 master view of adjacent 1-D parameters as one vector (fused biases)."""
+        first, n = self._adjacent(ps)
+        return self.flat[first.off:first.off + n]
+
+    def g(self, p: nn.Parameter) -> torch.Tensor:
+        s = self.slots[id(p)]
+        return self.gflat[s.off:s.off + s.numel].view(s.shape)
+
+    def g_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
+        first, rows = self._adjacent(ps)
+        if len(first.shape) == 2:
+            return self.gflat[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+        return self.gflat[first.off:first.off + rows]
+
+    def _adjacent(self, ps: Sequence[nn.Parameter]):
+        sl = [self.slots[id(p)] for p in ps]
+        rows = 0
+        for a, b in zip(sl[:-1], sl[1:]):
+            if a.off + a.numel != b.off or a.shape[1:] != b.shape[1:]:
+                raise RuntimeError("parameters %s / %s are not adjacent in the arena" % (a.name, b.name))
+        for s in sl:
+            rows += s.shape[0]
+        return sl[0], rows
+
+    # ------------------------------------------------------------------------------------------ bf16 shadow
+    def sync(self) -> None:
+        """Refresh the bf16 shadow if any parameter changed since the last refresh (one cast launch)."""
+        if self.shadow is None:
+            raise RuntimeError("ParamArena.sync: bf16 shadows need a ROCm device (no CPU path)")
+        v = 0
+        for s in self.order:
+            v += s.param._version
+        if v != self._synced:
+            from . import kernels
+            kernels.cast_f32_to_bf16(self.flat, self.shadow)
+            self._synced = v
+
+    def mark_dirty(self) -> None:
+        self._synced = None
+
+    # ------------------------------------------------------------------------------------------ gradients
+    def begin_step(self) -> None:
+        """Called at the start of a forward pass: if the user dropped the gradients (optimizer.zero_grad(), whose
+        default sets p.grad = None) the next backward overwrites instead of accumulating."""
+        if self._touched and self._touched[0].param.grad is None:
+            for s in self._touched:
+                s.live = False
+            self._touched = []
+
+    def grad_beta(self, ps) -> float:
+        """beta for a gradient write into the slot(s): 0.0 on the first write of an accumulation cycle, else 1.0.
+        Also (re)attaches p.grad to the arena view."""
+        if isinstance(ps, nn.Parameter):
+            ps = (ps,)
+        live = None
+        for p in ps:
+            s = self.slots[id(p)]
+            if live is None:
+                live = s.live
+            elif live != s.live:
+                raise RuntimeError("fused parameter group %s has mixed gradient state" % s.name)
+            if not s.live:
+                s.live = True
+                self._touched.append(s)
+            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * s.off:
+                p.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
+        return 1.0 if live else 0.0
+
+    def zero_grad(self) -> None:
+        self.gflat.zero_()
+        for s in self.order:
+            s.live = False
+        self._touched = []
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def workspace(self, tag: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        key = (tag, numel)
+        t = self._ws.get(key)
+        if t is None or t.dtype != dtype:
+            t = torch.empty(numel, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    # ------------------------------------------------------------------------------------------ DP buckets
+    def buckets(self, bucket_elems: int) -> List[Tuple[int, int]]:
+        """Contiguous [start, end) element ranges of gflat, from the END of the arena towards the start (the order
+        in which backward produces gradients), each at least ``bucket_elems`` long (last one takes the rest)."""
+        out = []
+        end = self.total
+        cur = end
+        for s in reversed(self.order):
+            cur = s.off
+            if end - cur >= bucket_elems:
+                out.append((cur, end))
+                end = cur
+        if end > 0:
+            out.append((0, end))
+        return out
+
+
+def _collect(module: nn.Module, prefix: str):
+    """Parameters in arena order: registration order, except that a module may impose the order of its whole
+    sub-tree through ``icka_param_order()`` (attention blocks put query/key/value weights, then their biases,
+    back to back so that they form one fused [3H,H] operand)."""
+    order = getattr(module, "icka_param_order", None)
+    if order is not None:
+        for name, p in order():
+            yield prefix + name, p
+        return
+    for name, p in module._parameters.items():
+        if p is not None:
+            yield prefix + name, p
+    for cname, child in module._modules.items():
+        if child is not None:
+            yield from _collect(child, prefix + cname + ".")
+
+
+def arena_of(module: nn.Module) -> ParamArena:
+    """Get (or lazily build / rebuild) the arena that owns ``module``'s parameters.  The arena is created by the
+    outermost icka module whose forward runs first and is shared with all its sub-modules."""
+    a = getattr(module, "_icka_arena", None)
+    if a is not None and a.valid_for(module):
+        return a
+    a = ParamArena(module)
+    for m in module.modules():
+        object.__setattr__(m, "_icka_arena", a)
+    return a

@@ -38,6 +38,16 @@ __global__ void cast_b2f_kernel(const bf16_t* __restrict__ src, float* __restric
         dst[i] = bf2f(src[i]);
 }
 
+__global__ void cast_pad_kernel(const float* __restrict__ src, int64_t lds, bf16_t* __restrict__ dst, int64_t ldd, int M,
+                                int N) {
+    const int64_t total = (int64_t)M * ldd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ldd;
+        const int c = (int)(i - r * ldd);
+        dst[i] = f2bf(c < N ? src[r * lds + c] : 0.f);
+    }
+}
+
 __global__ void additive_mask_kernel(const int64_t* __restrict__ mask, int64_t ld, float* __restrict__ out, int B, int T) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * T) return;
@@ -196,10 +206,14 @@ __global__ __launch_bounds__(256) void token_ce_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && cnt > 0.f) { atomicAdd(loss_sum, loss); atomicAdd(count, cnt); }
 }
 
-__global__ void scale_inv_kernel(bf16_t* x, const float* denom, int64_t n) {
-    const float s = 1.f / fmaxf(denom[0], 1.f);
+__global__ void scale_ratio_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* num,
+                                   const float* den, int64_t n) {
+    const float s = (num ? num[0] : 1.f) / (den ? fmaxf(den[0], 1.f) : 1.f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        x[i] = f2bf(bf2f(x[i]) * s);
+        y[i] = f2bf(bf2f(x[i]) * s);
+}
+__global__ void scalar_ratio_kernel(float* out, const float* num, const float* den) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = num[0] / fmaxf(den[0], 1.f);
 }
 
 }  // namespace
@@ -220,6 +234,15 @@ extern "C" int icka_cast_bf16_to_f32(const void* src, float* dst, int64_t n, voi
     if (!src || !dst) return ICKA_E_ARG;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_cast_pad_f32_to_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int32_t M, int32_t N,
+                                         void* stream) {
+    if (!src || !dst) return ICKA_E_ARG;
+    if (M <= 0 || N <= 0 || ldd < N || lds < N) return ICKA_E_SHAPE;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for((int64_t)M * ldd)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                       (bf16_t*)dst, ldd, M, N);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
@@ -308,10 +331,18 @@ extern "C" int icka_token_ce(const float* logits, int64_t ld, const int64_t* lab
     ICKA_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int icka_scale_by_inv(void* x, const float* denom, int64_t n, void* stream) {
-    if (!x || !denom) return ICKA_E_ARG;
+extern "C" int icka_scale_by_ratio(const void* x, void* y, const float* num, const float* den, int64_t n,
+                                   void* stream) {
+    if (!x || !y) return ICKA_E_ARG;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(scale_inv_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, denom, n);
+    hipLaunchKernelGGL(scale_ratio_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, num, den, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_scalar_ratio(float* out, const float* num, const float* den, void* stream) {
+    if (!out || !num || !den) return ICKA_E_ARG;
+    hipLaunchKernelGGL(scalar_ratio_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, num, den);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

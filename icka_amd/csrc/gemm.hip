@@ -23,7 +23,7 @@ struct GemmArgs {
     void* C;  int64_t ldc;
     bf16_t* C2; int64_t ldc2;
     const bf16_t* aux; int64_t ldaux;
-    const float* bias;
+    const float* bias; const float* bias2;
     float alpha, beta;
     int epi, c_f32;
     int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
@@ -132,6 +132,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
     if (g.bias) {
         for (int r = 0; r < 4; ++r)
             if (r < nvalid) v[r] += g.bias[n + r];
+    }
+    if (g.bias2) {
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) v[r] += g.bias2[n + r];
     }
     float a[4];
     switch (g.epi) {
@@ -285,7 +289,7 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     g.A = (const bf16_t*)d->A; g.lda = d->lda; g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
     g.A2 = (const bf16_t*)d->A2; g.lda2 = d->lda2; g.B2 = (const bf16_t*)d->B2; g.ldb2 = d->ldb2;
     g.C = d->C; g.ldc = d->ldc; g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
-    g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux; g.bias = d->bias;
+    g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux; g.bias = d->bias; g.bias2 = d->bias2;
     g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));

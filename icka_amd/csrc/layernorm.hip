@@ -13,9 +13,9 @@ constexpr int BWD_BLOCKS = 256;     // partial slabs per backward launch
 constexpr int SLOTS = 4;            // column-sum slots per slab
 
 struct LnFwdArgs {
-    const bf16_t* x; int64_t ldx; const float* bias; const bf16_t* res; int64_t ldr;
+    const void* x; int64_t ldx; int x_f32; const float* bias; const void* res; int64_t ldr; int r_f32;
     const float* gamma; const float* beta;
-    bf16_t* y; int64_t ldy; bf16_t* y2; int64_t ldy2; bf16_t* xhat; float* rstd;
+    bf16_t* y; int64_t ldy; bf16_t* y2; int64_t ldy2; float* yf; bf16_t* xhat; float* rstd;
     int M, H; float eps; DropCfg drop;
 };
 
@@ -27,6 +27,15 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
 __device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+// row element loads in either precision (GEMM outputs / the residual stream are kept in f32, operands in bf16)
+__device__ __forceinline__ void load8x(const void* base, int is_f32, int64_t off, float (&o)[8]) {
+    if (is_f32) load8f(reinterpret_cast<const float*>(base) + off, o);
+    else load8(reinterpret_cast<const bf16_t*>(base) + off, o);
+}
+__device__ __forceinline__ void store8f(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     bf16x8 o;
@@ -48,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                load8(a.x + (int64_t)row * a.ldx + c * 8, s[i]);
+                load8x(a.x, a.x_f32, (int64_t)row * a.ldx + c * 8, s[i]);
                 if (a.bias) {
                     float b[8];
                     load8f(a.bias + c * 8, b);
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
                 }
                 if (a.res) {
                     float r[8];
-                    load8(a.res + (int64_t)row * a.ldr + c * 8, r);
+                    load8x(a.res, a.r_f32, (int64_t)row * a.ldr + c * 8, r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) s[i][e] += r[e];
                 }
@@ -95,6 +104,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
                 for (int e = 0; e < 8; ++e) { xh[e] = (s[i][e] - mean) * rstd; o[e] = g[e] * xh[e] + b[e]; }
                 store8(a.y + (int64_t)row * a.ldy + c * 8, o);
                 if (a.y2) store8(a.y2 + (int64_t)row * a.ldy2 + c * 8, o);
+                if (a.yf) store8f(a.yf + (int64_t)row * a.H + c * 8, o);
                 if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
             }
         }
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 
 // out[slot][c] += sum over slabs; slot s of the slab goes to outs[s] (skipped when NULL).
 __global__ void finalize_kernel(const float* __restrict__ partials, int nslab, int H, float* o0, float* o1, float* o2,
-                                float* o3) {
+                                float* o3, int accumulate) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= SLOTS * H) return;
     const int slot = idx / H, c = idx - slot * H;
@@ -204,13 +214,13 @@ __global__ void finalize_kernel(const float* __restrict__ partials, int nslab, i
     if (!out) return;
     float s = 0.f;
     for (int b = 0; b < nslab; ++b) s += partials[((int64_t)b * SLOTS + slot) * H + c];
-    out[c] += s;
+    out[c] = accumulate ? out[c] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------------- embeddings
 struct EmbFwdArgs {
     const int64_t* ids; const int64_t* tt; const float* word; const float* pos; const float* type;
-    const float* gamma; const float* beta; bf16_t* y; bf16_t* xhat; float* rstd;
+    const float* gamma; const float* beta; bf16_t* y; float* yf; bf16_t* xhat; float* rstd;
     int M, S, H, vocab, n_type; float eps; DropCfg drop;
 };
 
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a) {
                     o[e] = (g[e] * xh[e] + b[e]) * drop_mul(a.drop, base + e);
                 }
                 store8(a.y + (int64_t)row * a.H + c * 8, o);
+                if (a.yf) store8f(a.yf + (int64_t)row * a.H + c * 8, o);
                 if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
             }
         }
@@ -364,18 +375,18 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int64_t icka_ln_bwd_workspace_floats(int32_t H) { return (int64_t)BWD_BLOCKS * SLOTS * H; }
 
-extern "C" int icka_ln_fwd(const void* x, int64_t ldx, const float* bias, const void* residual, int64_t ldr,
-                           const float* gamma, const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2,
-                           void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop, uint64_t seed,
-                           void* stream) {
+extern "C" int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual,
+                           int64_t ldr, int32_t res_is_f32, const float* gamma, const float* beta, void* y,
+                           int64_t ldy, void* y2, int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M,
+                           int32_t H, float eps, float p_drop, uint64_t seed, void* stream) {
     if (!x || !gamma || !beta || !y) return ICKA_E_ARG;
     if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
     if (ldx % 8 || ldy % 8 || (residual && ldr % 8) || (y2 && ldy2 % 8)) return ICKA_E_ALIGN;
     if (!al16(x) || !al16(y) || (residual && !al16(residual)) || (y2 && !al16(y2)) || (xhat && !al16(xhat)) ||
-        (bias && !al16(bias)) || !al16(gamma) || !al16(beta))
+        (bias && !al16(bias)) || !al16(gamma) || !al16(beta) || (y_f32 && !al16(y_f32)))
         return ICKA_E_ALIGN;
-    LnFwdArgs a{(const bf16_t*)x, ldx, bias, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)y, ldy,
-                (bf16_t*)y2, ldy2, (bf16_t*)xhat, rstd, M, H, eps, make_drop(p_drop, seed)};
+    LnFwdArgs a{x, ldx, x_is_f32, bias, residual, ldr, res_is_f32, gamma, beta, (bf16_t*)y, ldy,
+                (bf16_t*)y2, ldy2, y_f32, (bf16_t*)xhat, rstd, M, H, eps, make_drop(p_drop, seed)};
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), ln_fwd_kernel, row_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
@@ -385,7 +396,7 @@ extern "C" int icka_ln_fwd(const void* x, int64_t ldx, const float* bias, const 
 extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat,
                            const float* rstd, const float* gamma, void* dres, int64_t lddres, void* dx, int64_t lddx,
                            float* dgamma, float* dbeta, float* dbias, float* partials, int32_t M, int32_t H,
-                           float p_drop, uint64_t seed, void* stream) {
+                           float p_drop, uint64_t seed, int32_t accumulate, void* stream) {
     if (!dy || !xhat || !rstd || !gamma || !partials) return ICKA_E_ARG;
     if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
     if (lddy % 8 || (dy2 && lddy2 % 8) || (dres && lddres % 8) || (dx && lddx % 8)) return ICKA_E_ALIGN;
@@ -398,21 +409,21 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
     DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, grid, 3 * H * sizeof(float), st, a);
     ICKA_CHECK_LAUNCH();
     hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 255) / 256), dim3(256), 0, st, partials, grid, H, dgamma,
-                       dbeta, dbias, (float*)nullptr);
+                       dbeta, dbias, (float*)nullptr, accumulate);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
-                              const float* type, const float* gamma, const float* beta, void* y, void* xhat,
-                              float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps,
-                              float p_drop, uint64_t seed, void* stream) {
+                              const float* type, const float* gamma, const float* beta, void* y, float* y_f32,
+                              void* xhat, float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab,
+                              int32_t n_type, float eps, float p_drop, uint64_t seed, void* stream) {
     if (!ids || !word || !pos || !type || !gamma || !beta || !y) return ICKA_E_ARG;
     if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || n_type <= 0)
         return ICKA_E_SHAPE;
     if (!al16(word) || !al16(pos) || !al16(type) || !al16(gamma) || !al16(beta) || !al16(y) || (xhat && !al16(xhat)))
         return ICKA_E_ALIGN;
-    EmbFwdArgs a{ids, token_type, word, pos, type, gamma, beta, (bf16_t*)y, (bf16_t*)xhat, rstd,
+    EmbFwdArgs a{ids, token_type, word, pos, type, gamma, beta, (bf16_t*)y, y_f32, (bf16_t*)xhat, rstd,
                  B * S, S, H, vocab, n_type, eps, make_drop(p_drop, seed)};
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), embed_fwd_kernel, row_grid(B * S), 0, st, a);
@@ -424,7 +435,7 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
                               const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype,
                               float* dgamma, float* dbeta, float* partials, int32_t B, int32_t S, int32_t H,
                               int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop, uint64_t seed,
-                              void* stream) {
+                              int32_t accumulate, void* stream) {
     if (!dy || !ids || !xhat || !rstd || !gamma || !dword || !dpos || !dtype || !dgamma || !dbeta || !partials)
         return ICKA_E_ARG;
     if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || n_type <= 0)
@@ -439,7 +450,7 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
     float* t0 = n_type <= 2 ? dtype : nullptr;
     float* t1 = n_type == 2 ? dtype + H : nullptr;
     hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 255) / 256), dim3(256), 0, st, partials, grid, H, dgamma,
-                       dbeta, t0, t1);
+                       dbeta, t0, t1, accumulate);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -50,7 +50,7 @@ def _ld(t: Optional[torch.Tensor]) -> int:
 def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
          alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
-         B2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * op(A,B) [+ op(A2,B2)] + bias) + beta*out.   op: GEMM_NT / GEMM_NN / GEMM_TN."""
     lib = _lib.load()
     _mat(A, "A"); _mat(B, "B")
@@ -90,18 +90,26 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: 
         if bias.dtype != F32 or bias.numel() != N or not bias.is_contiguous():
             raise ValueError("bias must be contiguous f32 [N]")
     d.bias = _ptr(bias)
+    if bias2 is not None and (bias2.dtype != F32 or bias2.numel() != N or not bias2.is_contiguous() or not bias2.is_cuda):
+        raise ValueError("bias2 must be contiguous device f32 [N]")
+    d.bias2 = _ptr(bias2)
     d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
     check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
     return out
 
 
 # ------------------------------------------------------------------------------------------------- LayerNorm
-def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, xhat=None, rstd=None, eps=1e-12, p_drop=0.0, seed=0):
+def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, y_f32=None, xhat=None, rstd=None, eps=1e-12, p_drop=0.0,
+           seed=0):
+    """x / residual may be bf16 or f32 [M,H] row-major; y (and y2) bf16; y_f32 optional contiguous f32 copy."""
     lib = _lib.load()
-    _mat(x, "x"); _mat(y, "y")
+    _mat(x, "x", x.dtype if x.dtype in (BF16, F32) else BF16); _mat(y, "y")
+    if residual is not None:
+        _mat(residual, "residual", residual.dtype if residual.dtype in (BF16, F32) else BF16)
     M, H = x.shape
-    check(lib.icka_ln_fwd(x.data_ptr(), x.stride(0), _ptr(bias), _ptr(residual), _ld(residual), gamma.data_ptr(),
-                          beta.data_ptr(), y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), _ptr(xhat), _ptr(rstd),
+    check(lib.icka_ln_fwd(x.data_ptr(), x.stride(0), int(x.dtype == F32), _ptr(bias), _ptr(residual), _ld(residual),
+                          int(residual is not None and residual.dtype == F32), gamma.data_ptr(), beta.data_ptr(),
+                          y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), _ptr(y_f32), _ptr(xhat), _ptr(rstd),
                           M, H, eps, p_drop, seed, _stream()), "icka_ln_fwd")
     return y
 
@@ -111,37 +119,39 @@ def ln_bwd_workspace(H: int, device) -> torch.Tensor:
 
 
 def ln_bwd(dy, xhat, rstd, gamma, *, dy2=None, dres=None, dx=None, dgamma=None, dbeta=None, dbias=None,
-           partials=None, p_drop=0.0, seed=0):
+           partials=None, p_drop=0.0, seed=0, accumulate=True):
     lib = _lib.load()
     _mat(dy, "dy"); _mat(xhat, "xhat")
     M, H = dy.shape
     check(lib.icka_ln_bwd(dy.data_ptr(), dy.stride(0), _ptr(dy2), _ld(dy2), xhat.data_ptr(), rstd.data_ptr(),
                           gamma.data_ptr(), _ptr(dres), _ld(dres), _ptr(dx), _ld(dx), _ptr(dgamma), _ptr(dbeta),
-                          _ptr(dbias), partials.data_ptr(), M, H, p_drop, seed, _stream()), "icka_ln_bwd")
+                          _ptr(dbias), partials.data_ptr(), M, H, p_drop, seed, int(accumulate), _stream()),
+          "icka_ln_bwd")
 
 
 # ------------------------------------------------------------------------------------------------- embeddings
-def embed_fwd(ids, token_type, word, pos, typ, gamma, beta, y, *, xhat=None, rstd=None, eps=1e-12, p_drop=0.0,
-              seed=0):
+def embed_fwd(ids, token_type, word, pos, typ, gamma, beta, y, *, y_f32=None, xhat=None, rstd=None, eps=1e-12,
+              p_drop=0.0, seed=0):
     lib = _lib.load()
     _dev(ids, "ids")
     B, S = ids.shape
     H = word.shape[1]
     check(lib.icka_embed_fwd(ids.data_ptr(), _ptr(token_type), word.data_ptr(), pos.data_ptr(), typ.data_ptr(),
-                             gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(xhat), _ptr(rstd), B, S, H,
-                             word.shape[0], typ.shape[0], eps, p_drop, seed, _stream()), "icka_embed_fwd")
+                             gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(y_f32), _ptr(xhat), _ptr(rstd),
+                             B, S, H, word.shape[0], typ.shape[0], eps, p_drop, seed, _stream()), "icka_embed_fwd")
     return y
 
 
 def embed_bwd(dy, ids, token_type, xhat, rstd, gamma, dword, dpos, dtype_, dgamma, dbeta, partials, *,
-              padding_idx=0, p_drop=0.0, seed=0):
+              padding_idx=0, p_drop=0.0, seed=0, accumulate=True):
     lib = _lib.load()
     B, S = ids.shape
     H = dword.shape[1]
     check(lib.icka_embed_bwd(dy.data_ptr(), ids.data_ptr(), _ptr(token_type), xhat.data_ptr(), rstd.data_ptr(),
                              gamma.data_ptr(), dword.data_ptr(), dpos.data_ptr(), dtype_.data_ptr(),
                              dgamma.data_ptr(), dbeta.data_ptr(), partials.data_ptr(), B, S, H, dword.shape[0],
-                             dtype_.shape[0], padding_idx, p_drop, seed, _stream()), "icka_embed_bwd")
+                             dtype_.shape[0], padding_idx, p_drop, seed, int(accumulate), _stream()),
+          "icka_embed_bwd")
 
 
 # ------------------------------------------------------------------------------------------------- attention
@@ -182,6 +192,17 @@ def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
 def cast_bf16_to_f32(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     _dev(src, "src"); _dev(dst, "dst")
     check(_lib.load().icka_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "icka_cast")
+    return dst
+
+
+def cast_pad_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst bf16 [M, ldd>=N]: dst[:, :N] = src f32 [M,N]; pad columns zeroed."""
+    _dev(src, "src"); _dev(dst, "dst")
+    if src.dtype != F32 or src.dim() != 2 or src.stride(1) != 1 or dst.dtype != BF16 or not dst.is_contiguous():
+        raise TypeError("cast_pad: src f32 [M,N] row-major, dst contiguous bf16 [M,ldd]")
+    M, N = src.shape
+    check(_lib.load().icka_cast_pad_f32_to_bf16(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.shape[1], M, N,
+                                                _stream()), "icka_cast_pad_f32_to_bf16")
     return dst
 
 
@@ -244,13 +265,21 @@ def add_bf16(a, b, out):
 
 
 def token_ce(logits, labels, mask, loss_sum, count, dlogits):
-    """logits f32 [M,C]; labels/mask int64 [M]; dlogits bf16 [M, ldd>=C] (unscaled, see scale_by_inv)."""
+    """logits f32 [M,C]; labels/mask int64 [M]; dlogits bf16 [M, ldd>=C] (unscaled, see scale_by_ratio)."""
     M, Cn = logits.shape
     check(_lib.load().icka_token_ce(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
                                     loss_sum.data_ptr(), count.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
                                     M, Cn, _stream()), "icka_token_ce")
 
 
-def scale_by_inv(x, denom):
-    check(_lib.load().icka_scale_by_inv(x.data_ptr(), denom.data_ptr(), x.numel(), _stream()), "icka_scale_by_inv")
-    return x
+def scale_by_ratio(x, y, num=None, den=None):
+    """y = x * num[0] / max(den[0], 1) with device scalars (None = 1)."""
+    check(_lib.load().icka_scale_by_ratio(x.data_ptr(), y.data_ptr(), _ptr(num), _ptr(den), x.numel(), _stream()),
+          "icka_scale_by_ratio")
+    return y
+
+
+def scalar_ratio(out, num, den):
+    check(_lib.load().icka_scalar_ratio(out.data_ptr(), num.data_ptr(), den.data_ptr(), _stream()),
+          "icka_scalar_ratio")
+    return out

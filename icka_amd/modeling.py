@@ -1,0 +1,540 @@
+"""Drop-in nn.Modules for the ICKA MNER hot path, running on hand-written gfx950 kernels.
+
+Same class names, constructor arguments, ``forward`` signatures and ``state_dict`` keys as the reference's blocks
+(Cross_Modal_Interaction_Module.py:302-698, my_bert/gate_cl_modeling.py:239-604, a_transformers/modeling_bert.py
+encoder-only branch) and its gated MNER head (my_bert/cl_modeling.py:1252-1388, gate_cl_modeling.py:1248-1400), so
+checkpoints load unchanged and callers such as My_cross_attention.py:676-683/:814-817 can switch imports.
+
+Parameters are ordinary fp32 ``nn.Parameter``s (views into a ParamArena once the module has run on a ROCm device);
+compute is bf16 MFMA with fp32 accumulation / statistics.  Hidden states are exchanged as bf16 ``[B,S,H]`` tensors
+(fp32 inputs are cast on entry).  There is no CPU path: calling ``forward`` with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import ops
+from .arena import ParamArena, arena_of
+from .config import BertConfig, check_config
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ------------------------------------------------------------------------------------------------- small helpers
+class _CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, to_bf16: bool):
+        ctx.to_bf16 = to_bf16
+        x = x.contiguous()
+        if to_bf16:
+            return K.cast_f32_to_bf16(x, torch.empty_like(x, dtype=BF16))
+        return K.cast_bf16_to_f32(x, torch.empty_like(x, dtype=F32))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if ctx.to_bf16:
+            return K.cast_bf16_to_f32(dy, torch.empty_like(dy, dtype=F32)), None
+        return K.cast_f32_to_bf16(dy, torch.empty_like(dy, dtype=BF16)), None
+
+
+def _hidden2d(x: torch.Tensor, name: str = "hidden_states") -> torch.Tensor:
+    """[B,S,H] (bf16 or f32, ROCm) -> contiguous bf16 [B*S, H]."""
+    if not x.is_cuda:
+        raise TypeError("%s must be on a ROCm device: icka_amd has no CPU path" % name)
+    if x.dtype == F32:
+        x = _CastFn.apply(x, True)
+    elif x.dtype != BF16:
+        raise TypeError("%s must be bf16 or f32, got %s" % (name, x.dtype))
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x.view(-1, x.shape[-1])
+
+
+def _twin(x: torch.Tensor) -> Optional[torch.Tensor]:
+    """f32 twin of a bf16 hidden-state tensor produced by one of our blocks (carried as a Python attribute so the
+    public signatures stay the reference's): the residual stream is accumulated in f32."""
+    t = getattr(x, "_icka_f32", None)
+    if t is None or t.numel() != x.numel() or t.device != x.device:
+        return None
+    return t.view(-1, x.shape[-1])
+
+
+def _with_twin(y2d: torch.Tensor, yf2d: Optional[torch.Tensor], shape) -> torch.Tensor:
+    out = y2d.view(shape)
+    if yf2d is not None:
+        out._icka_f32 = yf2d
+    return out
+
+
+def _add_mask2d(mask: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """The reference hands blocks the *extended additive* mask [B,1,1,T] ((1-m)*-10000, :364-372): flatten to the
+    f32 [B,T] the attention kernel reads."""
+    if mask.dtype != F32:
+        mask = mask.float()
+    if mask.numel() != B * T:
+        mask = mask.expand(B, 1, 1, T)
+    return mask.reshape(B, T).contiguous()
+
+
+def _dims(config, B, S, R, train: bool) -> ops.Dims:
+    return ops.Dims(B, S, R, config.hidden_size, config.intermediate_size, config.num_attention_heads,
+                    float(getattr(config, "layer_norm_eps", 1e-12)), float(config.hidden_dropout_prob),
+                    float(config.attention_probs_dropout_prob), train)
+
+
+class _IckaModule(nn.Module):
+    """Shared plumbing: lazily (re)build the ParamArena over the outermost module and refresh bf16 shadows."""
+
+    def _arena(self) -> ParamArena:
+        A = arena_of(self)
+        if A.device.type != "cuda":
+            raise RuntimeError("%s: parameters are on %s; move the module to a ROCm device (icka_amd has no CPU "
+                               "path)" % (type(self).__name__, A.device))
+        A.begin_step()
+        A.sync()
+        return A
+
+    def _anchor(self, A: ParamArena) -> torch.Tensor:
+        return A.anchor
+
+
+# ------------------------------------------------------------------------------------------------- blocks
+class BertLayerNorm(_IckaModule):
+    """TF-style LayerNorm, eps inside the sqrt (Cross_Modal_Interaction_Module.py:509-522)."""
+
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        A = self._arena()
+        shape = x.shape
+        return _LayerNormFn.apply(A.anchor, _hidden2d(x, "x"), self, A).view(shape)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, mod, A):
+        M, H = x.shape
+        y = torch.empty_like(x)
+        xhat = torch.empty_like(x)
+        rstd = torch.empty(M, dtype=F32, device=x.device)
+        K.ln_fwd(x, None, None, mod.weight, mod.bias, y, xhat=xhat, rstd=rstd, eps=mod.variance_epsilon)
+        ctx.mod, ctx.A = mod, A
+        ctx.save_for_backward(xhat, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd = ctx.saved_tensors
+        mod, A = ctx.mod, ctx.A
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(dy.shape[1]))
+        acc = A.grad_beta((mod.weight, mod.bias)) > 0
+        K.ln_bwd(dy, xhat, rstd, mod.weight, dres=dx, dgamma=A.g(mod.weight), dbeta=A.g(mod.bias), partials=ws,
+                 accumulate=acc)
+        return None, dx, None, None
+
+
+class BertEmbeddings(_IckaModule):
+    """word + position + token_type -> LayerNorm -> dropout (:384-412)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=getattr(config, "layer_norm_eps", 1e-12))
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, input_ids, token_type_ids=None):
+        if not input_ids.is_cuda:
+            raise TypeError("input_ids must be on a ROCm device: icka_amd has no CPU path")
+        B, S = input_ids.shape
+        if S > self.position_embeddings.weight.shape[0]:
+            raise IndexError("sequence length %d exceeds max_position_embeddings" % S)
+        A = self._arena()
+        ids = input_ids.contiguous()
+        tt = None if token_type_ids is None else token_type_ids.contiguous()
+        d = _dims(self.config, B, S, 0, self.training)
+        y, yf = ops.EmbeddingsFn.apply(A.anchor, self, A, ids, tt, d)
+        return _with_twin(y, yf, (B, S, -1))
+
+
+class BertSelfAttention(nn.Module):
+    """Parameter container with the reference's names (:456-506); computed inside BertLayer's fused kernels."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def icka_param_order(self):
+        # weights back to back, then biases: one [3H,H] (or [2H,H] K|V) operand for the fused projection GEMM
+        return [("query.weight", self.query.weight), ("key.weight", self.key.weight),
+                ("value.weight", self.value.weight), ("query.bias", self.query.bias),
+                ("key.bias", self.key.bias), ("value.bias", self.value.bias)]
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("BertSelfAttention/BertCoAttention run fused inside BertLayer / "
+                                  "BertCrossAttentionLayer (icka_attn_* kernels); call the enclosing layer")
+
+
+class BertCoAttention(BertSelfAttention):
+    """Q from s1, K/V from s2 (:568-624)."""
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=getattr(config, "layer_norm_eps", 1e-12))
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertCrossAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertCoAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=getattr(config, "layer_norm_eps", 1e-12))
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertLayer(_IckaModule):
+    """forward(hidden_states, attention_mask) with the extended additive mask, as :431-442."""
+
+    def __init__(self, config):
+        super().__init__()
+        check_config(config)
+        self.config = config
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask):
+        B, S, H = hidden_states.shape
+        A = self._arena()
+        x = _hidden2d(hidden_states)
+        d = _dims(self.config, B, S, 0, self.training)
+        y, yf = ops.BertLayerFn.apply(A.anchor, x, _twin(hidden_states), self, A, _add_mask2d(attention_mask, B, S), d)
+        return _with_twin(y, yf, (B, S, H))
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        layer = BertLayer(config)
+        self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask, output_all_encoded_layers=True):
+        all_encoder_layers = []
+        for layer_module in self.layer:
+            hidden_states = layer_module(hidden_states, attention_mask)
+            if output_all_encoded_layers:
+                all_encoder_layers.append(hidden_states)
+        if not output_all_encoded_layers:
+            all_encoder_layers.append(hidden_states)
+        return all_encoder_layers
+
+
+class BertSelfEncoder(nn.Module):
+    """One-layer encoder (:683-698); constructed by the reference heads, unused on the hot path."""
+
+    def __init__(self, config):
+        super().__init__()
+        layer = BertLayer(config)
+        self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(1)])
+
+    def forward(self, hidden_states, attention_mask, output_all_encoded_layers=True):
+        return BertEncoder.forward(self, hidden_states, attention_mask, output_all_encoded_layers)
+
+
+class BertCrossAttentionLayer(_IckaModule):
+    """forward(s1_hidden_states, s2_hidden_states, s2_attention_mask) (:639-650)."""
+
+    def __init__(self, config):
+        super().__init__()
+        check_config(config)
+        self.config = config
+        self.attention = BertCrossAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, s1_hidden_states, s2_hidden_states, s2_attention_mask):
+        B, S, H = s1_hidden_states.shape
+        R = s2_hidden_states.shape[1]
+        A = self._arena()
+        s1 = _hidden2d(s1_hidden_states, "s1_hidden_states")
+        s2 = _hidden2d(s2_hidden_states, "s2_hidden_states")
+        d = _dims(self.config, B, S, R, self.training)
+        y, yf = ops.CrossLayerFn.apply(A.anchor, s1, _twin(s1_hidden_states), s2, self, A,
+                                       _add_mask2d(s2_attention_mask, B, R), d)
+        return _with_twin(y, yf, (B, S, H))
+
+
+class BertCrossEncoder(nn.Module):
+    """forward(s1, s2, s2_attention_mask, output_all_encoded_layers=True) -> list (:653-667)."""
+
+    def __init__(self, config, layer_num):
+        super().__init__()
+        layer = BertCrossAttentionLayer(config)
+        self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(layer_num)])
+
+    def forward(self, s1_hidden_states, s2_hidden_states, s2_attention_mask, output_all_encoded_layers=True):
+        all_encoder_layers = []
+        for layer_module in self.layer:
+            s1_hidden_states = layer_module(s1_hidden_states, s2_hidden_states, s2_attention_mask)
+            if output_all_encoded_layers:
+                all_encoder_layers.append(s1_hidden_states)
+        if not output_all_encoded_layers:
+            all_encoder_layers.append(s1_hidden_states)
+        return all_encoder_layers
+
+
+class BertPooler(_IckaModule):
+    """tanh(dense(hidden_states[:, 0])) (:669-681)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+    def forward(self, hidden_states):
+        A = self._arena()
+        B, S, H = hidden_states.shape
+        x = _hidden2d(hidden_states)
+        first = x.view(B, S, H)[:, 0]            # strided [B,H] view, row stride S*H: read in place by the GEMM
+        return ops.LinearFn.apply(A.anchor, first, self.dense, A, False, K.EPI_TANH)
+
+
+# ------------------------------------------------------------------------------------------------- models
+class BertPreTrainedModel(_IckaModule):
+    """Weight init + checkpoint key handling of the reference (:141-299).  ``from_pretrained`` takes a directory
+    holding ``bert_config.json``/``config.json`` + ``pytorch_model.bin`` or an explicit ``state_dict=``; the
+    reference's S3 download / TF-checkpoint paths are I/O outside the hot path and are not reproduced."""
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        for f in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+                  "hidden_dropout_prob", "attention_probs_dropout_prob", "max_position_embeddings",
+                  "type_vocab_size", "vocab_size"):
+            if not hasattr(config, f):
+                raise ValueError("Parameter config in `{}(config)` should expose BertConfig fields (missing `{}`)"
+                                 .format(self.__class__.__name__, f))
+        self.config = config
+
+    def init_bert_weights(self, module):
+        std = getattr(self.config, "initializer_range", 0.02)
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=std)
+        elif isinstance(module, BertLayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    @staticmethod
+    def convert_legacy_keys(state_dict):
+        """gamma/beta -> weight/bias renaming of old checkpoints (:256-268)."""
+        out = type(state_dict)()
+        for key, v in state_dict.items():
+            nk = key
+            if "gamma" in nk:
+                nk = nk.replace("gamma", "weight")
+            if "beta" in nk:
+                nk = nk.replace("beta", "bias")
+            out[nk] = v
+        return out
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *inputs, **kwargs):
+        import json
+        import os
+        state_dict = kwargs.pop("state_dict", None)
+        kwargs.pop("cache_dir", None)
+        if kwargs.pop("from_tf", False):
+            raise NotImplementedError("TensorFlow checkpoints: convert to a PyTorch state_dict first")
+        config = kwargs.pop("config", None)
+        if config is None:
+            for n in ("config.json", "bert_config.json"):
+                p = os.path.join(pretrained_model_name_or_path, n)
+                if os.path.exists(p):
+                    config = BertConfig.from_json_file(p)
+                    break
+        if config is None:
+            raise EnvironmentError("no config.json / bert_config.json under %r" % (pretrained_model_name_or_path,))
+        model = cls(config, *inputs, **kwargs)
+        if state_dict is None:
+            state_dict = torch.load(os.path.join(pretrained_model_name_or_path, "pytorch_model.bin"),
+                                    map_location="cpu")
+        state_dict = cls.convert_legacy_keys(state_dict)
+        # a bare BertModel loads 'bert.'-prefixed checkpoints (:286-289)
+        if not hasattr(model, "bert") and any(k.startswith("bert.") for k in state_dict):
+            state_dict = type(state_dict)((k[5:], v) for k, v in state_dict.items() if k.startswith("bert."))
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        model._load_report = {"missing": list(missing), "unexpected": list(unexpected)}
+        return model
+
+
+class BertModel(BertPreTrainedModel):
+    """forward(input_ids, token_type_ids=None, attention_mask=None, output_all_encoded_layers=True)
+    -> (encoded_layers, pooled_output), as :302-382."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        check_config(config)
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.pooler = BertPooler(config)
+        self.apply(self.init_bert_weights)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, output_all_encoded_layers=True):
+        if not input_ids.is_cuda:
+            raise TypeError("input_ids must be on a ROCm device: icka_amd has no CPU path")
+        B, S = input_ids.shape
+        self._arena()
+        add_mask = torch.zeros(B, S, dtype=F32, device=input_ids.device) if attention_mask is None else \
+            K.additive_mask(attention_mask.long() if attention_mask.dtype != torch.int64 else attention_mask, S,
+                            torch.empty(B, S, dtype=F32, device=input_ids.device))
+        extended_attention_mask = add_mask.view(B, 1, 1, S)
+        embedding_output = self.embeddings(input_ids, token_type_ids)
+        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
+                                      output_all_encoded_layers=output_all_encoded_layers)
+        sequence_output = encoded_layers[-1]
+        pooled_output = self.pooler(sequence_output)
+        if not output_all_encoded_layers:
+            encoded_layers = encoded_layers[-1]
+        return encoded_layers, pooled_output
+
+
+class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
+    """Gated multimodal token classifier (my_bert/cl_modeling.py:1252-1388; gate_cl_modeling.py:1248-1400).
+
+    forward(input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_mean, visual_embeds_att,
+            temp=None, temp_lamb=None, lamb=None, labels=None, negative_rate=None)
+    keeps the reference's positional signature (gate_cl_modeling.py:1319-1320).  The hot path ends at the per-token
+    logits (``bert_feats``): with ``labels=None`` the logits ``[B,S,num_labels]`` (f32) are returned; with labels,
+    the token-level cross-entropy over valid tokens (the benchmark loss).  The CRF and the
+    contrastive / crs auxiliary losses of the reference are outside the hot path; a caller that owns a CRF module
+    can assign it to ``self.crf`` and gets ``-crf(logits, labels, mask, reduction='mean')`` like the reference.
+
+    ``visual_embeds_att`` is the myResnet 'att' tensor ``[B,2048,7,7]`` (R = 49, reference layout) or region
+    tokens ``[B,R,2048]`` (BASELINE synthetic layout); ``regions`` defaults to 49 as in the reference.
+    """
+
+    def __init__(self, config, layer_num1=1, layer_num2=1, layer_num3=1, num_labels=2, regions=49):
+        super().__init__(config)
+        check_config(config)
+        self.num_labels = num_labels
+        self.regions = regions
+        self.bert = BertModel(config)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.vismap2text = nn.Linear(2048, config.hidden_size)
+        self.txt2img_attention = BertCrossEncoder(config, layer_num1)
+        self.Gate_text = nn.Linear(config.hidden_size, config.hidden_size)
+        self.Gate_image = nn.Linear(config.hidden_size, config.hidden_size)
+        self.classifier = nn.Linear(config.hidden_size * 2, num_labels)
+        self.crf = None
+        self.apply(self.init_bert_weights)
+
+    def logits(self, input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_att):
+        cfg = self.config
+        B, S = input_ids.shape
+        H = cfg.hidden_size
+        A = self._arena()
+        dev = input_ids.device
+        # ---- text encoder (cl_modeling.py:1341-1344)
+        sequence_output, _ = self.bert(input_ids, token_type_ids=segment_ids, attention_mask=input_mask,
+                                       output_all_encoded_layers=False)
+        seq = sequence_output.view(B * S, H)
+        seqf = _twin(sequence_output)
+        if self.training and cfg.hidden_dropout_prob > 0:
+            seq = ops.DropoutFn.apply(seq, A, float(cfg.hidden_dropout_prob))
+            seqf = None
+        # ---- region tokens + projection (:1348-1350)
+        v = visual_embeds_att
+        if not v.is_cuda:
+            raise TypeError("visual_embeds_att must be on a ROCm device")
+        if v.dim() == 4 or (v.dim() == 3 and v.shape[1] == 2048 and v.shape[2] != 2048):
+            R = v.shape[2] * v.shape[3] if v.dim() == 4 else v.shape[2]
+            layout = 1
+        else:
+            R, layout = v.shape[1], 0
+        tokens = torch.empty(B * R, 2048, dtype=BF16, device=dev)
+        K.regions_to_tokens(v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v, tokens, B, R,
+                            2048, layout)
+        vis = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE)
+        # ---- image mask (:1353-1356)
+        img_mask = K.additive_mask(added_attention_mask if added_attention_mask.dtype == torch.int64
+                                   else added_attention_mask.long(), R, torch.empty(B, R, dtype=F32, device=dev))
+        # ---- cross encoder (:1359-1361)
+        cross, crossf = seq, seqf
+        d = _dims(cfg, B, S, R, self.training)
+        for layer in self.txt2img_attention.layer:
+            cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
+        # ---- gate + classifier (:1363-1371)
+        logits = ops.GatedHeadFn.apply(A.anchor, seq, cross, self, A)
+        return logits.view(B, S, self.num_labels)
+
+    def forward(self, input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_mean=None,
+                visual_embeds_att=None, temp=None, temp_lamb=None, lamb=None, labels=None, negative_rate=None):
+        logits = self.logits(input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_att)
+        if labels is None:
+            return logits
+        if self.crf is not None:
+            return -self.crf(logits, labels, mask=input_mask.byte(), reduction="mean")
+        return token_ce_loss(logits, labels, input_mask)
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        A = getattr(self, "_icka_arena", None)
+        if A is not None:
+            A.begin_step()   # grads dropped -> the next backward overwrites the arena slots instead of accumulating
+
+
+def token_ce_loss(logits: torch.Tensor, labels: torch.Tensor, input_mask: torch.Tensor) -> torch.Tensor:
+    """Token-level cross-entropy, mean over tokens with input_mask != 0 (fused forward + logit gradient)."""
+    C = logits.shape[-1]
+    lg = logits.reshape(-1, C)
+    if lg.dtype != F32:
+        raise TypeError("logits must be f32")
+    return ops.TokenCEFn.apply(lg, labels.contiguous(), input_mask.contiguous())

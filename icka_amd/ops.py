@@ -1,0 +1,403 @@
+"""autograd.Functions of the hot path: one Function per reference block (embeddings, BERT layer, cross-attention
+layer, linear, gated head, dropout, pooler, token-CE), each a fixed sequence of libicka_hip.so launches.
+
+Design notes
+  * Activations between blocks are bf16 [tokens, hidden] matrices; parameters are NOT autograd inputs: kernels read
+    the bf16 shadow of the ParamArena and the backward writes parameter gradients straight into the arena's fp32
+    gradient buffer (GEMM beta 0/1), then attaches ``p.grad`` views.  An ``anchor`` leaf keeps autograd engaged.
+  * Every dropout site draws a 64-bit seed at forward time and stores it for its backward, which re-generates the
+    mask inside the kernels (nothing is materialised).
+  * Gradient fan-in (residual + dense paths) is fused into GEMM epilogues (EPI_ADD) or the LN backward (dy2).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+from .arena import ParamArena
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _empty(ref: torch.Tensor, *shape, dtype=BF16) -> torch.Tensor:
+    return torch.empty(*shape, dtype=dtype, device=ref.device)
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    """autograd may hand us non-contiguous / broadcast gradients: make them plain row-major bf16."""
+    if t.dtype != BF16:
+        raise TypeError("expected a bf16 gradient, got %s" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Dims(object):
+    """Static description of one call: batch, query length, kv length, sizes, dropout probabilities."""
+    __slots__ = ("B", "S", "R", "H", "I", "heads", "eps", "p_hidden", "p_attn", "train")
+
+    def __init__(self, B, S, R, H, I, heads, eps, p_hidden, p_attn, train):
+        self.B, self.S, self.R, self.H, self.I, self.heads, self.eps = B, S, R, H, I, heads, eps
+        self.p_hidden = p_hidden if train else 0.0
+        self.p_attn = p_attn if train else 0.0
+        self.train = train
+
+
+# =============================================================================================== sub-blocks
+def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool):
+    """BertAttention / BertCrossAttention: projections -> fused attention -> out-proj -> bias+dropout+residual+LN.
+    ``att`` is the reference-named module (``.self.{query,key,value}``, ``.output.{dense,LayerNorm}``).
+    x is the bf16 MFMA operand; xres its f32 twin used as the residual (None -> x).  Returns (y bf16, y f32, saved)."""
+    sa, so = att.self, att.output
+    M, H = x.shape
+    self_attn = kv_src is None
+    if self_attn:
+        qkv = _empty(x, M, 3 * H)
+        K.gemm(K.GEMM_NT, x, A.w_cat((sa.query.weight, sa.key.weight, sa.value.weight)), qkv,
+               bias=A.f_cat((sa.query.bias, sa.key.bias, sa.value.bias)))
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        kvbuf = None
+    else:
+        qkv = _empty(x, M, H)
+        K.gemm(K.GEMM_NT, x, A.w(sa.query.weight), qkv, bias=sa.query.bias)
+        kvbuf = _empty(x, kv_src.shape[0], 2 * H)
+        K.gemm(K.GEMM_NT, kv_src, A.w_cat((sa.key.weight, sa.value.weight)), kvbuf,
+               bias=A.f_cat((sa.key.bias, sa.value.bias)))
+        q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
+    ctx = _empty(x, M, H)
+    lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
+    seed_a = A.next_seed() if d.p_attn > 0 else 0
+    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
+    ao = _empty(x, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra bf16 rounding)
+    K.gemm(K.GEMM_NT, ctx, A.w(so.dense.weight), ao)
+    y = _empty(x, M, H)
+    yf = _empty(x, M, H, dtype=F32)
+    xhat = _empty(x, M, H) if save else None
+    rstd = _empty(x, M, dtype=F32) if save else None
+    seed_h = A.next_seed() if d.p_hidden > 0 else 0
+    K.ln_fwd(ao, so.dense.bias, x if xres is None else xres, so.LayerNorm.weight, so.LayerNorm.bias, y, y_f32=yf,
+             xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed_h)
+    saved = (qkv, kvbuf, ctx, lse, xhat, rstd, seed_a, seed_h) if save else None
+    return y, yf, saved
+
+
+def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, saved, dy, dy2, need_dkv_src: bool):
+    """Returns (dx, dkv_src).  dy2 is an optional second gradient of the block output (fused into the LN backward)."""
+    sa, so = att.self, att.output
+    qkv, kvbuf, ctx, lse, xhat, rstd, seed_a, seed_h = saved
+    M, H = x.shape
+    ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(H))
+    dres = _empty(x, M, H)
+    dao = _empty(x, M, H)
+    b_ln = A.grad_beta((so.LayerNorm.weight, so.LayerNorm.bias, so.dense.bias))
+    K.ln_bwd(dy, xhat, rstd, so.LayerNorm.weight, dy2=dy2, dres=dres, dx=dao, dgamma=A.g(so.LayerNorm.weight),
+             dbeta=A.g(so.LayerNorm.bias), dbias=A.g(so.dense.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h,
+             accumulate=b_ln > 0)
+    K.gemm(K.GEMM_TN, dao, ctx, A.g(so.dense.weight), beta=A.grad_beta(so.dense.weight))
+    dctx = _empty(x, M, H)
+    K.gemm(K.GEMM_NN, dao, A.w(so.dense.weight), dctx)
+    delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
+    csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(3 * H))
+    if kv_src is None:
+        dqkv = _empty(x, M, 3 * H)
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        K.attn_bwd(q, k, v, add_mask, ctx, dctx, lse, delta, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], d.B,
+                   d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
+        wg = (sa.query.weight, sa.key.weight, sa.value.weight)
+        bg = (sa.query.bias, sa.key.bias, sa.value.bias)
+        K.gemm(K.GEMM_TN, dqkv, x, A.g_cat(wg), beta=A.grad_beta(wg))
+        K.colsum(dqkv, A.g_cat(bg), csw, accumulate=A.grad_beta(bg) > 0)
+        dx = _empty(x, M, H)
+        K.gemm(K.GEMM_NN, dqkv, A.w_cat(wg), dx, epilogue=K.EPI_ADD, aux=dres)
+        return dx, None
+    dq = _empty(x, M, H)
+    dkv = _empty(x, kv_src.shape[0], 2 * H)
+    K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
+               d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
+    K.gemm(K.GEMM_TN, dq, x, A.g(sa.query.weight), beta=A.grad_beta(sa.query.weight))
+    K.colsum(dq, A.g(sa.query.bias), csw, accumulate=A.grad_beta(sa.query.bias) > 0)
+    wg = (sa.key.weight, sa.value.weight)
+    bg = (sa.key.bias, sa.value.bias)
+    K.gemm(K.GEMM_TN, dkv, kv_src, A.g_cat(wg), beta=A.grad_beta(wg))
+    K.colsum(dkv, A.g_cat(bg), csw, accumulate=A.grad_beta(bg) > 0)
+    dx = _empty(x, M, H)
+    K.gemm(K.GEMM_NN, dq, A.w(sa.query.weight), dx, epilogue=K.EPI_ADD, aux=dres)
+    dsrc = None
+    if need_dkv_src:
+        dsrc = _empty(x, kv_src.shape[0], H)
+        K.gemm(K.GEMM_NN, dkv, A.w_cat(wg), dsrc)
+    return dx, dsrc
+
+
+def _ffn_block_fwd(A: ParamArena, layer, x, xres, d: Dims, save: bool):
+    """BertIntermediate + BertOutput.  Returns (y bf16, y f32, saved)."""
+    inter, out = layer.intermediate, layer.output
+    M, H = x.shape
+    I = inter.dense.weight.shape[0]
+    z = _empty(x, M, I)
+    g = _empty(x, M, I)
+    K.gemm(K.GEMM_NT, x, A.w(inter.dense.weight), g, bias=inter.dense.bias, epilogue=K.EPI_GELU, out2=z)
+    fo = _empty(x, M, H, dtype=F32)
+    K.gemm(K.GEMM_NT, g, A.w(out.dense.weight), fo)
+    y = _empty(x, M, H)
+    yf = _empty(x, M, H, dtype=F32)
+    xhat = _empty(x, M, H) if save else None
+    rstd = _empty(x, M, dtype=F32) if save else None
+    seed_h = A.next_seed() if d.p_hidden > 0 else 0
+    K.ln_fwd(fo, out.dense.bias, x if xres is None else xres, out.LayerNorm.weight, out.LayerNorm.bias, y, y_f32=yf,
+             xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed_h)
+    return y, yf, ((z, g, xhat, rstd, seed_h) if save else None)
+
+
+def _ffn_block_bwd(A: ParamArena, layer, x, d: Dims, saved, dy, dy2=None):
+    """Returns (dx_ffn, dres): gradient through the dense path (dz @ W1) is returned WITH dres already added."""
+    inter, out = layer.intermediate, layer.output
+    z, g, xhat, rstd, seed_h = saved
+    M, H = x.shape
+    I = z.shape[1]
+    ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(H))
+    dres = _empty(x, M, H)
+    dfo = _empty(x, M, H)
+    b_ln = A.grad_beta((out.LayerNorm.weight, out.LayerNorm.bias, out.dense.bias))
+    K.ln_bwd(dy, xhat, rstd, out.LayerNorm.weight, dy2=dy2, dres=dres, dx=dfo, dgamma=A.g(out.LayerNorm.weight),
+             dbeta=A.g(out.LayerNorm.bias), dbias=A.g(out.dense.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h,
+             accumulate=b_ln > 0)
+    K.gemm(K.GEMM_TN, dfo, g, A.g(out.dense.weight), beta=A.grad_beta(out.dense.weight))
+    dz = _empty(x, M, I)
+    K.gemm(K.GEMM_NN, dfo, A.w(out.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)
+    K.gemm(K.GEMM_TN, dz, x, A.g(inter.dense.weight), beta=A.grad_beta(inter.dense.weight))
+    csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(I))
+    K.colsum(dz, A.g(inter.dense.bias), csw, accumulate=A.grad_beta(inter.dense.bias) > 0)
+    dx = _empty(x, M, H)
+    K.gemm(K.GEMM_NN, dz, A.w(inter.dense.weight), dx, epilogue=K.EPI_ADD, aux=dres)
+    return dx
+
+
+# =============================================================================================== Functions
+class EmbeddingsFn(torch.autograd.Function):
+    """BertEmbeddings.forward (Cross_Modal_Interaction_Module.py:398-412)."""
+
+    @staticmethod
+    def forward(ctx, anchor, mod, A: ParamArena, ids, tt, d: Dims):
+        B, S = ids.shape
+        H = d.H
+        save = any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
+        y = torch.empty(B * S, H, dtype=BF16, device=ids.device)
+        yf = torch.empty(B * S, H, dtype=F32, device=ids.device)
+        xhat = torch.empty_like(y) if save else None
+        rstd = torch.empty(B * S, dtype=F32, device=ids.device) if save else None
+        seed = A.next_seed() if d.p_hidden > 0 else 0
+        K.embed_fwd(ids, tt, mod.word_embeddings.weight, mod.position_embeddings.weight,
+                    mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias, y, y_f32=yf,
+                    xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed)
+        ctx.mod, ctx.A, ctx.d, ctx.seed = mod, A, d, seed
+        ctx.save_for_backward(ids, tt, xhat, rstd)
+        ctx.mark_non_differentiable(yf)
+        return y, yf
+
+    @staticmethod
+    def backward(ctx, dy, _dyf=None):
+        mod, A, d = ctx.mod, ctx.A, ctx.d
+        ids, tt, xhat, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(d.H))
+        tables = (mod.word_embeddings.weight, mod.position_embeddings.weight)
+        if A.grad_beta(tables) == 0.0:   # atomically accumulated tables: fresh gradient starts from zero
+            A.g(tables[0]).zero_()
+            A.g(tables[1]).zero_()
+        small = (mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
+        acc = A.grad_beta(small) > 0
+        K.embed_bwd(dy, ids, tt, xhat, rstd, mod.LayerNorm.weight, A.g(tables[0]), A.g(tables[1]), A.g(small[0]),
+                    A.g(small[1]), A.g(small[2]), ws, padding_idx=0, p_drop=d.p_hidden, seed=ctx.seed, accumulate=acc)
+        return None, None, None, None, None, None
+
+
+class BertLayerFn(torch.autograd.Function):
+    """BertLayer.forward (:438-442): self-attention block + feed-forward block."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, xf, layer, A: ParamArena, add_mask, d: Dims):
+        save = any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
+        x1, x1f, s_att = _attn_block_fwd(A, layer.attention, x, xf, None, add_mask, d, d.S, save)
+        x2, x2f, s_ffn = _ffn_block_fwd(A, layer, x1, x1f, d, save)
+        ctx.layer, ctx.A, ctx.d, ctx.s_att, ctx.s_ffn = layer, A, d, s_att, s_ffn
+        ctx.save_for_backward(x, x1, add_mask)
+        ctx.mark_non_differentiable(x2f)
+        return x2, x2f
+
+    @staticmethod
+    def backward(ctx, dy, _dyf=None):
+        x, x1, add_mask = ctx.saved_tensors
+        layer, A, d = ctx.layer, ctx.A, ctx.d
+        dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
+        dx, _ = _attn_block_bwd(A, layer.attention, x, None, add_mask, d, d.S, ctx.s_att, dx1, None, False)
+        ctx.s_att = ctx.s_ffn = None
+        return None, dx, None, None, None, None, None
+
+
+class CrossLayerFn(torch.autograd.Function):
+    """BertCrossAttentionLayer.forward (:646-650): Q from s1 (text), K/V from s2 (regions), residual = s1."""
+
+    @staticmethod
+    def forward(ctx, anchor, s1, s1f, s2, layer, A: ParamArena, add_mask, d: Dims):
+        save = any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
+        x1, x1f, s_att = _attn_block_fwd(A, layer.attention, s1, s1f, s2, add_mask, d, d.R, save)
+        x2, x2f, s_ffn = _ffn_block_fwd(A, layer, x1, x1f, d, save)
+        ctx.layer, ctx.A, ctx.d, ctx.s_att, ctx.s_ffn = layer, A, d, s_att, s_ffn
+        ctx.need_s2 = s2.requires_grad
+        ctx.save_for_backward(s1, s2, x1, add_mask)
+        ctx.mark_non_differentiable(x2f)
+        return x2, x2f
+
+    @staticmethod
+    def backward(ctx, dy, _dyf=None):
+        s1, s2, x1, add_mask = ctx.saved_tensors
+        layer, A, d = ctx.layer, ctx.A, ctx.d
+        dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
+        ds1, ds2 = _attn_block_bwd(A, layer.attention, s1, s2, add_mask, d, d.R, ctx.s_att, dx1, None, ctx.need_s2)
+        ctx.s_att = ctx.s_ffn = None
+        return None, ds1, None, ds2, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on a [tokens, in] bf16 matrix (vismap2text :958, generic dense)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, lin, A: ParamArena, out_f32: bool, epilogue: int):
+        M = x.shape[0]
+        N = lin.weight.shape[0]
+        y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x.device)
+        K.gemm(K.GEMM_NT, x, A.w(lin.weight), y, bias=lin.bias, epilogue=epilogue)
+        ctx.lin, ctx.A, ctx.epi = lin, A, epilogue
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(x, y if epilogue == K.EPI_TANH else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        lin, A = ctx.lin, ctx.A
+        M, N = dy.shape
+        if dy.dtype == F32:
+            ldd = (N + 7) // 8 * 8
+            dyb = torch.empty(M, ldd, dtype=BF16, device=dy.device)
+            K.cast_pad_f32_to_bf16(dy if dy.stride(1) == 1 else dy.contiguous(), dyb)
+            dyv = dyb[:, :N]
+        else:
+            dyv = _c(dy)
+        if ctx.epi == K.EPI_TANH:
+            raise NotImplementedError("backward through the tanh pooler is outside the hot path (pooled output only "
+                                      "feeds the reference's contrastive loss, SURVEY.md section 8a a9)")
+        K.gemm(K.GEMM_TN, dyv, x, A.g(lin.weight), beta=A.grad_beta(lin.weight))
+        if lin.bias is not None:
+            csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(N))
+            K.colsum(dyv, A.g(lin.bias), csw, accumulate=A.grad_beta(lin.bias) > 0)
+        dx = None
+        if ctx.need_dx:
+            dx = torch.empty_like(x)
+            K.gemm(K.GEMM_NN, dyv, A.w(lin.weight), dx)
+        return None, dx, None, None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout on the encoder output (:953); writes optional second copy (concat buffer)."""
+
+    @staticmethod
+    def forward(ctx, x, A: ParamArena, p: float):
+        seed = A.next_seed()
+        y = torch.empty_like(x)
+        K.dropout(x, y, p_drop=p, seed=seed)
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        K.dropout(dy, dx, p_drop=ctx.p, seed=ctx.seed)
+        return dx, None, None
+
+
+class GatedHeadFn(torch.autograd.Function):
+    """my_bert/cl_modeling.py:1363-1371:  Gate = sigmoid(Gate_text(seq) + Gate_image(cross));
+    logits = classifier(cat(seq, Gate * cross)).  Neither concat is materialised: the gate GEMM reads its K
+    reduction from two buffers / two weight matrices, and so does the classifier GEMM."""
+
+    @staticmethod
+    def forward(ctx, anchor, seq, cross, head, A: ParamArena):
+        M, H = seq.shape
+        C = head.classifier.weight.shape[0]
+        gate = torch.empty(M, H, dtype=BF16, device=seq.device)
+        gated = torch.empty_like(gate)
+        K.gemm(K.GEMM_NT, seq, A.w(head.Gate_text.weight), gated, A2=cross, B2=A.w(head.Gate_image.weight),
+               bias=head.Gate_text.bias, bias2=head.Gate_image.bias, epilogue=K.EPI_GATE, aux=cross, out2=gate)
+        Wc = A.w(head.classifier.weight)
+        logits = torch.empty(M, C, dtype=F32, device=seq.device)
+        K.gemm(K.GEMM_NT, seq, Wc[:, :H], logits, A2=gated, B2=Wc[:, H:], bias=head.classifier.bias)
+        ctx.head, ctx.A = head, A
+        ctx.save_for_backward(seq, cross, gate, gated)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        seq, cross, gate, gated = ctx.saved_tensors
+        head, A = ctx.head, ctx.A
+        M, H = seq.shape
+        C = dlogits.shape[1]
+        if dlogits.dtype == BF16 and dlogits.stride(1) == 1 and dlogits.stride(0) % 8 == 0:
+            dl = dlogits                          # fused token-CE hands over a padded bf16 buffer view
+        else:
+            buf = torch.empty(M, (C + 7) // 8 * 8, dtype=BF16, device=seq.device)
+            K.cast_pad_f32_to_bf16(dlogits.float() if dlogits.dtype != F32 else
+                                   (dlogits if dlogits.stride(1) == 1 else dlogits.contiguous()), buf)
+            dl = buf[:, :C]
+        cls = head.classifier
+        gW = A.g(cls.weight)
+        beta = A.grad_beta(cls.weight)
+        K.gemm(K.GEMM_TN, dl, seq, gW[:, :H], beta=beta)
+        K.gemm(K.GEMM_TN, dl, gated, gW[:, H:], beta=beta)
+        csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(max(H, C)))
+        K.colsum(dl, A.g(cls.bias), csw, accumulate=A.grad_beta(cls.bias) > 0)
+        Wc = A.w(cls.weight)
+        dseq_c = torch.empty(M, H, dtype=BF16, device=seq.device)
+        dgated = torch.empty_like(dseq_c)
+        K.gemm(K.GEMM_NN, dl, Wc[:, :H], dseq_c)
+        K.gemm(K.GEMM_NN, dl, Wc[:, H:], dgated)
+        du = torch.empty_like(dseq_c)
+        dcross_d = torch.empty_like(dseq_c)
+        K.gate_bwd(dgated, gate, cross, du, dcross_d)
+        K.gemm(K.GEMM_TN, du, seq, A.g(head.Gate_text.weight), beta=A.grad_beta(head.Gate_text.weight))
+        K.gemm(K.GEMM_TN, du, cross, A.g(head.Gate_image.weight), beta=A.grad_beta(head.Gate_image.weight))
+        K.colsum(du, A.g(head.Gate_text.bias), csw, accumulate=A.grad_beta(head.Gate_text.bias) > 0)
+        K.colsum(du, A.g(head.Gate_image.bias), csw, accumulate=A.grad_beta(head.Gate_image.bias) > 0)
+        dseq = torch.empty_like(dseq_c)
+        dcross = torch.empty_like(dseq_c)
+        K.gemm(K.GEMM_NN, du, A.w(head.Gate_text.weight), dseq, epilogue=K.EPI_ADD, aux=dseq_c)
+        K.gemm(K.GEMM_NN, du, A.w(head.Gate_image.weight), dcross, epilogue=K.EPI_ADD, aux=dcross_d)
+        return None, dseq, dcross, None, None
+
+
+class TokenCEFn(torch.autograd.Function):
+    """Benchmark loss: token-level cross-entropy, mean over valid tokens.  One launch yields
+    the loss accumulators and the unscaled logit gradient; dloss / #valid is applied on device (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, mask):
+        M, C = logits.shape
+        stats = torch.zeros(3, dtype=F32, device=logits.device)
+        dl = torch.empty(M, (C + 7) // 8 * 8, dtype=BF16, device=logits.device)
+        K.token_ce(logits, labels.reshape(-1), mask.reshape(-1), stats[0:1], stats[1:2], dl)
+        K.scalar_ratio(stats[2:3], stats[0:1], stats[1:2])
+        ctx.C = C
+        ctx.save_for_backward(dl, stats)
+        return stats[2:3].view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dl, stats = ctx.saved_tensors
+        g = dloss.reshape(1)
+        if g.dtype != F32:
+            raise TypeError("loss gradient must be f32")
+        out = torch.empty_like(dl)
+        K.scale_by_ratio(dl, out, num=g.contiguous(), den=stats[1:2])
+        return out[:, :ctx.C], None, None

@@ -57,6 +57,7 @@ typedef struct icka_gemm_desc {
     void* C2; int64_t ldc2;                     /* bf16 second output (GELU: z, GATE: g) */
     const void* aux; int64_t ldaux;             /* bf16 epilogue operand */
     const float* bias;                          /* f32 [N] or NULL */
+    const float* bias2;                         /* optional second f32 [N] bias (two Linear layers summed) */
     float alpha, beta;
     int32_t epilogue;      /* ICKA_EPI_* */
 } icka_gemm_desc;
@@ -65,36 +66,41 @@ int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused  y = LayerNorm(dropout(x + bias) + residual)   (BertSelfOutput.forward :561-565, BertOutput.forward
  * :532-536, BertLayerNorm.forward :518-522: biased variance, eps inside the sqrt).  One wave per row.
- *   x [M,H] bf16 (row stride ldx), bias f32[H] or NULL, residual [M,H] bf16 (ldr) or NULL, gamma/beta f32[H];
- *   y [M,H] bf16 (ldy); y2 optional second copy of y (ldy2); xhat [M,H] bf16 contiguous and rstd f32[M] are the
- *   saved statistics for backward (may be NULL in inference).
+ *   x [M,H] bf16 or f32 (x_is_f32; row stride ldx in elements), bias f32[H] or NULL, residual [M,H] bf16 or f32
+ *   (res_is_f32; ldr) or NULL, gamma/beta f32[H];  y [M,H] bf16 (ldy) is the MFMA operand of the next GEMM; y2
+ *   optional second bf16 copy (ldy2); y_f32 optional contiguous f32 copy (the residual stream is carried in f32
+ *   so bf16 rounding does not accumulate over layers); xhat [M,H] bf16 contiguous and rstd f32[M] are the saved
+ *   statistics for backward (may be NULL in inference).
  */
-int icka_ln_fwd(const void* x, int64_t ldx, const float* bias, const void* residual, int64_t ldr,
-                const float* gamma, const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2,
-                void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop, uint64_t seed, void* stream);
+int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual, int64_t ldr,
+                int32_t res_is_f32, const float* gamma, const float* beta, void* y, int64_t ldy, void* y2,
+                int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop,
+                uint64_t seed, void* stream);
 /* Backward of the above.  dy (+ optional dy2) are the incoming gradients of y.  Outputs: dres = gradient of the
  * residual input (bf16, may be NULL), dx = gradient of x (dropout mask re-generated from seed; may be NULL),
- * and f32 accumulations (+=) dgamma[H], dbeta[H], dbias[H] (dbias may be NULL).  `partials` is f32 workspace of
- * icka_ln_bwd_workspace_floats(H) floats. */
+ * and the f32 parameter gradients dgamma[H], dbeta[H], dbias[H] (dbias may be NULL): added to the existing values
+ * when accumulate != 0, overwritten otherwise.  `partials` is f32 workspace of icka_ln_bwd_workspace_floats(H). */
 int64_t icka_ln_bwd_workspace_floats(int32_t H);
 int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat, const float* rstd,
                 const float* gamma, void* dres, int64_t lddres, void* dx, int64_t lddx, float* dgamma, float* dbeta,
-                float* dbias, float* partials, int32_t M, int32_t H, float p_drop, uint64_t seed, void* stream);
+                float* dbias, float* partials, int32_t M, int32_t H, float p_drop, uint64_t seed, int32_t accumulate,
+                void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * BertEmbeddings.forward (:398-412): y = dropout(LayerNorm(word[ids] + pos[arange(S)] + type[tt])).
  * Tables are the fp32 master parameters (gathered directly, no shadow copy).  ids/tt are int64 [B*S].
  */
 int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
-                   const float* type, const float* gamma, const float* beta, void* y, void* xhat, float* rstd,
-                   int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps, float p_drop,
-                   uint64_t seed, void* stream);
-/* Backward: accumulates (+=) into the f32 gradient tables.  Row `padding_idx` of the word table receives no
- * gradient (nn.Embedding(padding_idx=0), :387).  partials: icka_ln_bwd_workspace_floats(H) floats. */
+                   const float* type, const float* gamma, const float* beta, void* y, float* y_f32, void* xhat,
+                   float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps,
+                   float p_drop, uint64_t seed, void* stream);
+/* Backward.  dword / dpos are ALWAYS accumulated into with f32 atomics (the caller zeroes them for a fresh
+ * gradient); dtype / dgamma / dbeta follow `accumulate` as in icka_ln_bwd.  Row `padding_idx` of the word table
+ * receives no gradient (nn.Embedding(padding_idx=0), :387).  partials: icka_ln_bwd_workspace_floats(H) floats. */
 int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
                    const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma,
                    float* dbeta, float* partials, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type,
-                   int32_t padding_idx, float p_drop, uint64_t seed, void* stream);
+                   int32_t padding_idx, float p_drop, uint64_t seed, int32_t accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused multi-head attention, head size 64 (bert-base 768/12, bert-large 1024/16).
@@ -120,6 +126,10 @@ int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
 /* fp32 -> bf16 cast of a flat buffer (parameter shadow refresh); n elements. */
 int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int icka_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* 2-D cast with zero padding: dst bf16 [M, ldd] ; dst[:, :N] = src f32 [M,N] (row stride lds), dst[:, N:ldd] = 0.
+ * (logit gradients [M,C] -> a 16-byte-aligned bf16 GEMM operand.) */
+int icka_cast_pad_f32_to_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int32_t M, int32_t N,
+                              void* stream);
 /* int64 0/1 mask [B, T] (row stride ld, first T columns used) -> additive f32 [B,T] = (1-m)*-10000  (:364-372). */
 int icka_additive_mask(const int64_t* mask, int64_t ld, float* out, int32_t B, int32_t T, void* stream);
 /* y = dropout(x) with the counter-hash mask; the same call with the same seed is its own backward (nn.Dropout,
@@ -143,11 +153,14 @@ int icka_gate_bwd(const void* dout, int64_t lddout, const void* g, const void* c
 int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, void* stream);
 /* Token-level cross-entropy over valid tokens (benchmark loss), fused forward + backward:
  * logits f32 [M,C] (ld), labels/mask int64 [M]; loss_sum f32[1] += sum of -log p ; count f32[1] += #valid ;
- * dlogits bf16 [M, ldd] (ldd >= C, pad columns zeroed) = (softmax - onehot) * valid  (caller scales by 1/count). */
+ * dlogits bf16 [M, ldd] (ldd >= C, pad columns zeroed) = (softmax - onehot) * valid  (see icka_scale_by_ratio). */
 int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* loss_sum,
                   float* count, void* dlogits, int64_t ldd, int32_t M, int32_t C, void* stream);
-/* x *= s[0] (device scalar reciprocal) for bf16 [n]; used to apply 1/count to dlogits without a host sync. */
-int icka_scale_by_inv(void* x, const float* denom, int64_t n, void* stream);
+/* y = x * num[0] / max(den[0], 1) for bf16 [n] with DEVICE scalars (NULL = 1): applies dloss / #valid to the
+ * logit gradients without a host sync.  y may alias x. */
+int icka_scale_by_ratio(const void* x, void* y, const float* num, const float* den, int64_t n, void* stream);
+/* out[0] = num[0] / max(den[0], 1)   (mean loss from the two accumulators of icka_token_ce). */
+int icka_scalar_ratio(float* out, const float* num, const float* den, void* stream);
 /* Debug/test helper: materialise the dropout keep-multiplier (0 or 1/(1-p)) for element indices [0,n) as f32. */
 int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t seed, void* stream);
 

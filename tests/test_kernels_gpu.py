@@ -158,7 +158,12 @@ def test_ln_fwd_bwd(M, H, p):
         assert torch.all((mask == 0) | ((mask - 1 / (1 - p)).abs() < 1e-6))
     y = torch.empty(M, H, dtype=BF16, device="cuda"); y2 = torch.empty(M, 2 * H, dtype=BF16, device="cuda")
     xhat = torch.empty_like(y); rstd = torch.empty(M, dtype=F32, device="cuda")
-    k.ln_fwd(x, bias, res, gamma, beta, y, y2=y2[:, H:], xhat=xhat, rstd=rstd, eps=1e-12, p_drop=p, seed=seed)
+    yf = torch.empty(M, H, dtype=F32, device="cuda")
+    k.ln_fwd(x, bias, res, gamma, beta, y, y2=y2[:, H:], y_f32=yf, xhat=xhat, rstd=rstd, eps=1e-12, p_drop=p, seed=seed)
+    assert torch.equal(yf.to(BF16), y)
+    ya = torch.empty_like(y)   # f32 input / f32 residual variants agree with the bf16 ones on the same values
+    k.ln_fwd(x.float(), bias, res.float(), gamma, beta, ya, eps=1e-12, p_drop=p, seed=seed)
+    assert torch.equal(ya, y)
     xf = x.float().requires_grad_(True); rf = res.float().requires_grad_(True)
     bf = bias.clone().requires_grad_(True); gf = gamma.clone().requires_grad_(True); b2 = beta.clone().requires_grad_(True)
     yref, xhref = _ln_ref(xf, bf, rf, gf, b2, mask, 1e-12)
@@ -330,7 +335,7 @@ def test_token_ce():
     loss_sum = torch.zeros(1, device="cuda"); count = torch.zeros(1, device="cuda")
     dl = torch.empty(M, 16, dtype=BF16, device="cuda")
     k.token_ce(logits, labels, mask, loss_sum, count, dl)
-    k.scale_by_inv(dl, count)
+    k.scale_by_ratio(dl, dl, den=count)
     lg = logits.clone().requires_grad_(True)
     tgt = torch.where(mask.bool(), labels, torch.full_like(labels, -100))
     ref = torch.nn.functional.cross_entropy(lg, tgt, ignore_index=-100)
