@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""bench.py -- MNER samples/s (forward + backward) on MI355X, the metric of BASELINE.json.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "c2"): bert-base text encoder (H768 L12 h12 I3072) + 36 x 2048 region features,
+seq_len 128, per-GPU batch 32, 1 cross-attention layer, gated head, 13 labels; bf16 MFMA compute with fp32
+accumulation/statistics; train mode (dropout 0.1 active); loss = token-level cross-entropy over valid tokens;
+synthetic Twitter-2015-shaped batches and seeded random-init weights (icka_amd.synth).  One step = forward +
+backward of one batch per GPU (+ RCCL gradient all-reduce when N > 1, overlapped with backward).  The optimizer
+step is outside the metric and reported separately by --with-optimizer.
+
+Rank 0 prints ONE JSON line with the contract's keys plus
+  roofline      -- the dominant kernel class (the MFMA GEMMs: >= 97 % of algorithmic FLOPs): algorithmic FLOPs of the
+                   GEMM launches of one step / their summed duration, measured with HIP events on the launch stream
+                   in an instrumented pass after the timed region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH).
+  cpu_baseline  -- the CPU oracle (oracle/mner_oracle.py; PyTorch CPU eager fp32, same op sequence as the reference)
+                   timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container on a
+    big host reports every host core in os.cpu_count(); oversubscribing the quota makes the CPU leg crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def flops_per_sample(S, R, H, I, L, Lc, C):
+    """Algorithmic GEMM FLOPs, forward, per sample; fwd+bwd = 3x."""
+    bert = L * (S * (8 * H * H + 4 * H * I) + 4 * S * S * H)
+    cross = Lc * (S * (4 * H * H + 4 * H * I) + 4 * R * H * H + 4 * S * R * H)
+    return bert + cross + 2 * R * 2048 * H + 4 * S * H * H + 4 * S * H * C
+
+
+def build_model(args, dev):
+    from icka_amd import synth
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    cfg = BertConfig(30522, hidden_size=args.hidden, num_hidden_layers=args.layers,
+                     num_attention_heads=args.hidden // 64, intermediate_size=4 * args.hidden)
+    model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=args.cross_layers, num_labels=args.labels,
+                                                 regions=args.regions)
+    synth.fill_module_(model)
+    return model.to(dev).train(), cfg
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement of the reference path), fwd+bwd, train mode, on a bounded sample of the workload."""
+    from icka_amd import synth
+    from oracle import mner_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d threads (os.cpu_count()=%s)" % (cores, os.cpu_count()))
+    ocfg = O.OracleConfig(vocab_size=30522, hidden_size=args.hidden, num_hidden_layers=args.layers,
+                          num_attention_heads=args.hidden // 64, intermediate_size=4 * args.hidden)
+    shapes = O.hot_path_keys(ocfg, args.cross_layers, args.labels)
+    P = {k: v.requires_grad_(True) for k, v in synth.seeded_state_dict(shapes).items()}
+    bs = args.cpu_batch
+    b = synth.synthetic_batch(bs, args.seq, args.regions, num_labels=args.labels)
+    times = []
+    for it in range(1 + args.cpu_iters):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        logits = O.mner_logits(P, ocfg, b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
+                               b["visual_embeds_att"], args.cross_layers, args.regions, training=True)
+        O.token_ce_loss(logits, b["labels"], b["input_mask"]).backward()
+        dt = time.perf_counter() - t0
+        log("cpu baseline iteration %d: %.2f s" % (it, dt))
+        if it > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(bs / med, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle (PyTorch CPU eager fp32, train mode) fwd+bwd, batch %d x seq %d x %d regions, 1 warm-up + "
+                      "median of %d iterations, %d threads" % (bs, args.seq, args.regions, args.cpu_iters, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--cross-layers", type=int, default=1)
+    ap.add_argument("--labels", type=int, default=13)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--comm-bf16", action="store_true")
+    ap.add_argument("--with-optimizer", action="store_true", help="also time fwd+bwd+AdamW (reported separately)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in icka_amd)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from icka_amd import kernels as K
+    from icka_amd import synth
+    torch.manual_seed(synth.REFERENCE_SEED)
+    log("building model")
+    model, cfg = build_model(args, dev)
+    # each rank draws a disjoint slice of the synthetic stream (reference: DistributedSampler, :707)
+    batch = synth.synthetic_batch(args.batch, args.seq, args.regions, num_labels=args.labels,
+                                  seed=synth.REFERENCE_SEED + rank)
+    g = {k: v.to(dev) for k, v in batch.items()}
+
+    def step():
+        loss = model(g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"],
+                     g["visual_embeds_mean"], g["visual_embeds_att"], labels=g["labels"])
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return loss
+
+    reducer = None
+    step_loss = None
+    log("first step (builds the parameter arena)")
+    # first step builds the arena; attach the reducer afterwards
+    model.zero_grad()
+    loss = model(g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"],
+                 g["visual_embeds_mean"], g["visual_embeds_att"], labels=g["labels"])
+    loss.backward()
+    arena = model._icka_arena
+    if world > 1:
+        from icka_amd.dp import GradReducer
+        reducer = GradReducer(arena, bucket_mb=args.bucket_mb, comm_bf16=args.comm_bf16)
+        reducer.broadcast_parameters(0)
+        arena.reducer = reducer
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-5) if args.with_optimizer else None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("warm-up %d steps" % args.warmup)
+    for _ in range(args.warmup):
+        model.zero_grad()
+        step_loss = step()
+    sync()
+    log("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.zero_grad()          # set_to_none: the backward overwrites the gradient arena, no memset
+        step_loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    ms_per_step = 1e3 * dt / args.steps
+    samples_per_s = args.batch * world * args.steps / dt
+    final_loss = float(step_loss.item())
+    log("%.3f ms/step, %.1f samples/s, loss %.4f" % (ms_per_step, samples_per_s, final_loss))
+
+    opt_ms = None
+    if opt is not None:
+        for _ in range(3):
+            model.zero_grad(); step(); opt.step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            model.zero_grad(); step(); opt.step()
+        sync()
+        opt_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+
+    # ---- roofline of the dominant kernel class (MFMA GEMMs), instrumented pass, rank 0 only, N = 1 semantics
+    roof = None
+    fl_sample = 3 * flops_per_sample(args.seq, args.regions, args.hidden, 4 * args.hidden, args.layers,
+                                     args.cross_layers, args.labels)
+    if rank == 0 and not args.no_roofline:
+        K.profile_gemm(True)
+        nprof = 3
+        for _ in range(nprof):
+            model.zero_grad()
+            step()
+        torch.cuda.synchronize()
+        flops, ms, launches = K.profile_gemm(False)
+        if ms > 0:
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_kernel<NT|NN|TN> (128x128x64 bf16 MFMA)",
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches // nprof, "avg_launch_us": round(1e3 * ms / launches, 2),
+                    "gemm_ms_per_step": round(ms / nprof, 3),
+                    "whole_step_tflops": round(samples_per_s / world * fl_sample / 1e12, 2),
+                    "whole_step_frac": round(samples_per_s / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {
+            "metric": "MNER samples/sec (fwd+bwd) at seq=%d, %d regions, bs=%d per GPU" % (args.seq, args.regions, args.batch),
+            "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "c2: bert-base(H%d,L%d,h%d,I%d)+%dx2048 regions, seq_len %d, per-GPU batch %d, "
+                                   "%d cross layer(s), gated head, %d labels, train mode p=0.1, token-CE loss"
+                                   % (args.hidden, args.layers, args.hidden // 64, 4 * args.hidden, args.regions,
+                                      args.seq, args.batch, args.cross_layers, args.labels),
+                       "global_batch": args.batch * world, "seq_len": args.seq, "regions": args.regions,
+                       "parallelism": "dp%d" % world, "flops_per_sample_fwd_bwd": fl_sample},
+            "loss": round(final_loss, 5),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if opt_ms is not None:
+            out["ms_per_step_with_adamw"] = round(opt_ms, 3)
+        if cpu is not None:
+            out["gpu_over_cpu"] = round(samples_per_s / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

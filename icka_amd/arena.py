@@ -69,6 +69,8 @@ class ParamArena(object):
         # autograd anchor: a leaf that requires grad, passed to every Function so that backward runs even when
         # no *tensor input* requires grad (parameters are read from the arena, not passed through autograd)
         self.anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+        self.reducer = None          # optional dp.GradReducer: overlaps bucket all-reduces with backward
+        self._pending_final: List[Slot] = []
         self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self._seed_ctr = 0
 
@@ -173,9 +175,16 @@ class ParamArena(object):
             if not s.live:
                 s.live = True
                 self._touched.append(s)
+            self._pending_final.append(s)
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * s.off:
                 p.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
         return 1.0 if live else 0.0
+
+    def flush_final(self) -> None:
+        """End of a block's backward: every gradient slot written since the last flush is final for this step."""
+        if self.reducer is not None and self._pending_final:
+            self.reducer.mark_final(self._pending_final)
+        self._pending_final = []
 
     def zero_grad(self) -> None:
         self.gflat.zero_()

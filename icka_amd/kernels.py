@@ -47,6 +47,23 @@ def _ld(t: Optional[torch.Tensor]) -> int:
 
 
 # ------------------------------------------------------------------------------------------------------- GEMM
+_PROF = None   # None, or a list of (start_event, stop_event, flops) while profile_gemm(True) is active
+
+
+def profile_gemm(enable: bool):
+    """Instrument every GEMM launch with a pair of HIP events on the launch stream (bench.py roofline leg).
+    profile_gemm(True) starts collecting; profile_gemm(False) returns (algorithmic FLOPs, summed ms, launches)."""
+    global _PROF
+    if enable:
+        _PROF = []
+        return None
+    rec, _PROF = _PROF or [], None
+    torch.cuda.synchronize()
+    flops = sum(f for _, _, f in rec)
+    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    return flops, ms, len(rec)
+
+
 def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
          alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
@@ -94,6 +111,13 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: 
         raise ValueError("bias2 must be contiguous device f32 [N]")
     d.bias2 = _ptr(bias2)
     d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
+    if _PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
+        e1.record()
+        _PROF.append((e0, e1, 2.0 * M * N * K))
+        return out
     check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
     return out
 

@@ -143,6 +143,7 @@ class _LayerNormFn(torch.autograd.Function):
         acc = A.grad_beta((mod.weight, mod.bias)) > 0
         K.ln_bwd(dy, xhat, rstd, mod.weight, dres=dx, dgamma=A.g(mod.weight), dbeta=A.g(mod.bias), partials=ws,
                  accumulate=acc)
+        A.flush_final()
         return None, dx, None, None
 
 

@@ -209,6 +209,7 @@ class EmbeddingsFn(torch.autograd.Function):
         acc = A.grad_beta(small) > 0
         K.embed_bwd(dy, ids, tt, xhat, rstd, mod.LayerNorm.weight, A.g(tables[0]), A.g(tables[1]), A.g(small[0]),
                     A.g(small[1]), A.g(small[2]), ws, padding_idx=0, p_drop=d.p_hidden, seed=ctx.seed, accumulate=acc)
+        A.flush_final()
         return None, None, None, None, None, None
 
 
@@ -232,6 +233,7 @@ class BertLayerFn(torch.autograd.Function):
         dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
         dx, _ = _attn_block_bwd(A, layer.attention, x, None, add_mask, d, d.S, ctx.s_att, dx1, None, False)
         ctx.s_att = ctx.s_ffn = None
+        A.flush_final()
         return None, dx, None, None, None, None, None
 
 
@@ -256,6 +258,7 @@ class CrossLayerFn(torch.autograd.Function):
         dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
         ds1, ds2 = _attn_block_bwd(A, layer.attention, s1, s2, add_mask, d, d.R, ctx.s_att, dx1, None, ctx.need_s2)
         ctx.s_att = ctx.s_ffn = None
+        A.flush_final()
         return None, ds1, None, ds2, None, None, None, None
 
 
@@ -296,6 +299,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.need_dx:
             dx = torch.empty_like(x)
             K.gemm(K.GEMM_NN, dyv, A.w(lin.weight), dx)
+        A.flush_final()
         return None, dx, None, None, None, None
 
 
@@ -374,6 +378,7 @@ class GatedHeadFn(torch.autograd.Function):
         dcross = torch.empty_like(dseq_c)
         K.gemm(K.GEMM_NN, du, A.w(head.Gate_text.weight), dseq, epilogue=K.EPI_ADD, aux=dseq_c)
         K.gemm(K.GEMM_NN, du, A.w(head.Gate_image.weight), dcross, epilogue=K.EPI_ADD, aux=dcross_d)
+        A.flush_final()
         return None, dseq, dcross, None, None
 
 
