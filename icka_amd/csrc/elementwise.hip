@@ -128,13 +128,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
             partial[(int64_t)blockIdx.y * N + col + e] = red[0][cx][e] + red[1][cx][e] + red[2][cx][e] + red[3][cx][e];
     }
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int N,
-                                       int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                               int groups, int N, int accumulate) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += partial[(int64_t)g * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < N)
+        for (int g = sy; g < groups; g += 16) s += partial[(int64_t)g * N + c];
+    red[sy][cx] = s;
+    __syncthreads();
+    if (sy == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 __global__ void gate_bwd_kernel(const bf16_t* __restrict__ dout, int64_t lddout, const bf16_t* __restrict__ g,
@@ -294,7 +303,7 @@ extern "C" int icka_colsum(const void* x, int64_t ldx, float* out, float* partia
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, groups), dim3(256), 0, st, (const bf16_t*)x, ldx, partials, M,
                        N, rpg, vec);
     ICKA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partials, out, groups, N, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, partials, out, groups, N, accumulate);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

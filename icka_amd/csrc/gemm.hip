@@ -27,6 +27,7 @@ struct GemmArgs {
     float alpha, beta;
     int epi, c_f32;
     int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
+    int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
 };
 
 // k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
@@ -263,10 +264,264 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
     }
 }
 
+
+// =====================================================================================================================
+// Fast path (M % 128 == 0, N % 128 == 0, K % 64 == 0, 16-B aligned operands): same tile / MFMA / LDS images as above,
+// but (1) tiles are staged by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no
+// staging VGPRs, no ds_write pass) -- the swizzle is applied to the per-lane SOURCE address because the DMA
+// destination is lane-linear -- with the next k-tile's DMA issued before the current tile's MFMAs, one barrier per
+// k-tile; (2) the epilogue goes through LDS as an f32 [128][128] tile (XOR-swizzled 16-B chunks) so that every
+// thread finishes 8 consecutive columns of a row: bias / activation / fan-in operands and the C stores are all
+// 16-byte, row-contiguous accesses (whole 256-B rows per 16 lanes) instead of 8-byte stores scattered over 16 rows.
+// Per-lane SOURCE pointers of the 4 one-KiB pieces a wave stages per operand tile (k-tile 0).  They advance by a
+// wave-uniform stride per k-tile, so the k-loop carries no address arithmetic beyond 8 pointer bumps.
+template <bool KM>
+__device__ __forceinline__ void dma_init(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int row0,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave + 4 * j;  // 1-KiB piece: 8 tile rows (k-contiguous image) or 4 k-rows (k-major image)
+        if (!KM) {
+            const int row = 8 * p + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            ptr[j] = P + (int64_t)(row0 + row) * ld + 8 * lc;
+        } else {
+            const int kr = 4 * p + (lane >> 4);
+            const int lc = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+            ptr[j] = P + (int64_t)kr * ld + row0 + 8 * lc;
+        }
+    }
+}
+// Issue the 4 LDS-DMA loads of one operand tile (pieces wave, wave+4, wave+8, wave+12 -> 4 KiB apart) from INLINE
+// ASM: hipcc treats a compiler-visible LDS-DMA as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the
+// next ds_read_b64_tr_b16, which serialises the whole pipeline; hidden in asm, the ring is ordered only by our own
+// counted vmcnt + s_barrier (cdna guide section 5.7).  M0 (LDS destination base) is saved/restored inside.
+__device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t stride, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "s"(lds_base)
+        : "memory", "scc");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ptr[j] += stride;
+}
+
+// f32 C tile in LDS: [128 rows][32 chunks of 4 floats], chunk index XORed with row&31
+__device__ __forceinline__ uint32_t off_c(int row, int ch) { return row * 512 + ((ch ^ (row & 31)) << 4); }
+
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+}
+
+template <bool A_KM, bool B_KM, int NBUF, int ABL>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[(NBUF < 2 ? 2 : NBUF) * 2 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int nbn = g.N / BN;
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
+    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    const int k1t = g.K1 > 0 ? g.K1 / BK : -1;  // k-tile at which the reduction switches to (A2, B2)
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    dma_init<A_KM>(pa, g.A, g.lda, m0, wave, lane);
+    dma_init<B_KM>(pb, g.B, g.ldb, n0, wave, lane);
+    int64_t sa = A_KM ? (int64_t)BK * g.lda : BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+
+#define ICKA_STAGE(KT, BUF)                                             \
+    do {                                                                \
+        if ((KT) == k1t) {                                              \
+            dma_init<A_KM>(pa, g.A2, g.lda2, m0, wave, lane);           \
+            dma_init<B_KM>(pb, g.B2, g.ldb2, n0, wave, lane);           \
+            sa = A_KM ? (int64_t)BK * g.lda2 : BK;                      \
+            sb = B_KM ? (int64_t)BK * g.ldb2 : BK;                      \
+        }                                                               \
+        dma_issue(pa, sa, lds0 + (BUF) + wave * 1024);                  \
+        dma_issue(pb, sb, lds0 + (BUF) + TILE_BYTES + wave * 1024);     \
+    } while (0)
+
+    // LDS ring of NBUF stages, prefetch distance NBUF-1 k-tiles.  Each wave waits for ITS pieces of tile kt with a
+    // counted vmcnt (the 8 DMA of tile kt+1 may stay in flight), then one raw s_barrier makes every wave's pieces
+    // visible and also proves all waves finished reading the buffer that the next DMA overwrites.
+    // prologue: fill NBUF-1 stages
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+        if (t < nk) ICKA_STAGE(t, t * 2 * TILE_BYTES);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles kt+1 .. min(kt+NBUF-2, nk-1) may stay in flight (8 DMA each per wave)
+        int ahead = nk - 1 - kt;
+        ahead = ahead > NBUF - 2 ? NBUF - 2 : ahead;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NBUF - 1 < nk && ABL != 2) {
+            int nx = cur + NBUF - 1;
+            nx = nx >= NBUF ? nx - NBUF : nx;
+            ICKA_STAGE(kt + NBUF - 1, nx * 2 * TILE_BYTES);
+        }
+        const char* sA = smem + cur * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+        if (ABL != 1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = read_frag<A_KM>(sA, wr + 16 * t, ks, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+        }
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+    }
+#undef ICKA_STAGE
+    __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
+
+    // ---- epilogue through LDS (all waves are past the last barrier: the operand buffers are dead)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = wr + 16 * mi + (lane & 15);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
+            *reinterpret_cast<f32x4*>(smem + off_c(row, ch)) = acc[mi][ni] * g.alpha;
+        }
+    }
+    __syncthreads();
+    const int c8 = tid & 15;           // 8-column group of the row
+    const int n = n0 + 8 * c8;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (g.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
+    }
+    if (g.bias2) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias2 + n), b1 = *reinterpret_cast<const f32x4*>(g.bias2 + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (tid >> 4) + 16 * i;
+        const int m = m0 + row;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8 + 1));
+        float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
+                      hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
+        float a[8];
+        switch (g.epi) {
+            case ICKA_EPI_GELU:
+                store8_bf16(g.C2 + (int64_t)m * g.ldc2 + n, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                break;
+            case ICKA_EPI_DGELU:
+                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(a[e]);
+                break;
+            case ICKA_EPI_ADD:
+                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += a[e];
+                break;
+            case ICKA_EPI_GATE:
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
+                if (g.C2) store8_bf16(g.C2 + (int64_t)m * g.ldc2 + n, v);
+                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= a[e];
+                break;
+            case ICKA_EPI_TANH:
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                break;
+            default: break;
+        }
+        if (g.c_f32) {
+            float* p = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
+            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            if (g.beta != 0.f) {
+                o0 += g.beta * *reinterpret_cast<const f32x4*>(p);
+                o1 += g.beta * *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            *reinterpret_cast<f32x4*>(p) = o0;
+            *reinterpret_cast<f32x4*>(p + 4) = o1;
+        } else {
+            bf16_t* p = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
+            if (g.beta != 0.f) {
+                load8_bf16(p, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += g.beta * a[e];
+            }
+            store8_bf16(p, v);
+        }
+    }
+}
+
+int g_abl = 0;
+int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
+
 template <bool A_KM, bool B_KM>
 int launch(const GemmArgs& g, bool aligned, hipStream_t st) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    if (aligned) hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, true>), dim3(nb), dim3(256), 0, st, g);
+    if (aligned) {
+#ifdef ICKA_GEMM_ABLATE
+        if (g_abl == 1) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(256), 0, st, g);
+        else if (g_abl == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(256), 0, st, g);
+        else
+#endif
+        // ring depth: many tiles per CU -> two co-resident blocks (64 KiB ring of 2) overlap one block's epilogue with
+        // the other's main loop; few tiles -> one block per CU with a deeper ring (measured, tools/gemm_bench.py)
+        const int nbuf = g_nbuf > 0 ? g_nbuf : (nb >= 448 ? 2 : 3);
+        if (nbuf == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 2, 0>), dim3(nb), dim3(256), 0, st, g);
+        else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 0>), dim3(nb), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 4, 0>), dim3(nb), dim3(256), 0, st, g);
+    }
     else hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, false>), dim3(nb), dim3(256), 0, st, g);
     ICKA_CHECK_LAUNCH();
     return 0;
@@ -275,6 +530,17 @@ int launch(const GemmArgs& g, bool aligned, hipStream_t st) {
 inline bool vec_ok(const void* p, int64_t ld) { return (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
 
 }  // namespace
+
+extern "C" int icka_gemm_set_ablation(int mode) {
+    g_abl = mode;
+    return 0;
+}
+
+extern "C" int icka_gemm_set_ring(int nbuf) {
+    if (nbuf != 0 && (nbuf < 2 || nbuf > 4)) return ICKA_E_ARG;
+    g_nbuf = nbuf;
+    return 0;
+}
 
 extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return ICKA_E_ARG;
@@ -291,9 +557,15 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     g.C = d->C; g.ldc = d->ldc; g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
     g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux; g.bias = d->bias; g.bias2 = d->bias2;
     g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
+    g.abl = g_abl;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
-    const bool aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec;
+    auto al = [](const void* p, int64_t ld, int64_t mod) {
+        return !p || (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ld % mod == 0);
+    };
+    const bool aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
+                         al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
+                         al(d->bias, 4, 4) && al(d->bias2, 4, 4);
     hipStream_t st = (hipStream_t)stream;
     switch (d->op) {
         case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st);

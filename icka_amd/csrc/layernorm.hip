@@ -204,17 +204,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     flush_columns<NCH, 3>(acc, lds_f, a.partials, a.H);
 }
 
-// out[slot][c] += sum over slabs; slot s of the slab goes to outs[s] (skipped when NULL).
-__global__ void finalize_kernel(const float* __restrict__ partials, int nslab, int H, float* o0, float* o1, float* o2,
-                                float* o3, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= SLOTS * H) return;
-    const int slot = idx / H, c = idx - slot * H;
-    float* out = slot == 0 ? o0 : slot == 1 ? o1 : slot == 2 ? o2 : o3;
-    if (!out) return;
+// out[slot][c] (+)= sum over slabs.  Block = 64 columns x 16 slab-lanes: the slab loop is split 16 ways and combined
+// through LDS, so the reduction is a few dependent loads deep instead of nslab.
+__global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict__ partials, int nslab, int H, float* o0,
+                                                        float* o1, float* o2, float* o3, int accumulate) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int b = 0; b < nslab; ++b) s += partials[((int64_t)b * SLOTS + slot) * H + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (idx < SLOTS * H) {
+        const int slot = idx / H, c = idx - slot * H;
+        for (int b = sy; b < nslab; b += 16) s += partials[((int64_t)b * SLOTS + slot) * H + c];
+    }
+    red[sy][cx] = s;
+    __syncthreads();
+    if (sy == 0 && idx < SLOTS * H) {
+        const int slot = idx / H, c = idx - slot * H;
+        float* out = slot == 0 ? o0 : slot == 1 ? o1 : slot == 2 ? o2 : o3;
+        if (out) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][cx];
+            out[c] = accumulate ? out[c] + t : t;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- embeddings
@@ -408,7 +421,7 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
     const int grid = bwd_grid(M);
     DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, grid, 3 * H * sizeof(float), st, a);
     ICKA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 255) / 256), dim3(256), 0, st, partials, grid, H, dgamma,
+    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, grid, H, dgamma,
                        dbeta, dbias, (float*)nullptr, accumulate);
     ICKA_CHECK_LAUNCH();
     return 0;
@@ -449,7 +462,7 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
     ICKA_CHECK_LAUNCH();
     float* t0 = n_type <= 2 ? dtype : nullptr;
     float* t1 = n_type == 2 ? dtype + H : nullptr;
-    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 255) / 256), dim3(256), 0, st, partials, grid, H, dgamma,
+    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, grid, H, dgamma,
                        dbeta, t0, t1, accumulate);
     ICKA_CHECK_LAUNCH();
     return 0;

@@ -62,6 +62,11 @@ typedef struct icka_gemm_desc {
     int32_t epilogue;      /* ICKA_EPI_* */
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
+/* Tuning knob of the aligned fast path: depth of the LDS-DMA ring (2: 64 KiB LDS, two blocks per CU; 3 / 4: 96 /
+ * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  Default 4. */
+int icka_gemm_set_ring(int nbuf);
+/* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
+int icka_gemm_set_ablation(int mode);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused  y = LayerNorm(dropout(x + bias) + residual)   (BertSelfOutput.forward :561-565, BertOutput.forward
