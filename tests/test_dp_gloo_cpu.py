@@ -1,0 +1,130 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient path (ParamArena buckets + GradReducer).
+
+Identity under test: N ranks each stepping on their own micro-batch and averaging gradients
+== one rank stepping on the concatenated batch (loss = mean over the global valid tokens needs the per-rank token
+counts, so each rank uses sum-of-token-losses / global_count; here both ranks have the same valid-token count).
+The model math on CPU is the oracle (tests may use it); what is exercised is the product's arena layout, bucket
+partition, overlap bookkeeping (mark_final / finish) and the all-reduce itself.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from icka_amd import synth
+from icka_amd.arena import ParamArena
+from icka_amd.config import BertConfig
+from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+from oracle import mner_oracle as O
+
+CFG = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+           max_position_embeddings=64)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_grads(model, batch):
+    """Oracle forward/backward driven by the product module's own (arena-view) parameters."""
+    P = dict(model.named_parameters())
+    ocfg = O.OracleConfig(vocab_size=512, **CFG)
+    logits = O.mner_logits(P, ocfg, batch["input_ids"], batch["segment_ids"], batch["input_mask"],
+                           batch["added_attention_mask"], batch["visual_embeds_att"], 1, 36)
+    loss = O.token_ce_loss(logits, batch["labels"], batch["input_mask"])
+    grads = torch.autograd.grad(loss, [p for p in P.values()], allow_unused=True)
+    return loss, dict(zip(P.keys(), grads))
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from icka_amd.dp import GradReducer
+    model = MTCCMBertForMMTokenClassificationCRF(BertConfig(512, **CFG), layer_num1=1, num_labels=13, regions=36)
+    synth.fill_module_(model)
+    if rank == 1:   # replicas must not depend on identical init: rank 0's parameters are broadcast
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    arena = ParamArena(model)
+    red = GradReducer(arena, bucket_mb=0.25)
+    assert len(red.buckets) > 3
+    red.broadcast_parameters(0)
+    full = synth.synthetic_batch(4, 32, 36, vocab_size=512, seed=5, ragged=False)
+    mine = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    for step in range(2):   # second step exercises the calibrated (overlapped) bucket bookkeeping
+        _, g = _oracle_grads(model, mine)
+        arena.reducer = red
+        # emulate backward order: blocks finish from the END of the arena; write grads then flush per "block"
+        for s in reversed(arena.order):
+            gi = g[s.name]
+            if gi is None:
+                continue
+            arena.grad_beta(s.param)
+            arena.g(s.param).copy_(gi)
+            arena.flush_final()
+        red.finish()
+    _, gfull = _oracle_grads(model, full)
+    worst = 0.0
+    gmax = max(g.abs().max().item() for g in gfull.values() if g is not None)
+    for s in arena.order:
+        if gfull[s.name] is None:
+            continue
+        ref = gfull[s.name]
+        # key.bias has an exactly-zero true gradient (softmax shift invariance): floor the denominator
+        err = (arena.g(s.param) - ref).abs().max().item() / (ref.abs().max().item() + 1e-6 * gmax)
+        worst = max(worst, err)
+        assert s.param.grad is not None and s.param.grad.data_ptr() == arena.g(s.param).data_ptr()
+    torch.save({"worst": worst, "nb": len(red.buckets), "calibrated": red._calibrated}, os.path.join(tmp, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        assert res["worst"] < 1e-5, res
+        assert res["calibrated"]
+
+
+def test_bucket_partition_covers_arena_in_reverse_order():
+    model = MTCCMBertForMMTokenClassificationCRF(BertConfig(512, **CFG), layer_num1=1, num_labels=13)
+    arena = ParamArena(model)
+    b = arena.buckets(50_000)
+    assert b[0][1] == arena.total and b[-1][0] == 0
+    for (s0, e0), (s1, e1) in zip(b[:-1], b[1:]):
+        assert e1 == s0 and e0 > s0
+    assert all(e - s >= 50_000 for s, e in b[:-1])
+    # fused QKV operands are physically adjacent
+    sa = model.bert.encoder.layer[0].attention.self
+    first, rows = arena._adjacent((sa.query.weight, sa.key.weight, sa.value.weight))
+    assert rows == 3 * 128 and first.name.endswith("query.weight")
+
+
+def test_arena_keeps_state_dict_contract():
+    model = MTCCMBertForMMTokenClassificationCRF(BertConfig(512, **CFG), layer_num1=1, num_labels=13)
+    synth.fill_module_(model)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    arena = ParamArena(model)
+    after = model.state_dict()
+    assert list(before) == list(after)
+    for k in before:
+        assert torch.equal(before[k], after[k]) and after[k].dtype == torch.float32
+    # parameters are views into one flat buffer; loading a checkpoint writes through
+    sd = {k: v + 1 for k, v in before.items()}
+    model.load_state_dict(sd)
+    assert torch.equal(arena.flat[arena.order[0].off:arena.order[0].off + 4],
+                       sd[arena.order[0].name].reshape(-1)[:4])
+    assert arena.valid_for(model)
+    with pytest.raises(RuntimeError):
+        arena.sync()   # bf16 shadows need a device: no CPU path
