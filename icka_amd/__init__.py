@@ -1,0 +1,18 @@
+"""icka_amd -- MI355X-native (gfx950 / CDNA4) implementation of the ICKA multimodal-NER hot path.
+
+Drop-in modules with the reference's names and signatures; every arithmetic step runs in hand-written HIP kernels
+behind a C-ABI (include/icka_hip.h, icka_amd/libicka_hip.so).  No CPU path.
+"""
+from .config import BertConfig
+from .modeling import (BertAttention, BertCoAttention, BertCrossAttention, BertCrossAttentionLayer,
+                       BertCrossEncoder, BertEmbeddings, BertEncoder, BertIntermediate, BertLayer, BertLayerNorm,
+                       BertModel, BertOutput, BertPooler, BertPreTrainedModel, BertSelfAttention, BertSelfEncoder,
+                       BertSelfOutput, MTCCMBertForMMTokenClassificationCRF, token_ce_loss)
+from .arena import ParamArena
+from .dp import GradReducer
+
+__all__ = ["BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
+           "BertSelfEncoder", "BertCrossEncoder", "BertCrossAttentionLayer", "BertAttention", "BertCrossAttention",
+           "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
+           "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "token_ce_loss", "ParamArena",
+           "GradReducer"]
