@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--comm-bf16", action="store_true")
     ap.add_argument("--with-optimizer", action="store_true", help="also time fwd+bwd+AdamW (reported separately)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (tests the "
+                                                              "RCCL path on a single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,8 +152,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from icka_amd import kernels as K
@@ -180,7 +187,7 @@ def main():
                  g["visual_embeds_mean"], g["visual_embeds_att"], labels=g["labels"])
     loss.backward()
     arena = model._icka_arena
-    if world > 1:
+    if use_dist:
         from icka_amd.dp import GradReducer
         reducer = GradReducer(arena, bucket_mb=args.bucket_mb, comm_bf16=args.comm_bf16)
         reducer.broadcast_parameters(0)
@@ -188,24 +195,42 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=3e-5) if args.with_optimizer else None
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- whole-step hipGraph (falls back to eager launches if capture is not possible, e.g. an RCCL build that
+    #      cannot be captured): the timed region then replays the graph
+    mode = "eager"
+    run_step = step
+    if not args.no_graph:
+        try:
+            from icka_amd.graph import GraphedStep
+            log("capturing the step into a hipGraph")
+            gstep = GraphedStep(model, step)
+            run_step = gstep
+            mode = "hipgraph"
+        except Exception as e:  # noqa: BLE001
+            log("graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            run_step = step
+
     log("warm-up %d steps" % args.warmup)
     for _ in range(args.warmup):
-        model.zero_grad()
-        step_loss = step()
+        if mode == "eager":
+            model.zero_grad()
+        step_loss = run_step()
     sync()
-    log("timing %d steps" % args.steps)
+    log("timing %d steps (%s)" % (args.steps, mode))
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.zero_grad()          # set_to_none: the backward overwrites the gradient arena, no memset
-        step_loss = step()
+        if mode == "eager":
+            model.zero_grad()      # set_to_none: the backward overwrites the gradient arena, no memset
+        step_loss = run_step()
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     ms_per_step = 1e3 * dt / args.steps
@@ -216,11 +241,15 @@ def main():
     opt_ms = None
     if opt is not None:
         for _ in range(3):
-            model.zero_grad(); step(); opt.step()
+            if mode == "eager":
+                model.zero_grad()
+            run_step(); opt.step()
         sync()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            model.zero_grad(); step(); opt.step()
+            if mode == "eager":
+                model.zero_grad()
+            run_step(); opt.step()
         sync()
         opt_ms = 1e3 * (time.perf_counter() - t1) / args.steps
 
@@ -231,7 +260,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         K.profile_gemm(True)
         nprof = 3
-        for _ in range(nprof):
+        for _ in range(nprof):   # eager launches: every GEMM bracketed by HIP events on the launch stream
             model.zero_grad()
             step()
         torch.cuda.synchronize()
@@ -250,7 +279,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank == 0:
         out = {
@@ -263,7 +292,7 @@ def main():
                                    % (args.hidden, args.layers, args.hidden // 64, 4 * args.hidden, args.regions,
                                       args.seq, args.batch, args.cross_layers, args.labels),
                        "global_batch": args.batch * world, "seq_len": args.seq, "regions": args.regions,
-                       "parallelism": "dp%d" % world, "flops_per_sample_fwd_bwd": fl_sample},
+                       "parallelism": "dp%d" % world, "flops_per_sample_fwd_bwd": fl_sample, "launch": mode},
             "loss": round(final_loss, 5),
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -272,7 +301,7 @@ def main():
         if cpu is not None:
             out["gpu_over_cpu"] = round(samples_per_s / cpu["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

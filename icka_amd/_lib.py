@@ -39,8 +39,11 @@ PROTOTYPES = {
     "icka_abi_version": (c_i32, []),
     "icka_build_arch": (C.c_char_p, []),
     "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "icka_gemm_grouped": (c_i32, [C.POINTER(GemmDesc), c_i32, c_vp]),
     "icka_gemm_set_ring": (c_i32, [c_i32]),
     "icka_gemm_set_ablation": (c_i32, [c_i32]),
+    "icka_gemm_set_warp_specialized": (c_i32, [c_i32]),
+    "icka_gemm_set_stamp_buffer": (c_i32, [c_vp]),
     "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
                             c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_ln_bwd_workspace_floats": (c_i64, [c_i32]),
@@ -68,6 +71,8 @@ PROTOTYPES = {
     "icka_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "icka_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "icka_scalar_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
+    "icka_set_dropout_nonce": (c_i32, [c_vp]),
+    "icka_bump_dropout_nonce": (c_i32, [c_vp, c_vp]),
     "icka_dropout_mask": (c_i32, [c_vp, c_i64, c_f32, c_u64, c_vp]),
 }
 

@@ -71,6 +71,7 @@ class ParamArena(object):
         self.anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
         self.reducer = None          # optional dp.GradReducer: overlaps bucket all-reduces with backward
         self._pending_final: List[Slot] = []
+        self.pending_wgrad = []      # queued weight-gradient GEMM descriptors (+ keep-alive tensors), see ops._wgrad
         self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self._seed_ctr = 0
 

@@ -65,7 +65,9 @@ struct AttnArgs {
 };
 
 // ------------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_) {
+    AttnArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     __shared__ __attribute__((aligned(16))) char smem[3 * TILE_B];
     char* sQ = smem; char* sK = smem + TILE_B; char* sV = smem + 2 * TILE_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i15 = lane & 15;
@@ -177,7 +179,9 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ O, int64_t ldo, con
 }
 
 // ---------------------------------------------------------------------------------------------------- dQ kernel
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_) {
+    AttnArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];
     char* sQ = smem; char* sDO = smem + TILE_B; char* sK = smem + 2 * TILE_B; char* sV = smem + 3 * TILE_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i15 = lane & 15;
@@ -248,7 +252,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------- dK/dV kernel
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_) {
+    AttnArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B + 2 * TILE * 4];
     char* sK = smem; char* sV = smem + TILE_B; char* sQ = smem + 2 * TILE_B; char* sDO = smem + 3 * TILE_B;
     float* s_lse = reinterpret_cast<float*>(smem + 4 * TILE_B);

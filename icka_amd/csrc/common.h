@@ -62,11 +62,20 @@ struct DropCfg {
     uint32_t s0, s1;   // 64-bit seed halves
     uint32_t thr;      // drop if hash < thr ; thr = p * 2^32
     float scale;       // 1 / (1 - p)
+    const uint32_t* nonce;  // optional device words XORed into the seed at kernel start: a captured hipGraph replays
+                            // the same seed VALUES, the nonce (bumped by a node of the graph) makes every replay draw
+                            // fresh masks while forward and backward of one step still agree
 };
+extern const uint32_t* g_icka_nonce;   // set by icka_set_dropout_nonce (elementwise.hip)
 __host__ __device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed) {
     DropCfg d;
     d.s0 = (uint32_t)seed;
     d.s1 = (uint32_t)(seed >> 32);
+#ifndef __HIP_DEVICE_COMPILE__
+    d.nonce = g_icka_nonce;
+#else
+    d.nonce = nullptr;
+#endif
     if (p <= 0.f) { d.thr = 0u; d.scale = 1.f; }
     else {
         double t = (double)p * 4294967296.0;
@@ -82,16 +91,40 @@ __host__ __device__ __forceinline__ uint32_t icka_hash(uint32_t s0, uint32_t s1,
     x ^= x >> 16;
     return x;
 }
+// fold the device nonce into the seed (call once at kernel entry)
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg d) {
+    if (d.nonce && d.thr) { d.s0 ^= d.nonce[0]; d.s1 ^= d.nonce[1]; }
+    return d;
+}
 // multiplier applied to a kept element: scale if kept, 0 if dropped
 __device__ __forceinline__ float drop_mul(const DropCfg& d, uint32_t idx) {
     return (d.thr == 0u || icka_hash(d.s0, d.s1, idx) >= d.thr) ? d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// erf-GELU (Cross_Modal_Interaction_Module.py:31-37) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (Cross_Modal_Interaction_Module.py:31-37) and its derivative.
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 grid of the outputs): one v_rcp, one v_exp
+// and five FMAs instead of libm's erff -- the GEMM epilogues evaluate it 16K times per 128x128 tile.
+// Returns erf(x/sqrt2) and, through `e`, exp(-x*x/2) (shared with the Gaussian term of the derivative).
+__device__ __forceinline__ float erf_gauss(float x, float& e) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.f + 0.3275911f * u);
+    e = __expf(-u * u);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    return copysignf(1.f - p * t * e, x);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e;
+    return 0.5f * x * (1.f + erf_gauss(x, e));
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float e;
+    const float er = erf_gauss(x, e);
+    return 0.5f * (1.f + er) + x * 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 

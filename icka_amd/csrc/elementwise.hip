@@ -56,7 +56,8 @@ __global__ void additive_mask_kernel(const int64_t* __restrict__ mask, int64_t l
 }
 
 __global__ void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
-                               bf16_t* __restrict__ y2, int64_t ldy2, int M, int H, DropCfg d) {
+                               bf16_t* __restrict__ y2, int64_t ldy2, int M, int H, DropCfg d_) {
+    const DropCfg d = drop_resolve(d_);
     const int cpr = H >> 3;
     const int64_t total = (int64_t)M * cpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -72,7 +73,8 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t
     }
 }
 
-__global__ void dropout_mask_kernel(float* out, int64_t n, DropCfg d) {
+__global__ void dropout_mask_kernel(float* out, int64_t n, DropCfg d_) {
+    const DropCfg d = drop_resolve(d_);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = drop_mul(d, (uint32_t)i);
 }
@@ -221,13 +223,32 @@ __global__ void scale_ratio_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = f2bf(bf2f(x[i]) * s);
 }
+__global__ void bump_nonce_kernel(uint32_t* p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t a = p[0] + 0x9E3779B9u;
+        p[0] = a;
+        p[1] = icka_hash(a, 0x85EBCA6Bu, p[1]);
+    }
+}
 __global__ void scalar_ratio_kernel(float* out, const float* num, const float* den) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = num[0] / fmaxf(den[0], 1.f);
 }
 
 }  // namespace
 
+const uint32_t* g_icka_nonce = nullptr;
+
 extern "C" int icka_abi_version(void) { return 1; }
+extern "C" int icka_set_dropout_nonce(const uint32_t* device_words) {
+    g_icka_nonce = device_words;
+    return 0;
+}
+extern "C" int icka_bump_dropout_nonce(uint32_t* device_words, void* stream) {
+    if (!device_words) return ICKA_E_ARG;
+    hipLaunchKernelGGL(bump_nonce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, device_words);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" const char* icka_build_arch(void) { return "gfx950"; }
 
 extern "C" int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {

@@ -28,6 +28,8 @@ struct GemmArgs {
     int epi, c_f32;
     int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
     int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
+    unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
+    int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
 };
 
 // k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
@@ -130,11 +132,11 @@ __device__ __forceinline__ void store4_bf16(bf16_t* base, int64_t ld, int m, int
 __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4 acc) {
     const int nvalid = (g.N - n) < 4 ? (g.N - n) : 4;
     float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
-    if (g.bias) {
+    if (g.bias && blockIdx.y == 0) {
         for (int r = 0; r < 4; ++r)
             if (r < nvalid) v[r] += g.bias[n + r];
     }
-    if (g.bias2) {
+    if (g.bias2 && blockIdx.y == 0) {
         for (int r = 0; r < 4; ++r)
             if (r < nvalid) v[r] += g.bias2[n + r];
     }
@@ -162,6 +164,12 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
             for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
             break;
         default: break;
+    }
+    if (g.ksplit > 1) {   // partial sum of one k-range (host guarantees f32 C, plain epilogue, C pre-scaled by beta)
+        float* p = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) atomicAdd(p + r, v[r]);
+        return;
     }
     if (g.c_f32) {
         float* p = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
@@ -220,10 +228,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk_all = (g.K + BK - 1) / BK;
+    // split-K (skinny outputs with a long reduction): blockIdx.y owns a contiguous range of k-tiles
+    const int per = (nk_all + g.ksplit - 1) / g.ksplit;
+    const int kt0 = blockIdx.y * per;
+    const int nk = (kt0 + per < nk_all ? kt0 + per : nk_all) - kt0;
+    if (nk <= 0) return;
     u32x4 ra[4], rb[4];
 
-    fetch_tiles<A_KM, B_KM, ALIGNED>(g, 0, m0, n0, tid, ra, rb);
+    fetch_tiles<A_KM, B_KM, ALIGNED>(g, kt0, m0, n0, tid, ra, rb);
     r2s<A_KM>(ra, smem, tid);
     r2s<B_KM>(rb, smem + TILE_BYTES, tid);
     __syncthreads();
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
     for (int kt = 0; kt < nk; ++kt) {
         const char* sA = smem + (kt & 1) * 2 * TILE_BYTES;
         const char* sB = sA + TILE_BYTES;
-        if (kt + 1 < nk) fetch_tiles<A_KM, B_KM, ALIGNED>(g, kt + 1, m0, n0, tid, ra, rb);  // in flight under the MFMAs
+        if (kt + 1 < nk) fetch_tiles<A_KM, B_KM, ALIGNED>(g, kt0 + kt + 1, m0, n0, tid, ra, rb);  // under the MFMAs
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -335,99 +348,10 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs gp) {
-    const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[(NBUF < 2 ? 2 : NBUF) * 2 * TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    const int nbn = g.N / BN;
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
-    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = g.K / BK;
-    const int k1t = g.K1 > 0 ? g.K1 / BK : -1;  // k-tile at which the reduction switches to (A2, B2)
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
-    dma_init<A_KM>(pa, g.A, g.lda, m0, wave, lane);
-    dma_init<B_KM>(pb, g.B, g.ldb, n0, wave, lane);
-    int64_t sa = A_KM ? (int64_t)BK * g.lda : BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
-
-#define ICKA_STAGE(KT, BUF)                                             \
-    do {                                                                \
-        if ((KT) == k1t) {                                              \
-            dma_init<A_KM>(pa, g.A2, g.lda2, m0, wave, lane);           \
-            dma_init<B_KM>(pb, g.B2, g.ldb2, n0, wave, lane);           \
-            sa = A_KM ? (int64_t)BK * g.lda2 : BK;                      \
-            sb = B_KM ? (int64_t)BK * g.ldb2 : BK;                      \
-        }                                                               \
-        dma_issue(pa, sa, lds0 + (BUF) + wave * 1024);                  \
-        dma_issue(pb, sb, lds0 + (BUF) + TILE_BYTES + wave * 1024);     \
-    } while (0)
-
-    // LDS ring of NBUF stages, prefetch distance NBUF-1 k-tiles.  Each wave waits for ITS pieces of tile kt with a
-    // counted vmcnt (the 8 DMA of tile kt+1 may stay in flight), then one raw s_barrier makes every wave's pieces
-    // visible and also proves all waves finished reading the buffer that the next DMA overwrites.
-    // prologue: fill NBUF-1 stages
-#pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t)
-        if (t < nk) ICKA_STAGE(t, t * 2 * TILE_BYTES);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tiles kt+1 .. min(kt+NBUF-2, nk-1) may stay in flight (8 DMA each per wave)
-        int ahead = nk - 1 - kt;
-        ahead = ahead > NBUF - 2 ? NBUF - 2 : ahead;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + NBUF - 1 < nk && ABL != 2) {
-            int nx = cur + NBUF - 1;
-            nx = nx >= NBUF ? nx - NBUF : nx;
-            ICKA_STAGE(kt + NBUF - 1, nx * 2 * TILE_BYTES);
-        }
-        const char* sA = smem + cur * 2 * TILE_BYTES;
-        const char* sB = sA + TILE_BYTES;
-        if (ABL != 1)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fa[t] = read_frag<A_KM>(sA, wr + 16 * t, ks, lane);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
-        }
-        cur = cur + 1 == NBUF ? 0 : cur + 1;
-    }
-#undef ICKA_STAGE
-    __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
-
-    // ---- epilogue through LDS (all waves are past the last barrier: the operand buffers are dead)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int row = wr + 16 * mi + (lane & 15);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
-            *reinterpret_cast<f32x4*>(smem + off_c(row, ch)) = acc[mi][ni] * g.alpha;
-        }
-    }
-    __syncthreads();
+// Second half of the LDS-staged epilogue: thread t finishes 8 consecutive columns (c8 = t & 15) of rows
+// (t >> 4) + RSTEP*i; 16 lanes cover a whole 128-column row -> 16-byte row-contiguous global accesses.
+template <int RSTEP>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
     const int c8 = tid & 15;           // 8-column group of the row
     const int n = n0 + 8 * c8;
     float bias[8];
@@ -444,8 +368,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs gp) {
         for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (tid >> 4) + 16 * i;
+    for (int i = 0; i < 128 / RSTEP; ++i) {
+        const int row = (tid >> 4) + RSTEP * i;
         const int m = m0 + row;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8 + 1));
@@ -503,11 +427,414 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs gp) {
     }
 }
 
+template <bool A_KM, bool B_KM, int NBUF, int ABL>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int nbn = g.N / BN;
+    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
+    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    const int k1t = g.K1 > 0 ? g.K1 / BK : -1;  // k-tile at which the reduction switches to (A2, B2)
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    dma_init<A_KM>(pa, g.A, g.lda, m0, wave, lane);
+    dma_init<B_KM>(pb, g.B, g.ldb, n0, wave, lane);
+    int64_t sa = A_KM ? (int64_t)BK * g.lda : BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+
+#define ICKA_STAGE(KT, BUF)                                             \
+    do {                                                                \
+        if ((KT) == k1t) {                                              \
+            dma_init<A_KM>(pa, g.A2, g.lda2, m0, wave, lane);           \
+            dma_init<B_KM>(pb, g.B2, g.ldb2, n0, wave, lane);           \
+            sa = A_KM ? (int64_t)BK * g.lda2 : BK;                      \
+            sb = B_KM ? (int64_t)BK * g.ldb2 : BK;                      \
+        }                                                               \
+        dma_issue(pa, sa, lds0 + (BUF) + wave * 1024);                  \
+        dma_issue(pb, sb, lds0 + (BUF) + TILE_BYTES + wave * 1024);     \
+    } while (0)
+
+    // LDS ring of NBUF stages, prefetch distance NBUF-1 k-tiles.  Each wave waits for ITS pieces of tile kt with a
+    // counted vmcnt (the 8 DMA of tile kt+1 may stay in flight), then one raw s_barrier makes every wave's pieces
+    // visible and also proves all waves finished reading the buffer that the next DMA overwrites.
+    if (NBUF < 4) {
+        // ---- v2 loop: ring of NBUF stages, fragments read right after the barrier -------------------------------
+#pragma unroll
+        for (int t = 0; t < NBUF - 1; ++t)
+            if (t < nk) ICKA_STAGE(t, t * 2 * TILE_BYTES);
+        int cur = 0;
+#ifdef ICKA_GEMM_STAMP
+        unsigned long long seg[5] = {0, 0, 0, 0, 0}, tA, tB;
+        const unsigned long long real0 = __builtin_amdgcn_s_memrealtime(), cyc0 = __builtin_amdgcn_s_memtime();
+#define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define STAMP(v)
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+#ifdef ICKA_GEMM_STAMP
+            STAMP(tA);
+#endif
+            // tiles kt+1 .. min(kt+NBUF-2, nk-1) may stay in flight (8 DMA each per wave)
+            int ahead = nk - 1 - kt;
+            ahead = ahead > NBUF - 2 ? NBUF - 2 : ahead;
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ICKA_GEMM_STAMP
+            STAMP(tB); seg[0] += tB - tA; tA = tB;
+#endif
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#ifdef ICKA_GEMM_STAMP
+            STAMP(tB); seg[1] += tB - tA; tA = tB;
+#endif
+            if (kt + NBUF - 1 < nk && ABL != 2) {
+                int nx = cur + NBUF - 1;
+                nx = nx >= NBUF ? nx - NBUF : nx;
+                ICKA_STAGE(kt + NBUF - 1, nx * 2 * TILE_BYTES);
+            }
+#ifdef ICKA_GEMM_STAMP
+            STAMP(tB); seg[2] += tB - tA; tA = tB;
+#endif
+            const char* sA = smem + cur * 2 * TILE_BYTES;
+            const char* sB = sA + TILE_BYTES;
+            if (ABL != 1)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t] = read_frag<A_KM>(sA, wr + 16 * t, ks, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+            }
+            cur = cur + 1 == NBUF ? 0 : cur + 1;
+#ifdef ICKA_GEMM_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(tB); seg[3] += tB - tA;
+#endif
+        }
+#ifdef ICKA_GEMM_STAMP
+        if (g.stamp && (tid & 63) == 0 && wave == 0) {
+            unsigned long long* o = g.stamp + (size_t)bid * 8;
+            o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3];
+            o[4] = __builtin_amdgcn_s_memtime() - cyc0;
+            o[5] = __builtin_amdgcn_s_memrealtime() - real0;
+            o[6] = nk;
+        }
+#endif
+    } else {
+        // ---- v3 loop (ring of 4, one block per CU = one wave per SIMD): software-pipelined FRAGMENTS.  The barrier
+        // sits between the two 16-MFMA halves of a k-tile: the second half's fragments (ks=1 of tile kt) are read
+        // under the first half's MFMAs, and the NEXT tile's first fragments (ks=0 of tile kt+1, made visible by
+        // this iteration's barrier) plus the DMA issue of tile kt+3 go under the second half's MFMAs, so neither
+        // the LDS latency nor the DMA issue sequence is exposed at one wave per SIMD.
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nk) ICKA_STAGE(t, t * 2 * TILE_BYTES);
+        if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tiles 0,1 landed; tile 2 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa0[t] = read_frag<A_KM>(smem, wr + 16 * t, 0, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb0[t] = read_frag<B_KM>(smem + TILE_BYTES, wc + 16 * t, 0, lane);
+        int cur = 0;
+#ifdef ICKA_GEMM_STAMP
+        unsigned long long cseg[2] = {0, 0}, cA, cB;
+        const unsigned long long ccyc0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+#ifdef ICKA_GEMM_STAMP
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cA)::"memory");
+#endif
+            const char* sA = smem + cur * 2 * TILE_BYTES;
+            const char* sB = sA + TILE_BYTES;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa1[t] = read_frag<A_KM>(sA, wr + 16 * t, 1, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb1[t] = read_frag<B_KM>(sB, wc + 16 * t, 1, lane);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb0[ni], fa0[mi], acc[mi][ni]);
+            const int nxt = cur == 3 ? 0 : cur + 1;
+            if (kt + 1 < nk) {
+                // tile kt+1 must have landed (own pieces); tile kt+2 (if any) may stay in flight
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 3 < nk) {
+                    const int st = cur == 0 ? 3 : cur - 1;   // buffer of tile kt-1 == (kt+3) % 4
+                    ICKA_STAGE(kt + 3, st * 2 * TILE_BYTES);
+                }
+                const char* nA = smem + nxt * 2 * TILE_BYTES;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa0[t] = read_frag<A_KM>(nA, wr + 16 * t, 0, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fb0[t] = read_frag<B_KM>(nA + TILE_BYTES, wc + 16 * t, 0, lane);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb1[ni], fa1[mi], acc[mi][ni]);
+            cur = nxt;
+        }
+    }
+#undef ICKA_STAGE
+    __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
+
+    // ---- epilogue through LDS (all waves are past the last barrier: the operand buffers are dead)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = wr + 16 * mi + (lane & 15);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
+            *reinterpret_cast<f32x4*>(smem + off_c(row, ch)) = acc[mi][ni] * g.alpha;
+        }
+    }
+    __syncthreads();
+    epilogue_rows<16>(g, smem, m0, n0, tid);
+}
+
+// =====================================================================================================================
+// Warp-specialised fast path (512 threads): waves 0-3 COMPUTE (LDS fragment reads + MFMA, 64x64 each), waves 4-7 LOAD
+// (they only issue the LDS-DMA of the ring and wait for it).  In-kernel stamps of the 4-wave kernel showed a wave
+// spending ~500 cycles per k-tile issuing its 8 global_load_lds (~60 cycles each) in series with its 512 cycles of
+// MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
+// One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
+// after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0>
+__device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    const int nbn = g.N / BN;
+    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
+    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
+    const int nk = g.K / BK;
+    const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * 64;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------- loader waves
+        const int lw = wave - 4;
+        const int k1t = g.K1 > 0 ? g.K1 / BK : -1;
+        const bf16_t* pa[4];
+        const bf16_t* pb[4];
+        dma_init<A_KM>(pa, g.A, g.lda, m0, lw, lane);
+        dma_init<B_KM>(pb, g.B, g.ldb, n0, lw, lane);
+        int64_t sa = A_KM ? (int64_t)BK * g.lda : BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+#define ICKA_WS_STAGE(KT, BUF)                                          \
+    do {                                                                \
+        if ((KT) == k1t) {                                              \
+            dma_init<A_KM>(pa, g.A2, g.lda2, m0, lw, lane);             \
+            dma_init<B_KM>(pb, g.B2, g.ldb2, n0, lw, lane);             \
+            sa = A_KM ? (int64_t)BK * g.lda2 : BK;                      \
+            sb = B_KM ? (int64_t)BK * g.ldb2 : BK;                      \
+        }                                                               \
+        if (ABL != 2) {                                                 \
+            dma_issue(pa, sa, lds0 + (BUF) + lw * 1024);                \
+            dma_issue(pb, sb, lds0 + (BUF) + TILE_BYTES + lw * 1024);   \
+        }                                                               \
+    } while (0)
+#pragma unroll
+        for (int t = 0; t < NBUF - 1; ++t)
+            if (t < nk) ICKA_WS_STAGE(t, t * 2 * TILE_BYTES);
+        int cur = 0;
+#ifdef ICKA_GEMM_STAMP
+        unsigned long long seg[4] = {0, 0, 0, 0}, tA, tB;
+        const unsigned long long real0 = __builtin_amdgcn_s_memrealtime(), cyc0 = __builtin_amdgcn_s_memtime();
+#define WSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+#ifdef ICKA_GEMM_STAMP
+            WSTAMP(tA);
+#endif
+            int ahead = nk - 1 - kt;
+            ahead = ahead > NBUF - 2 ? NBUF - 2 : ahead;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ICKA_GEMM_STAMP
+            WSTAMP(tB); seg[0] += tB - tA; tA = tB;
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef ICKA_GEMM_STAMP
+            WSTAMP(tB); seg[1] += tB - tA; tA = tB;
+#endif
+            if (kt + NBUF - 1 < nk) {
+                int nx = cur + NBUF - 1;
+                nx = nx >= NBUF ? nx - NBUF : nx;
+                ICKA_WS_STAGE(kt + NBUF - 1, nx * 2 * TILE_BYTES);
+            }
+            cur = cur + 1 == NBUF ? 0 : cur + 1;
+#ifdef ICKA_GEMM_STAMP
+            WSTAMP(tB); seg[2] += tB - tA;
+#endif
+        }
+#ifdef ICKA_GEMM_STAMP
+        if (g.stamp && lane == 0 && wave == 4) {
+            unsigned long long* o = g.stamp + (size_t)bid * 16;
+            o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2];
+            o[4] = __builtin_amdgcn_s_memtime() - cyc0;
+            o[5] = __builtin_amdgcn_s_memrealtime() - real0;
+            o[6] = nk;
+        }
+#endif
+#undef ICKA_WS_STAGE
+    } else {
+        // ------------------------------------------------------------------------------------------ compute waves
+        // Fragments are software-pipelined in registers with a prefetch distance of TWO 16-MFMA halves: while tile
+        // kt is multiplied out of one register set (P), both halves of tile kt+1 are read into the other (Q).  Measured
+        // (tools/probe/mfma_probe): LDS read latency at one wave per SIMD is hundreds of cycles once LDS-DMA writes
+        // share the LDS pipe, far more than one half (272 cycles) covers.  Barrier kt+1 (tile kt+1 published, tile
+        // kt fully in registers -> its buffer may be re-staged) is taken at the TOP of iteration kt.
+        bf16x8 pa0[4], pb0[4], pa1[4], pb1[4], qa0[4], qb0[4], qa1[4], qb1[4];
+#define ICKA_READ(FA, FB, BUFI, KS)                                                                  \
+    if (ABL != 1) do {                                                                               \
+        const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) FA[t] = read_frag<A_KM>(b_, wr + 16 * t, KS, lane);              \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) FB[t] = read_frag<B_KM>(b_ + TILE_BYTES, wc + 16 * t, KS, lane); \
+        __builtin_amdgcn_sched_barrier(0); /* keep the reads AHEAD of the next MFMA group (hipcc sinks them) */     \
+    } while (0)
+#define ICKA_MMA(FA, FB)                                                                             \
+    if (ABL != 1) do {                                                                               \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(FB[ni], FA[mi], acc[mi][ni]); \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+#define ICKA_SYNC()                                          \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+        asm volatile("" ::: "memory");                       \
+    } while (0)
+        __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
+        asm volatile("" ::: "memory");
+        ICKA_READ(pa0, pb0, 0, 0);
+        ICKA_READ(pa1, pb1, 0, 1);
+        int nxt = NBUF > 1 ? 1 : 0;     // ring slot of tile kt+1
+        int kt = 0;
+        for (; kt + 2 <= nk - 1; kt += 2) {
+            ICKA_SYNC();                         // barrier kt+1
+            ICKA_READ(qa0, qb0, nxt, 0);
+            ICKA_MMA(pa0, pb0);
+            ICKA_READ(qa1, qb1, nxt, 1);
+            ICKA_MMA(pa1, pb1);
+            nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+            ICKA_SYNC();                         // barrier kt+2
+            ICKA_READ(pa0, pb0, nxt, 0);
+            ICKA_MMA(qa0, qb0);
+            ICKA_READ(pa1, pb1, nxt, 1);
+            ICKA_MMA(qa1, qb1);
+            nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+        }
+        // tail: kt is the next tile to multiply (in P); nk - kt is 1 or 2
+        if (kt + 1 <= nk - 1) {
+            ICKA_SYNC();
+            ICKA_READ(qa0, qb0, nxt, 0);
+            ICKA_MMA(pa0, pb0);
+            ICKA_READ(qa1, qb1, nxt, 1);
+            ICKA_MMA(pa1, pb1);
+            ICKA_MMA(qa0, qb0);
+            ICKA_MMA(qa1, qb1);
+        } else {
+            ICKA_MMA(pa0, pb0);
+            ICKA_MMA(pa1, pb1);
+        }
+#undef ICKA_READ
+#undef ICKA_MMA
+#undef ICKA_SYNC
+    }
+    __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
+
+    // ---- epilogue through LDS: compute waves deposit their accumulators, all 8 waves finish rows
+    if (wave < 4) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = wr + 16 * mi + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
+                *reinterpret_cast<f32x4*>(smem + off_c(row, ch)) = acc[mi][ni] * g.alpha;
+            }
+        }
+    }
+    __syncthreads();
+    epilogue_rows<32>(g, smem, m0, n0, tid);
+}
+
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL>(g, smem, blockIdx.x, gridDim.x);
+}
+
+template <bool A_KM, bool B_KM, int NBUF, int ABL>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    gemm_dma_body<A_KM, B_KM, NBUF, ABL>(g, smem, blockIdx.x, gridDim.x);
+}
+
+// Several independent GEMMs of one layout in ONE launch (the four weight-gradient GEMMs of a layer: 36..144 tiles
+// each, 432 together): the chip is filled once instead of four partially filled launches.
+constexpr int MAX_GROUP = 4;
+struct GroupArgs {
+    GemmArgs p[MAX_GROUP];
+    int start[MAX_GROUP + 1];  // first block of each problem; start[n..] = total
+};
+template <bool A_KM, bool B_KM, int NBUF>
+__global__ __launch_bounds__(256) void gemm_dma_group_kernel(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    const int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) pi += bid >= ga.start[i] ? 1 : 0;
+    const GemmArgs g = ga.p[pi];
+    gemm_dma_body<A_KM, B_KM, NBUF, 0>(g, smem, bid - ga.start[pi], ga.start[pi + 1] - ga.start[pi]);
+}
+
+
 int g_abl = 0;
+unsigned long long* g_stamp = nullptr;
+int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
 int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
 
+__global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int64_t r = i / N;
+    float* p = C + r * ldc + (i - r * N);
+    *p = beta == 0.f ? 0.f : *p * beta;
+}
+
 template <bool A_KM, bool B_KM>
-int launch(const GemmArgs& g, bool aligned, hipStream_t st) {
+int launch(GemmArgs g, bool aligned, hipStream_t st) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (aligned) {
 #ifdef ICKA_GEMM_ABLATE
@@ -515,14 +842,45 @@ int launch(const GemmArgs& g, bool aligned, hipStream_t st) {
         else if (g_abl == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(256), 0, st, g);
         else
 #endif
-        // ring depth: many tiles per CU -> two co-resident blocks (64 KiB ring of 2) overlap one block's epilogue with
-        // the other's main loop; few tiles -> one block per CU with a deeper ring (measured, tools/gemm_bench.py)
-        const int nbuf = g_nbuf > 0 ? g_nbuf : (nb >= 448 ? 2 : 3);
-        if (nbuf == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 2, 0>), dim3(nb), dim3(256), 0, st, g);
-        else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 0>), dim3(nb), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 4, 0>), dim3(nb), dim3(256), 0, st, g);
+        {
+            // ring depth: many tiles per CU -> two co-resident blocks (64 KiB ring of 2) overlap one block's
+            // epilogue with the other's main loop; few tiles -> one block per CU with a deeper ring (measured,
+            // tools/gemm_bench.py)
+            if (g_ws) {
+#ifdef ICKA_GEMM_ABLATE
+                if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+#endif
+                if (g_nbuf == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
+                else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3>), dim3(nb), dim3(512), 0, st, g);
+                ICKA_CHECK_LAUNCH();
+                return 0;
+            }
+            const int nbuf = g_nbuf > 0 ? g_nbuf : (nb >= 448 ? 2 : 4);
+            if (nbuf == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 2, 0>), dim3(nb), dim3(256), 0, st, g);
+            else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 0>), dim3(nb), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 4, 0>), dim3(nb), dim3(256), 0, st, g);
+        }
+    } else {
+        // skinny output + long reduction (classifier weight gradient: 13 x 768 x 4096 tokens): split K over
+        // blockIdx.y and accumulate f32 partial tiles atomically (C is scaled by beta / zeroed first)
+        const int nk = (g.K + BK - 1) / BK;
+        int ks = 1;
+        if (g.c_f32 && g.epi == ICKA_EPI_NONE && nb < 64 && nk >= 16) {
+            ks = 256 / nb;
+            if (ks > nk / 4) ks = nk / 4;
+            if (ks < 1) ks = 1;
+        }
+        if (ks > 1) {
+            const int64_t n = (int64_t)g.M * g.N;
+            hipLaunchKernelGGL(scale_c_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<float*>(g.C), g.ldc, g.M, g.N, g.beta);
+            ICKA_CHECK_LAUNCH();
+            g.beta = 0.f;
+            g.ksplit = ks;
+        }
+        hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, false>), dim3(nb, ks), dim3(256), 0, st, g);
     }
-    else hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, false>), dim3(nb), dim3(256), 0, st, g);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
@@ -530,6 +888,16 @@ int launch(const GemmArgs& g, bool aligned, hipStream_t st) {
 inline bool vec_ok(const void* p, int64_t ld) { return (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
 
 }  // namespace
+
+extern "C" int icka_gemm_set_warp_specialized(int on) {
+    g_ws = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int icka_gemm_set_stamp_buffer(void* p) {
+    g_stamp = (unsigned long long*)p;
+    return 0;
+}
 
 extern "C" int icka_gemm_set_ablation(int mode) {
     g_abl = mode;
@@ -542,7 +910,7 @@ extern "C" int icka_gemm_set_ring(int nbuf) {
     return 0;
 }
 
-extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
+static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     if (!d || !d->A || !d->B || !d->C) return ICKA_E_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return ICKA_E_SHAPE;
     if (d->op < ICKA_GEMM_NT || d->op > ICKA_GEMM_TN) return ICKA_E_ARG;
@@ -550,7 +918,6 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     if ((d->epilogue == ICKA_EPI_GELU) && !d->C2) return ICKA_E_ARG;
     if ((d->epilogue == ICKA_EPI_DGELU || d->epilogue == ICKA_EPI_ADD || d->epilogue == ICKA_EPI_GATE) && !d->aux)
         return ICKA_E_ARG;
-    GemmArgs g;
     g.M = d->M; g.N = d->N; g.K = d->K; g.K1 = d->K1;
     g.A = (const bf16_t*)d->A; g.lda = d->lda; g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
     g.A2 = (const bf16_t*)d->A2; g.lda2 = d->lda2; g.B2 = (const bf16_t*)d->B2; g.ldb2 = d->ldb2;
@@ -558,18 +925,90 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux; g.bias = d->bias; g.bias2 = d->bias2;
     g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
     g.abl = g_abl;
+    g.stamp = g_stamp;
+    g.ksplit = 1;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
     auto al = [](const void* p, int64_t ld, int64_t mod) {
         return !p || (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ld % mod == 0);
     };
-    const bool aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
-                         al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
-                         al(d->bias, 4, 4) && al(d->bias2, 4, 4);
+    aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
+              al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
+              al(d->bias, 4, 4) && al(d->bias2, 4, 4);
+    return 0;
+}
+
+extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
+    GemmArgs g;
+    bool aligned = false;
+    const int rc = convert(d, g, aligned);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (d->op) {
         case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st);
         case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
         default: return launch<true, true>(g, aligned, st);
     }
+}
+
+template <bool A_KM, bool B_KM, int NBUF>
+__global__ __launch_bounds__(512) void gemm_ws_group_kernel(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    const int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) pi += bid >= ga.start[i] ? 1 : 0;
+    const GemmArgs g = ga.p[pi];
+    gemm_ws_body<A_KM, B_KM, NBUF>(g, smem, bid - ga.start[pi], ga.start[pi + 1] - ga.start[pi]);
+}
+
+template <bool A_KM, bool B_KM>
+static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
+    if (g_ws) {
+        hipLaunchKernelGGL((gemm_ws_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(512), 0, st, ga);
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
+    const int nbuf = g_nbuf > 0 ? g_nbuf : (total >= 448 ? 2 : 4);
+    if (nbuf == 2) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 2>), dim3(total), dim3(256), 0, st, ga);
+    else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 4>), dim3(total), dim3(256), 0, st, ga);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream) {
+    if (!descs || n <= 0) return ICKA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int i = 0;
+    while (i < n) {
+        // greedily pack up to MAX_GROUP consecutive fast-path problems of the same layout into one launch
+        GroupArgs ga;
+        int cnt = 0, total = 0;
+        const int op = descs[i].op;
+        while (i + cnt < n && cnt < MAX_GROUP && descs[i + cnt].op == op) {
+            bool aligned = false;
+            const int rc = convert(&descs[i + cnt], ga.p[cnt], aligned);
+            if (rc) return rc;
+            if (!aligned) break;
+            ga.start[cnt] = total;
+            total += (ga.p[cnt].M / BM) * (ga.p[cnt].N / BN);
+            ++cnt;
+        }
+        if (cnt >= 2) {
+            for (int k = cnt; k <= MAX_GROUP; ++k) ga.start[k] = total;
+            for (int k = cnt; k < MAX_GROUP; ++k) ga.p[k] = ga.p[0];
+            int rc;
+            if (op == ICKA_GEMM_NT) rc = launch_group<false, false>(ga, total, st);
+            else if (op == ICKA_GEMM_NN) rc = launch_group<false, true>(ga, total, st);
+            else rc = launch_group<true, true>(ga, total, st);
+            if (rc) return rc;
+            i += cnt;
+        } else {
+            const int rc = icka_gemm(&descs[i], stream);
+            if (rc) return rc;
+            ++i;
+        }
+    }
+    return 0;
 }

@@ -45,7 +45,9 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
+    LnFwdArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nchunk = a.H >> 3;
@@ -139,7 +141,9 @@ __device__ __forceinline__ void flush_columns(float (&acc)[NS][NCH][8], float* l
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
+    LnBwdArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
@@ -238,7 +242,9 @@ struct EmbFwdArgs {
 };
 
 template <int NCH>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a) {
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a_) {
+    EmbFwdArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nchunk = a.H >> 3;
@@ -304,7 +310,9 @@ struct EmbBwdArgs {
 };
 
 template <int NCH>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbBwdArgs a) {
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbBwdArgs a_) {
+    EmbBwdArgs a = a_;
+    a.drop = drop_resolve(a.drop);
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;

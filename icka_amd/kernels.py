@@ -64,12 +64,11 @@ def profile_gemm(enable: bool):
     return flops, ms, len(rec)
 
 
-def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
-         epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-         alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
-         B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epilogue(alpha * op(A,B) [+ op(A2,B2)] + bias) + beta*out.   op: GEMM_NT / GEMM_NN / GEMM_TN."""
-    lib = _lib.load()
+def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+              epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+              alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
+              B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None) -> GemmDesc:
+    """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched)."""
     _mat(A, "A"); _mat(B, "B")
     if op == GEMM_NT:
         M, K = A.shape; N, Kb = B.shape
@@ -111,15 +110,38 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: 
         raise ValueError("bias2 must be contiguous device f32 [N]")
     d.bias2 = _ptr(bias2)
     d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
+    return d
+
+
+def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> torch.Tensor:
+    """out[M,N] = epilogue(alpha * op(A,B) [+ op(A2,B2)] + bias) + beta*out.   op: GEMM_NT / GEMM_NN / GEMM_TN."""
+    lib = _lib.load()
+    d = gemm_desc(op, A, B, out, **kw)
     if _PROF is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
         e1.record()
-        _PROF.append((e0, e1, 2.0 * M * N * K))
+        _PROF.append((e0, e1, 2.0 * d.M * d.N * d.K))
         return out
     check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
     return out
+
+
+def gemm_grouped(descs) -> None:
+    """Launch several GEMMs (gemm_desc results) at once; same-layout fast-path problems share one launch."""
+    if not descs:
+        return
+    lib = _lib.load()
+    arr = (GemmDesc * len(descs))(*descs)
+    if _PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
+        e1.record()
+        _PROF.append((e0, e1, sum(2.0 * d.M * d.N * d.K for d in descs)))
+        return
+    check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
 
 
 # ------------------------------------------------------------------------------------------------- LayerNorm
@@ -307,3 +329,14 @@ def scalar_ratio(out, num, den):
     check(_lib.load().icka_scalar_ratio(out.data_ptr(), num.data_ptr(), den.data_ptr(), _stream()),
           "icka_scalar_ratio")
     return out
+
+
+def set_dropout_nonce(words: Optional[torch.Tensor]) -> None:
+    """Register (or clear) the 2 x int32 device tensor whose value every dropout kernel folds into its seed."""
+    if words is not None and (not words.is_cuda or words.numel() < 2 or words.element_size() != 4):
+        raise TypeError("nonce must be a device tensor of two 32-bit words")
+    check(_lib.load().icka_set_dropout_nonce(_ptr(words)), "icka_set_dropout_nonce")
+
+
+def bump_dropout_nonce(words: torch.Tensor) -> None:
+    check(_lib.load().icka_bump_dropout_nonce(words.data_ptr(), _stream()), "icka_bump_dropout_nonce")

@@ -43,6 +43,19 @@ class Dims(object):
         self.train = train
 
 
+# Weight gradients (dW = dY^T . X, reduction over the tokens) have no consumer inside backward: each block queues
+# them and launches the whole batch as ONE grouped GEMM at the end of its backward (4 GEMMs of 36..144 tiles each
+# fill the 256 CUs together instead of one after the other).
+def _wgrad(A: ParamArena, dy, x, gout, beta: float) -> None:
+    A.pending_wgrad.append((K.gemm_desc(K.GEMM_TN, dy, x, gout, beta=beta), dy, x, gout))
+
+
+def _flush_wgrad(A: ParamArena) -> None:
+    if A.pending_wgrad:
+        K.gemm_grouped([t[0] for t in A.pending_wgrad])
+        A.pending_wgrad = []
+
+
 # =============================================================================================== sub-blocks
 def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool):
     """BertAttention / BertCrossAttention: projections -> fused attention -> out-proj -> bias+dropout+residual+LN.
@@ -93,7 +106,7 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     K.ln_bwd(dy, xhat, rstd, so.LayerNorm.weight, dy2=dy2, dres=dres, dx=dao, dgamma=A.g(so.LayerNorm.weight),
              dbeta=A.g(so.LayerNorm.bias), dbias=A.g(so.dense.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h,
              accumulate=b_ln > 0)
-    K.gemm(K.GEMM_TN, dao, ctx, A.g(so.dense.weight), beta=A.grad_beta(so.dense.weight))
+    _wgrad(A, dao, ctx, A.g(so.dense.weight), A.grad_beta(so.dense.weight))
     dctx = _empty(x, M, H)
     K.gemm(K.GEMM_NN, dao, A.w(so.dense.weight), dctx)
     delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
@@ -105,7 +118,7 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
                    d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
         wg = (sa.query.weight, sa.key.weight, sa.value.weight)
         bg = (sa.query.bias, sa.key.bias, sa.value.bias)
-        K.gemm(K.GEMM_TN, dqkv, x, A.g_cat(wg), beta=A.grad_beta(wg))
+        _wgrad(A, dqkv, x, A.g_cat(wg), A.grad_beta(wg))
         K.colsum(dqkv, A.g_cat(bg), csw, accumulate=A.grad_beta(bg) > 0)
         dx = _empty(x, M, H)
         K.gemm(K.GEMM_NN, dqkv, A.w_cat(wg), dx, epilogue=K.EPI_ADD, aux=dres)
@@ -114,11 +127,11 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     dkv = _empty(x, kv_src.shape[0], 2 * H)
     K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
                d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
-    K.gemm(K.GEMM_TN, dq, x, A.g(sa.query.weight), beta=A.grad_beta(sa.query.weight))
+    _wgrad(A, dq, x, A.g(sa.query.weight), A.grad_beta(sa.query.weight))
     K.colsum(dq, A.g(sa.query.bias), csw, accumulate=A.grad_beta(sa.query.bias) > 0)
     wg = (sa.key.weight, sa.value.weight)
     bg = (sa.key.bias, sa.value.bias)
-    K.gemm(K.GEMM_TN, dkv, kv_src, A.g_cat(wg), beta=A.grad_beta(wg))
+    _wgrad(A, dkv, kv_src, A.g_cat(wg), A.grad_beta(wg))
     K.colsum(dkv, A.g_cat(bg), csw, accumulate=A.grad_beta(bg) > 0)
     dx = _empty(x, M, H)
     K.gemm(K.GEMM_NN, dq, A.w(sa.query.weight), dx, epilogue=K.EPI_ADD, aux=dres)
@@ -162,10 +175,10 @@ def _ffn_block_bwd(A: ParamArena, layer, x, d: Dims, saved, dy, dy2=None):
     K.ln_bwd(dy, xhat, rstd, out.LayerNorm.weight, dy2=dy2, dres=dres, dx=dfo, dgamma=A.g(out.LayerNorm.weight),
              dbeta=A.g(out.LayerNorm.bias), dbias=A.g(out.dense.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h,
              accumulate=b_ln > 0)
-    K.gemm(K.GEMM_TN, dfo, g, A.g(out.dense.weight), beta=A.grad_beta(out.dense.weight))
+    _wgrad(A, dfo, g, A.g(out.dense.weight), A.grad_beta(out.dense.weight))
     dz = _empty(x, M, I)
     K.gemm(K.GEMM_NN, dfo, A.w(out.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)
-    K.gemm(K.GEMM_TN, dz, x, A.g(inter.dense.weight), beta=A.grad_beta(inter.dense.weight))
+    _wgrad(A, dz, x, A.g(inter.dense.weight), A.grad_beta(inter.dense.weight))
     csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(I))
     K.colsum(dz, A.g(inter.dense.bias), csw, accumulate=A.grad_beta(inter.dense.bias) > 0)
     dx = _empty(x, M, H)
@@ -233,6 +246,7 @@ class BertLayerFn(torch.autograd.Function):
         dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
         dx, _ = _attn_block_bwd(A, layer.attention, x, None, add_mask, d, d.S, ctx.s_att, dx1, None, False)
         ctx.s_att = ctx.s_ffn = None
+        _flush_wgrad(A)
         A.flush_final()
         return None, dx, None, None, None, None, None
 
@@ -258,6 +272,7 @@ class CrossLayerFn(torch.autograd.Function):
         dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
         ds1, ds2 = _attn_block_bwd(A, layer.attention, s1, s2, add_mask, d, d.R, ctx.s_att, dx1, None, ctx.need_s2)
         ctx.s_att = ctx.s_ffn = None
+        _flush_wgrad(A)
         A.flush_final()
         return None, ds1, None, ds2, None, None, None, None
 

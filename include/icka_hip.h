@@ -62,11 +62,19 @@ typedef struct icka_gemm_desc {
     int32_t epilogue;      /* ICKA_EPI_* */
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
+/* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that
+ * several partially-filling grids (the weight-gradient GEMMs of a layer) fill the chip together. */
+int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream);
 /* Tuning knob of the aligned fast path: depth of the LDS-DMA ring (2: 64 KiB LDS, two blocks per CU; 3 / 4: 96 /
  * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  Default 4. */
 int icka_gemm_set_ring(int nbuf);
 /* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
 int icka_gemm_set_ablation(int mode);
+/* 1 (default): 512-thread warp-specialised fast path (4 loader + 4 compute waves); 0: 256-thread single-role path. */
+int icka_gemm_set_warp_specialized(int on);
+/* Diagnostic builds (-DICKA_GEMM_STAMP) only: device buffer of [blocks][8] u64 receiving per-segment cycle sums of
+ * the fast-path k-loop (vmcnt wait, barrier, DMA issue, LDS reads+MFMA, total cycles, 100 MHz real-time ticks, nk). */
+int icka_gemm_set_stamp_buffer(void* p);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused  y = LayerNorm(dropout(x + bias) + residual)   (BertSelfOutput.forward :561-565, BertOutput.forward
@@ -166,6 +174,12 @@ int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const 
 int icka_scale_by_ratio(const void* x, void* y, const float* num, const float* den, int64_t n, void* stream);
 /* out[0] = num[0] / max(den[0], 1)   (mean loss from the two accumulators of icka_token_ce). */
 int icka_scalar_ratio(float* out, const float* num, const float* den, void* stream);
+/* Dropout nonce for hipGraph replay.  Every dropout-bearing kernel XORs two DEVICE words into its (by-value) seed at
+ * entry when a nonce is registered.  A captured graph re-launches the same seed values, so the graph also captures
+ * icka_bump_dropout_nonce at the start of a step: each replay then draws fresh masks, and the forward and backward
+ * kernels of one replay still see the same nonce.  NULL (default) disables it.  Process-global. */
+int icka_set_dropout_nonce(const uint32_t* device_words);
+int icka_bump_dropout_nonce(uint32_t* device_words, void* stream);
 /* Debug/test helper: materialise the dropout keep-multiplier (0 or 1/(1-p)) for element indices [0,n) as f32. */
 int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t seed, void* stream);
 

@@ -73,7 +73,7 @@ def test_gemm_nn(M, N, K):
 
 
 @pytest.mark.parametrize("Kt,M,N", [(64, 128, 128), (4096, 768, 768), (4096, 2304, 768), (300, 13, 1536), (1000, 72, 200),
-                                    (4096, 768, 3072)])
+                                    (4096, 768, 3072), (4096, 13, 768), (2048, 13, 1536)])
 def test_gemm_tn(Kt, M, N):
     k = _k()
     A, B = rnd(Kt, M if M % 8 == 0 else 16, seed=1), rnd(Kt, N, seed=2)
@@ -125,6 +125,24 @@ def test_gemm_epilogues_and_dual_k():
     o.fill_(1.0)
     k.gemm(k.GEMM_NT, A, B, o, alpha=0.5, beta=1.0)
     assert rel_err(o, 0.5 * (A.float() @ B.float().t()) + 1.0) < 1e-2
+
+
+def test_gemm_grouped_matches_individual_launches():
+    """The four weight-gradient GEMMs of a layer in one launch (+ a ragged one that falls back)."""
+    k = _k()
+    T, H, I = 1024, 256, 512
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H), (13, H)]
+    descs, outs, refs, keep = [], [], [], []
+    for i, (m, n) in enumerate(shapes):
+        A = rnd(T, m if m % 8 == 0 else 16, seed=10 + i)[:, :m]
+        B = rnd(T, n, seed=20 + i)
+        out = torch.full((m, n), 0.5, dtype=F32, device="cuda")
+        descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=1.0))
+        keep.append((A, B)); outs.append(out)
+        refs.append(A.float().t() @ B.float() + 0.5)
+    k.gemm_grouped(descs)
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < 1e-4
 
 
 def test_gemm_bad_args():

@@ -36,10 +36,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ring", type=int, default=3)
     ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--ws", type=int, default=1)
     args = ap.parse_args()
     from icka_amd import _lib
     assert _lib.load().icka_gemm_set_ring(args.ring) == 0
-    print("ring depth", args.ring, "ablation", args.ablate)
+    _lib.load().icka_gemm_set_warp_specialized(args.ws)
+    print("ring depth", args.ring, "ablation", args.ablate, "warp-specialised", args.ws)
     torch.manual_seed(0)
     cases = []
     for name, op, m, n, k, epi, odt in SHAPES:
