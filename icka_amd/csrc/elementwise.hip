@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void regions_t_kernel(const float* __restrict_
     }
 }
 
-constexpr int CS_GROUPS = 64;
+constexpr int CS_GROUPS = 256;
 // partial[group][N] = sum over the group's rows; block = 64 chunk-lanes x 4 row-lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ partial,
                                                      int M, int N, int rows_per_group, int vec) {
@@ -318,7 +318,7 @@ extern "C" int icka_colsum(const void* x, int64_t ldx, float* out, float* partia
     if (!x || !out || !partials) return ICKA_E_ARG;
     if (M <= 0 || N <= 0) return ICKA_E_SHAPE;
     const int vec = (ldx % 8 == 0) && al16(x);
-    int groups = (M + 63) / 64; groups = groups > CS_GROUPS ? CS_GROUPS : groups;
+    int groups = (M + 15) / 16; groups = groups > CS_GROUPS ? CS_GROUPS : groups;
     const int rpg = (M + groups - 1) / groups;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, groups), dim3(256), 0, st, (const bf16_t*)x, ldx, partials, M,

@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int MAX_CH = 4;           // chunks of 8 per lane -> H <= 2048
-constexpr int BWD_BLOCKS = 256;     // partial slabs per backward launch
+constexpr int BWD_BLOCKS = 1024;    // partial slabs per backward launch (one row per wave at M = 4096: 16 waves/CU)
 constexpr int SLOTS = 4;            // column-sum slots per slab
 
 struct LnFwdArgs {
@@ -140,47 +140,40 @@ __device__ __forceinline__ void flush_columns(float (&acc)[NS][NCH][8], float* l
     for (int i = threadIdx.x; i < NS * H; i += 256) slab[i] = lds[i];
 }
 
+// Row part of the backward: dres / dx only (pure streaming, one row per wave).  The column reductions (dgamma, dbeta,
+// dbias) are a separate pass (ln_cols_kernel): fusing them here forced either few waves (latency-bound rows) or a
+// per-block flush of 3*H partial sums that cost more than the rows themselves (measured 28 -> 56 us at 1024 blocks).
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
     LnBwdArgs a = a_;
     a.drop = drop_resolve(a.drop);
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nchunk = a.H >> 3;
     const float inv_h = 1.f / (float)a.H;
-    float acc[3][NCH][8];  // dgamma, dbeta, dbias
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[s][i][e] = 0.f;
-
     for (int row = wid; row < a.M; row += nw) {
-        float dy[NCH][8], xh[NCH][8], gd[NCH][8];
+        float xh[NCH][8], gd[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                load8(a.dy + (int64_t)row * a.lddy + c * 8, dy[i]);
+                float dy[8];
+                load8(a.dy + (int64_t)row * a.lddy + c * 8, dy);
                 if (a.dy2) {
                     float t[8];
                     load8(a.dy2 + (int64_t)row * a.lddy2 + c * 8, t);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dy[i][e] += t[e];
+                    for (int e = 0; e < 8; ++e) dy[e] += t[e];
                 }
                 load8(a.xhat + (int64_t)row * a.H + c * 8, xh[i]);
                 float g[8];
                 load8f(a.gamma + c * 8, g);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    gd[i][e] = g[e] * dy[i][e];
+                    gd[i][e] = g[e] * dy[e];
                     s1 += gd[i][e];
                     s2 += gd[i][e] * xh[i][e];
-                    acc[0][i][e] += dy[i][e] * xh[i][e];
-                    acc[1][i][e] += dy[i][e];
                 }
             }
         }
@@ -200,12 +193,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
                     for (int e = 0; e < 8; ++e) ds[e] *= drop_mul(a.drop, base + e);
                 }
                 if (a.dx) store8(a.dx + (int64_t)row * a.lddx + c * 8, ds);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[2][i][e] += ds[e];
             }
         }
     }
-    flush_columns<NCH, 3>(acc, lds_f, a.partials, a.H);
+}
+
+// Column part: slab[g][0] = sum_rows dy*xhat, slab[g][1] = sum_rows dy, slab[g][2] = sum_rows dx (if dx), over the
+// rows of group g.  Block = 32 chunk-lanes (256 columns) x 8 row-lanes; 16-byte loads, consecutive lanes on
+// consecutive chunks.
+constexpr int COL_GROUPS = 128;
+__global__ __launch_bounds__(256) void ln_cols_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
+                                                      const bf16_t* __restrict__ dy2, int64_t lddy2,
+                                                      const bf16_t* __restrict__ xhat, const bf16_t* __restrict__ dx,
+                                                      int64_t lddx, float* __restrict__ partials, int M, int H,
+                                                      int rows_per_group) {
+    __shared__ float red[3][8][32][8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + cx) * 8;
+    const int r0 = blockIdx.y * rows_per_group;
+    int r1 = r0 + rows_per_group; r1 = r1 > M ? M : r1;
+    float ag[8], ab[8], ax[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; ax[e] = 0.f; }
+    if (col < H) {
+        for (int r = r0 + ry; r < r1; r += 8) {
+            float d[8], x[8];
+            load8(dy + (int64_t)r * lddy + col, d);
+            if (dy2) {
+                float t[8];
+                load8(dy2 + (int64_t)r * lddy2 + col, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] += t[e];
+            }
+            load8(xhat + (int64_t)r * H + col, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ag[e] += d[e] * x[e]; ab[e] += d[e]; }
+            if (dx) {
+                load8(dx + (int64_t)r * lddx + col, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ax[e] += x[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][ry][cx][e] = ag[e]; red[1][ry][cx][e] = ab[e]; red[2][ry][cx][e] = ax[e]; }
+    __syncthreads();
+    // 3 slots x 256 columns = 768 sums per block, 3 per thread
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) {
+        const int slot = i >> 8, cc = i & 255, c = blockIdx.x * 256 + cc;
+        if (c < H) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[slot][k][cc >> 3][cc & 7];
+            partials[((int64_t)blockIdx.y * SLOTS + slot) * H + c] = t;
+        }
+    }
 }
 
 // out[slot][c] (+)= sum over slabs.  Block = 64 columns x 16 slab-lanes: the slab loop is split 16 ways and combined
@@ -356,6 +398,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbBwdArgs a_) {
         }
         const float c1 = wave_sum(s1) * inv_h, c2 = wave_sum(s2) * inv_h;
         const float rstd = a.rstd[row];
+        // The row of table gradients goes through LDS so that the global f32 atomics are issued lane-strided: one
+        // wave-instruction adds 64 CONSECUTIVE floats (256 contiguous bytes), the full-rate shape of
+        // global_atomic_add_f32 (MI355X_MICROARCH "Global float atomics"); 8-per-lane chunks would scatter 32-B pieces.
+        float* rowbuf = lds_f + 4 * a.H + (threadIdx.x >> 6) * a.H;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -363,18 +409,22 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbBwdArgs a_) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float ds = rstd * (gd[i][e] - c1 - xh[i][e] * c2);
-                    // word rows: random rows, 256-B contiguous per wave-instruction -> full-rate f32 atomics
-                    if (id != a.padding_idx) atomicAdd(a.dword + id * a.H + c * 8 + e, ds);
-                    atomicAdd(a.dpos + (int64_t)sp * a.H + c * 8 + e, ds);
+                    rowbuf[c * 8 + e] = ds;
                     if (a.n_type <= 2) {
                         acc[2][i][e] += t == 0 ? ds : 0.f;
                         acc[3][i][e] += t == 1 ? ds : 0.f;
-                    } else {
-                        atomicAdd(a.dtype + t * a.H + c * 8 + e, ds);
                     }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < a.H; j += 64) {
+            const float ds = rowbuf[j];
+            if (id != a.padding_idx) atomicAdd(a.dword + id * a.H + j, ds);
+            atomicAdd(a.dpos + (int64_t)sp * a.H + j, ds);
+            if (a.n_type > 2) atomicAdd(a.dtype + t * a.H + j, ds);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     flush_columns<NCH, 4>(acc, lds_f, a.partials, a.H);
 }
@@ -419,6 +469,7 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
                            float* dgamma, float* dbeta, float* dbias, float* partials, int32_t M, int32_t H,
                            float p_drop, uint64_t seed, int32_t accumulate, void* stream) {
     if (!dy || !xhat || !rstd || !gamma || !partials) return ICKA_E_ARG;
+    if (dbias && !dx) return ICKA_E_ARG;   // dbias is the column sum of dx
     if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
     if (lddy % 8 || (dy2 && lddy2 % 8) || (dres && lddres % 8) || (dx && lddx % 8)) return ICKA_E_ALIGN;
     if (!al16(dy) || (dy2 && !al16(dy2)) || !al16(xhat) || (dres && !al16(dres)) || (dx && !al16(dx)) || !al16(gamma))
@@ -426,12 +477,19 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
     LnBwdArgs a{(const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2, (const bf16_t*)xhat, rstd, gamma,
                 (bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partials, M, H, make_drop(p_drop, seed)};
     hipStream_t st = (hipStream_t)stream;
-    const int grid = bwd_grid(M);
-    DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, grid, 3 * H * sizeof(float), st, a);
+    DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, row_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, grid, H, dgamma,
-                       dbeta, dbias, (float*)nullptr, accumulate);
-    ICKA_CHECK_LAUNCH();
+    if (dgamma || dbeta || dbias) {
+        int groups = (M + 31) / 32; groups = groups > COL_GROUPS ? COL_GROUPS : groups;
+        const int rpg = (M + groups - 1) / groups;
+        hipLaunchKernelGGL(ln_cols_kernel, dim3((H + 255) / 256, groups), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)dy2, lddy2, (const bf16_t*)xhat, dbias ? (const bf16_t*)dx : nullptr, lddx,
+                           partials, M, H, rpg);
+        ICKA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, groups, H, dgamma,
+                           dbeta, dbias, (float*)nullptr, accumulate);
+        ICKA_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -466,7 +524,7 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
                  B * S, S, H, vocab, n_type, padding_idx, make_drop(p_drop, seed)};
     hipStream_t st = (hipStream_t)stream;
     const int grid = bwd_grid(B * S);
-    DISPATCH_NCH(pick_nch(H), embed_bwd_kernel, grid, 4 * H * sizeof(float), st, a);
+    DISPATCH_NCH(pick_nch(H), embed_bwd_kernel, grid, 8 * H * sizeof(float), st, a);
     ICKA_CHECK_LAUNCH();
     float* t0 = n_type <= 2 ? dtype : nullptr;
     float* t1 = n_type == 2 ? dtype + H : nullptr;

@@ -206,6 +206,7 @@ class EmbeddingsFn(torch.autograd.Function):
         ctx.mod, ctx.A, ctx.d, ctx.seed = mod, A, d, seed
         ctx.save_for_backward(ids, tt, xhat, rstd)
         ctx.mark_non_differentiable(yf)
+        ctx.set_materialize_grads(False)   # no 12.6 MB zero-fill for the twin's (unused) gradient
         return y, yf
 
     @staticmethod
@@ -237,6 +238,7 @@ class BertLayerFn(torch.autograd.Function):
         ctx.layer, ctx.A, ctx.d, ctx.s_att, ctx.s_ffn = layer, A, d, s_att, s_ffn
         ctx.save_for_backward(x, x1, add_mask)
         ctx.mark_non_differentiable(x2f)
+        ctx.set_materialize_grads(False)
         return x2, x2f
 
     @staticmethod
@@ -263,6 +265,7 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.need_s2 = s2.requires_grad
         ctx.save_for_backward(s1, s2, x1, add_mask)
         ctx.mark_non_differentiable(x2f)
+        ctx.set_materialize_grads(False)
         return x2, x2f
 
     @staticmethod

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.icka_abi_version() == 1
     assert lib.icka_build_arch() == b"gfx950"
-    assert lib.icka_ln_bwd_workspace_floats(768) == 256 * 4 * 768
+    assert lib.icka_ln_bwd_workspace_floats(768) == 1024 * 4 * 768
 
 
 def test_gemm_desc_layout_matches_c_struct():
