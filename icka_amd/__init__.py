@@ -7,12 +7,14 @@ from .config import BertConfig
 from .modeling import (BertAttention, BertCoAttention, BertCrossAttention, BertCrossAttentionLayer,
                        BertCrossEncoder, BertEmbeddings, BertEncoder, BertIntermediate, BertLayer, BertLayerNorm,
                        BertModel, BertOutput, BertPooler, BertPreTrainedModel, BertSelfAttention, BertSelfEncoder,
-                       BertSelfOutput, MTCCMBertForMMTokenClassificationCRF, token_ce_loss)
+                       BertSelfOutput, MTCCMBertForMMTokenClassificationCRF, cls_layer_both, scalar_gate_fusion,
+                       token_ce_loss)
 from .arena import ParamArena
 from .dp import GradReducer
 
 __all__ = ["BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
            "BertSelfEncoder", "BertCrossEncoder", "BertCrossAttentionLayer", "BertAttention", "BertCrossAttention",
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
-           "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "token_ce_loss", "ParamArena",
+           "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",
+           "token_ce_loss", "ParamArena",
            "GradReducer"]

@@ -67,6 +67,12 @@ PROTOTYPES = {
     "icka_colsum": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_colsum_workspace_floats": (c_i64, [c_i32]),
     "icka_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "icka_sample_gate_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "icka_sample_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                     c_i32, c_i32, c_i32, c_vp]),
+    "icka_crs_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_crs_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                             c_vp]),
     "icka_add_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "icka_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "icka_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

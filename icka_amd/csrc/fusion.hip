@@ -1,0 +1,271 @@
+// Per-sample gates of the two MNER heads (gfx950), all HBM-bound element-wise / reduction kernels:
+//   * Cross_Modal form (Cross_Modal_Interaction_Module.py:1029-1036): g_b = sigmoid(logit_b);
+//         out[b,s,:] = g_b * tok[b,s,:] + (1 - g_b) * cross[b,s,:]
+//   * gate_cl form (my_bert/gate_cl_modeling.py:1364-1373): crs[b,:] = Linear_{2HS->2}(cat(seq,cross)[b].view(-1));
+//         p_b = softmax(crs[b])[-1];  cross'[b] = p_b * cross[b]
+// Token-major bf16 matrices [B*S, H] with row strides; 16-byte chunks per lane; per-sample sums by block reduction +
+// one f32 atomic per block (the accumulators are zeroed by the caller).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    __syncthreads();
+    return t;
+}
+inline bool ok16(const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; }
+
+constexpr int SPLIT = 8;  // blocks per sample
+
+// mode 0: g = sigmoid(gate[b]) ; out = g*a + (1-g)*c         (blend; c may be NULL -> out = g*a)
+// mode 1: g = softmax(gate[b, 0..1])[1] ; out = g*a
+__device__ __forceinline__ float sample_gate(const float* gate, int b, int mode) {
+    if (mode == 0) return 1.f / (1.f + __expf(-gate[b]));
+    const float x0 = gate[2 * b], x1 = gate[2 * b + 1];
+    return 1.f / (1.f + __expf(x0 - x1));
+}
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const bf16_t* __restrict__ a, int64_t lda,
+                                                       const bf16_t* __restrict__ c, int64_t ldc,
+                                                       const float* __restrict__ gate, int mode,
+                                                       bf16_t* __restrict__ out, int64_t ldo, int S, int H) {
+    const int b = blockIdx.y;
+    const float g = sample_gate(gate, b, mode);
+    const int cpr = H >> 3, total = S * cpr;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int s = i / cpr, ch = (i - s * cpr) * 8;
+        const int64_t row = (int64_t)b * S + s;
+        float x[8], y[8];
+        ld8(a + row * lda + ch, x);
+        if (c) {
+            ld8(c + row * ldc + ch, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = g * x[e] + (1.f - g) * y[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= g;
+        }
+        st8(out + row * ldo + ch, x);
+    }
+}
+
+// backward of the above: da = g*dout ; dc = (1-g)*dout (mode 0 with c) ;
+// dgate: mode 0: dgate[b] += g(1-g) * sum dout*(a-c) ; mode 1: dgate[b,1] += t, dgate[b,0] -= t, t = g(1-g)*sum dout*a
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict__ dout, int64_t lddo,
+                                                       const bf16_t* __restrict__ a, int64_t lda,
+                                                       const bf16_t* __restrict__ c, int64_t ldc,
+                                                       const float* __restrict__ gate, int mode,
+                                                       bf16_t* __restrict__ da, int64_t ldda,
+                                                       bf16_t* __restrict__ dc, int64_t lddc,
+                                                       float* __restrict__ dgate, int S, int H) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const float g = sample_gate(gate, b, mode);
+    const int cpr = H >> 3, total = S * cpr;
+    float acc = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int s = i / cpr, ch = (i - s * cpr) * 8;
+        const int64_t row = (int64_t)b * S + s;
+        float d[8], x[8], y[8], o[8];
+        ld8(dout + row * lddo + ch, d);
+        ld8(a + row * lda + ch, x);
+        if (c) {
+            ld8(c + row * ldc + ch, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += d[e] * (x[e] - y[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += d[e] * x[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = g * d[e];
+        st8(da + row * ldda + ch, o);
+        if (c && dc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (1.f - g) * d[e];
+            st8(dc + row * lddc + ch, o);
+        }
+    }
+    const float t = block_sum(acc, red) * g * (1.f - g);
+    if (threadIdx.x == 0) {
+        if (mode == 0) atomicAdd(dgate + b, t);
+        else { atomicAdd(dgate + 2 * b + 1, t); atomicAdd(dgate + 2 * b, -t); }
+    }
+}
+
+// crs[b,j] += sum_{s,k} seq[b,s,k]*W[j, s*2H + k] + cross[b,s,k]*W[j, s*2H + H + k]   (+ bias_j once)
+__global__ __launch_bounds__(256) void crs_fwd_kernel(const bf16_t* __restrict__ seq, int64_t lds,
+                                                      const bf16_t* __restrict__ cross, int64_t ldc,
+                                                      const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                      float* __restrict__ crs, int S, int H) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int cpr = H >> 3, total = S * cpr;
+    const int64_t wrow = (int64_t)S * 2 * H;
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int s = i / cpr, ch = (i - s * cpr) * 8;
+        const int64_t row = (int64_t)b * S + s;
+        float x[8], y[8], w[8];
+        ld8(seq + row * lds + ch, x);
+        ld8(cross + row * ldc + ch, y);
+        const int64_t wo = (int64_t)s * 2 * H + ch;
+        ld8(W + wo, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a0 += x[e] * w[e];
+        ld8(W + wo + H, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a0 += y[e] * w[e];
+        ld8(W + wrow + wo, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a1 += x[e] * w[e];
+        ld8(W + wrow + wo + H, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a1 += y[e] * w[e];
+    }
+    a0 = block_sum(a0, red);
+    a1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && bias) { a0 += bias[0]; a1 += bias[1]; }
+        atomicAdd(crs + 2 * b, a0);
+        atomicAdd(crs + 2 * b + 1, a1);
+    }
+}
+
+// input gradients of the crs Linear: dseq[b,s,k] = sum_j dcrs[b,j] W[j, s*2H+k] ; dcross likewise with +H
+__global__ __launch_bounds__(256) void crs_dgrad_kernel(const float* __restrict__ dcrs, const bf16_t* __restrict__ W,
+                                                        bf16_t* __restrict__ dseq, bf16_t* __restrict__ dcross, int B,
+                                                        int S, int H) {
+    const int cpr = H >> 3;
+    const int64_t total = (int64_t)B * S * cpr, wrow = (int64_t)S * 2 * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / cpr;
+        const int ch = (int)(i - row * cpr) * 8;
+        const int b = (int)(row / S), s = (int)(row - (int64_t)b * S);
+        const float d0 = dcrs[2 * b], d1 = dcrs[2 * b + 1];
+        const int64_t wo = (int64_t)s * 2 * H + ch;
+        float w0[8], w1[8], o[8];
+        ld8(W + wo, w0); ld8(W + wrow + wo, w1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = d0 * w0[e] + d1 * w1[e];
+        st8(dseq + row * H + ch, o);
+        ld8(W + wo + H, w0); ld8(W + wrow + wo + H, w1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = d0 * w0[e] + d1 * w1[e];
+        st8(dcross + row * H + ch, o);
+    }
+}
+
+// weight gradient: dW[j, s*2H + k] (+)= sum_b dcrs[b,j] seq[b,s,k] ; second half from cross.  One thread per 8 k.
+__global__ __launch_bounds__(256) void crs_wgrad_kernel(const float* __restrict__ dcrs, const bf16_t* __restrict__ seq,
+                                                        int64_t lds, const bf16_t* __restrict__ cross, int64_t ldc,
+                                                        float* __restrict__ dW, float* __restrict__ dbias, int B, int S,
+                                                        int H, int accumulate) {
+    const int cpr = H >> 3;
+    const int64_t total = (int64_t)S * cpr * 2, wrow = (int64_t)S * 2 * H;   // (s, half, chunk)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int s = (int)(i / (2 * cpr));
+        const int r = (int)(i - (int64_t)s * 2 * cpr);
+        const int half = r / cpr, ch = (r - half * cpr) * 8;
+        const bf16_t* src = half ? cross : seq;
+        const int64_t ld = half ? ldc : lds;
+        float g0[8], g1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g0[e] = 0.f; g1[e] = 0.f; }
+        for (int b = 0; b < B; ++b) {
+            float x[8];
+            ld8(src + ((int64_t)b * S + s) * ld + ch, x);
+            const float d0 = dcrs[2 * b], d1 = dcrs[2 * b + 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g0[e] += d0 * x[e]; g1[e] += d1 * x[e]; }
+        }
+        float* p0 = dW + (int64_t)s * 2 * H + half * H + ch;
+        float* p1 = p0 + wrow;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p0[e] = accumulate ? p0[e] + g0[e] : g0[e];
+            p1[e] = accumulate ? p1[e] + g1[e] : g1[e];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 && dbias) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += dcrs[2 * b + threadIdx.x];
+        dbias[threadIdx.x] = accumulate ? dbias[threadIdx.x] + t : t;
+    }
+}
+
+}  // namespace
+
+extern "C" int icka_sample_gate_fwd(const void* a, int64_t lda, const void* c, int64_t ldc, const float* gate,
+                                    int32_t mode, void* out, int64_t ldo, int32_t B, int32_t S, int32_t H,
+                                    void* stream) {
+    if (!a || !gate || !out || (mode != 0 && mode != 1)) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8) return ICKA_E_SHAPE;
+    if (!ok16(a, lda) || !ok16(out, ldo) || (c && !ok16(c, ldc))) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(SPLIT, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                       (const bf16_t*)c, ldc, gate, mode, (bf16_t*)out, ldo, S, H);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_sample_gate_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* c,
+                                    int64_t ldc, const float* gate, int32_t mode, void* da, int64_t ldda, void* dc,
+                                    int64_t lddc, float* dgate, int32_t B, int32_t S, int32_t H, void* stream) {
+    if (!dout || !a || !gate || !da || !dgate || (mode != 0 && mode != 1)) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8) return ICKA_E_SHAPE;
+    if (!ok16(dout, lddo) || !ok16(a, lda) || !ok16(da, ldda) || (c && !ok16(c, ldc)) || (dc && !ok16(dc, lddc)))
+        return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(SPLIT, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, lddo,
+                       (const bf16_t*)a, lda, (const bf16_t*)c, ldc, gate, mode, (bf16_t*)da, ldda, (bf16_t*)dc, lddc,
+                       dgate, S, H);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_crs_fwd(const void* seq, int64_t lds, const void* cross, int64_t ldc, const void* W,
+                            const float* bias, float* crs, int32_t B, int32_t S, int32_t H, void* stream) {
+    if (!seq || !cross || !W || !crs) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8) return ICKA_E_SHAPE;
+    if (!ok16(seq, lds) || !ok16(cross, ldc) || !ok16(W, 8)) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(crs_fwd_kernel, dim3(SPLIT, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)seq, lds,
+                       (const bf16_t*)cross, ldc, (const bf16_t*)W, bias, crs, S, H);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_crs_bwd(const float* dcrs, const void* seq, int64_t lds, const void* cross, int64_t ldc,
+                            const void* W, void* dseq, void* dcross, float* dW, float* dbias, int32_t B, int32_t S,
+                            int32_t H, int32_t accumulate, void* stream) {
+    if (!dcrs || !seq || !cross || !W || !dseq || !dcross || !dW) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8) return ICKA_E_SHAPE;
+    if (!ok16(seq, lds) || !ok16(cross, ldc) || !ok16(W, 8) || !ok16(dseq, 8) || !ok16(dcross, 8)) return ICKA_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n1 = (int64_t)B * S * (H / 8);
+    hipLaunchKernelGGL(crs_dgrad_kernel, dim3((unsigned)((n1 + 255) / 256 > 2048 ? 2048 : (n1 + 255) / 256)), dim3(256),
+                       0, st, dcrs, (const bf16_t*)W, (bf16_t*)dseq, (bf16_t*)dcross, B, S, H);
+    ICKA_CHECK_LAUNCH();
+    const int64_t n2 = (int64_t)S * (H / 8) * 2;
+    hipLaunchKernelGGL(crs_wgrad_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, dcrs,
+                       (const bf16_t*)seq, lds, (const bf16_t*)cross, ldc, dW, dbias, B, S, H, accumulate);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}

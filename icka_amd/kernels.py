@@ -340,3 +340,35 @@ def set_dropout_nonce(words: Optional[torch.Tensor]) -> None:
 
 def bump_dropout_nonce(words: torch.Tensor) -> None:
     check(_lib.load().icka_bump_dropout_nonce(words.data_ptr(), _stream()), "icka_bump_dropout_nonce")
+
+
+# ------------------------------------------------------------------------------------------------- per-sample gates
+def sample_gate_fwd(a, c, gate, mode, out, B, S):
+    _mat(a, "a"); _mat(out, "out")
+    H = a.shape[1]
+    check(_lib.load().icka_sample_gate_fwd(a.data_ptr(), a.stride(0), _ptr(c), _ld(c), gate.data_ptr(), mode,
+                                           out.data_ptr(), out.stride(0), B, S, H, _stream()), "icka_sample_gate_fwd")
+    return out
+
+
+def sample_gate_bwd(dout, a, c, gate, mode, da, dc, dgate, B, S):
+    _mat(dout, "dout"); _mat(a, "a"); _mat(da, "da")
+    H = a.shape[1]
+    check(_lib.load().icka_sample_gate_bwd(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), _ptr(c), _ld(c),
+                                           gate.data_ptr(), mode, da.data_ptr(), da.stride(0), _ptr(dc), _ld(dc),
+                                           dgate.data_ptr(), B, S, H, _stream()), "icka_sample_gate_bwd")
+
+
+def crs_fwd(seq, cross, W, bias, crs, B, S):
+    _mat(seq, "seq"); _mat(cross, "cross")
+    H = seq.shape[1]
+    check(_lib.load().icka_crs_fwd(seq.data_ptr(), seq.stride(0), cross.data_ptr(), cross.stride(0), W.data_ptr(),
+                                   _ptr(bias), crs.data_ptr(), B, S, H, _stream()), "icka_crs_fwd")
+    return crs
+
+
+def crs_bwd(dcrs, seq, cross, W, dseq, dcross, dW, dbias, B, S, accumulate):
+    H = seq.shape[1]
+    check(_lib.load().icka_crs_bwd(dcrs.data_ptr(), seq.data_ptr(), seq.stride(0), cross.data_ptr(), cross.stride(0),
+                                   W.data_ptr(), dseq.data_ptr(), dcross.data_ptr(), dW.data_ptr(), _ptr(dbias), B, S, H,
+                                   int(accumulate), _stream()), "icka_crs_bwd")

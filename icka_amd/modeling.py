@@ -347,6 +347,42 @@ class BertPooler(_IckaModule):
         return ops.LinearFn.apply(A.anchor, first, self.dense, A, False, K.EPI_TANH)
 
 
+class cls_layer_both(_IckaModule):
+    """proj(LayerNorm(lang_feat + img_feat)) (Cross_Modal_Interaction_Module.py:873-884; ``proj_norm`` and
+    ``LayerNorm`` are one nn.LayerNorm, eps 1e-5, exactly as the reference aliases them)."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.proj_norm = self.LayerNorm = nn.LayerNorm(input_dim)
+        self.proj = nn.Linear(input_dim, output_dim)
+
+    def forward(self, lang_feat, img_feat):
+        A = self._arena()
+        x = lang_feat if lang_feat.dtype == BF16 else _CastFn.apply(lang_feat, True)
+        r = img_feat if img_feat.dtype == BF16 else _CastFn.apply(img_feat, True)
+        feat = ops.AddLayerNormFn.apply(A.anchor, x, r, self.proj_norm, A, float(self.proj_norm.eps))
+        return ops.LinearFn.apply(A.anchor, feat, self.proj, A, False, K.EPI_NONE)
+
+
+def scalar_gate_fusion(owner: nn.Module, cross_output_layer: torch.Tensor, token_embedding: torch.Tensor):
+    """Lines 1029-1036 of the reference's current model: ``owner`` exposes ``cls_layer`` (cls_layer_both) and
+    ``aux_head`` (nn.Linear(H,1));  g = sigmoid(aux_head(cls_layer(cross[:,0], tok[:,0])));
+    returns g*token_embedding + (1-g)*cross_output_layer  ([B,S,H] bf16).  ``token_embedding`` comes from the
+    out-of-scope RoBERTa stage and is an input here."""
+    A = arena_of(owner)
+    A.begin_step(); A.sync()
+    B, S, H = cross_output_layer.shape
+    cross = _hidden2d(cross_output_layer, "cross_output_layer")
+    tok = _hidden2d(token_embedding, "token_embedding")
+    c0 = cross.view(B, S, H)[:, 0]          # strided [B,H] views (row stride S*H), read in place
+    t0 = tok.view(B, S, H)[:, 0]
+    feat = ops.AddLayerNormFn.apply(A.anchor, c0, t0, owner.cls_layer.proj_norm, A, float(owner.cls_layer.proj_norm.eps))
+    related = ops.LinearFn.apply(A.anchor, feat, owner.cls_layer.proj, A, False, K.EPI_NONE)
+    logit = ops.LinearFn.apply(A.anchor, related, owner.aux_head, A, True, K.EPI_NONE)        # f32 [B,1]
+    out = ops.SampleGateFn.apply(tok, cross, logit.view(B), 0, B, S)
+    return out.view(B, S, H)
+
+
 # ------------------------------------------------------------------------------------------------- models
 class BertPreTrainedModel(_IckaModule):
     """Weight init + checkpoint key handling of the reference (:141-299).  ``from_pretrained`` takes a directory
@@ -462,15 +498,23 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
     tokens ``[B,R,2048]`` (BASELINE synthetic layout); ``regions`` defaults to 49 as in the reference.
     """
 
-    def __init__(self, config, layer_num1=1, layer_num2=1, layer_num3=1, num_labels=2, regions=49):
+    def __init__(self, config, layer_num1=1, layer_num2=1, layer_num3=1, num_labels=2, regions=49, variant="cl",
+                 max_seq_length=128):
         super().__init__(config)
         check_config(config)
+        if variant not in ("cl", "gate_cl"):
+            raise ValueError("variant must be 'cl' (my_bert/cl_modeling.py) or 'gate_cl' (my_bert/gate_cl_modeling.py)")
         self.num_labels = num_labels
         self.regions = regions
+        self.variant = variant
         self.bert = BertModel(config)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.vismap2text = nn.Linear(2048, config.hidden_size)
         self.txt2img_attention = BertCrossEncoder(config, layer_num1)
+        if variant == "gate_cl":
+            # relevance score head: nn.Linear(hidden*2*128, 2) in the reference (gate_cl_modeling.py:1258); the
+            # hard-coded 128 is the max_seq_length parameter here
+            self.crs_classifier = nn.Linear(config.hidden_size * 2 * max_seq_length, 2)
         self.Gate_text = nn.Linear(config.hidden_size, config.hidden_size)
         self.Gate_image = nn.Linear(config.hidden_size, config.hidden_size)
         self.classifier = nn.Linear(config.hidden_size * 2, num_labels)
@@ -512,6 +556,13 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         d = _dims(cfg, B, S, R, self.training)
         for layer in self.txt2img_attention.layer:
             cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
+        if self.variant == "gate_cl":
+            # P = softmax(crs_classifier(cat(seq, cross).view(B,-1)))[:, -1];  cross = P * cross   (:1364-1373)
+            if self.crs_classifier.weight.shape[1] != 2 * H * S:
+                raise ValueError("gate_cl: sequence length %d does not match crs_classifier (built for %d)"
+                                 % (S, self.crs_classifier.weight.shape[1] // (2 * H)))
+            crs = ops.CrsFn.apply(A.anchor, seq, cross, self.crs_classifier, A, B, S)
+            cross = ops.SampleGateFn.apply(cross, None, crs, 1, B, S)
         # ---- gate + classifier (:1363-1371)
         logits = ops.GatedHeadFn.apply(A.anchor, seq, cross, self, A)
         return logits.view(B, S, self.num_labels)

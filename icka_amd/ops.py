@@ -400,6 +400,81 @@ class GatedHeadFn(torch.autograd.Function):
         return None, dseq, dcross, None, None
 
 
+class SampleGateFn(torch.autograd.Function):
+    """Per-sample gates (kernels: fusion.hip).  mode 0: out = g*a + (1-g)*c with g = sigmoid(gate[b])
+    (Cross_Modal_Interaction_Module.py:1035-1036); mode 1: out = softmax(gate[b])[1] * a (gate_cl_modeling.py:1369-1373)."""
+
+    @staticmethod
+    def forward(ctx, a, c, gate, mode: int, B: int, S: int):
+        out = torch.empty_like(a)
+        K.sample_gate_fwd(a, c, gate, mode, out, B, S)
+        ctx.mode, ctx.B, ctx.S = mode, B, S
+        ctx.save_for_backward(a, c, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, c, gate = ctx.saved_tensors
+        dout = _c(dout)
+        da = torch.empty_like(a)
+        dc = torch.empty_like(a) if c is not None else None
+        dgate = torch.zeros_like(gate)
+        K.sample_gate_bwd(dout, a, c, gate, ctx.mode, da, dc, dgate, ctx.B, ctx.S)
+        return da, dc, dgate, None, None, None
+
+
+class CrsFn(torch.autograd.Function):
+    """crs_classifier(cat(seq, cross).view(B, -1)) of gate_cl (gate_cl_modeling.py:1364-1366) -> f32 [B,2]."""
+
+    @staticmethod
+    def forward(ctx, anchor, seq, cross, lin, A: ParamArena, B: int, S: int):
+        crs = torch.zeros(B, 2, dtype=F32, device=seq.device)
+        K.crs_fwd(seq, cross, A.w(lin.weight), lin.bias, crs, B, S)
+        ctx.lin, ctx.A, ctx.B, ctx.S = lin, A, B, S
+        ctx.save_for_backward(seq, cross)
+        return crs
+
+    @staticmethod
+    def backward(ctx, dcrs):
+        seq, cross = ctx.saved_tensors
+        lin, A = ctx.lin, ctx.A
+        dseq = torch.empty(seq.shape[0], seq.shape[1], dtype=BF16, device=seq.device)
+        dcross = torch.empty_like(dseq)
+        acc = A.grad_beta((lin.weight, lin.bias)) > 0
+        K.crs_bwd(dcrs.contiguous(), seq, cross, A.w(lin.weight), dseq, dcross, A.g(lin.weight), A.g(lin.bias),
+                  ctx.B, ctx.S, acc)
+        A.flush_final()
+        return None, dseq, dcross, None, None, None, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """LayerNorm(x + r) on [rows, H] (cls_layer_both.forward, Cross_Modal_Interaction_Module.py:879-884)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, r, norm, A: ParamArena, eps: float):
+        M, H = x.shape
+        y = torch.empty(M, H, dtype=BF16, device=x.device)
+        xhat = torch.empty_like(y)
+        rstd = torch.empty(M, dtype=F32, device=x.device)
+        K.ln_fwd(x, None, r, norm.weight, norm.bias, y, xhat=xhat, rstd=rstd, eps=eps)
+        ctx.norm, ctx.A = norm, A
+        ctx.save_for_backward(xhat, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd = ctx.saved_tensors
+        norm, A = ctx.norm, ctx.A
+        dy = _c(dy)
+        d = torch.empty_like(dy)
+        ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(dy.shape[1]))
+        acc = A.grad_beta((norm.weight, norm.bias)) > 0
+        K.ln_bwd(dy, xhat, rstd, norm.weight, dres=d, dgamma=A.g(norm.weight), dbeta=A.g(norm.bias), partials=ws,
+                 accumulate=acc)
+        A.flush_final()
+        return None, d, d, None, None, None
+
+
 class TokenCEFn(torch.autograd.Function):
     """Benchmark loss: token-level cross-entropy, mean over valid tokens.  One launch yields
     the loss accumulators and the unscaled logit gradient; dloss / #valid is applied on device (no host sync)."""

@@ -162,6 +162,23 @@ int64_t icka_colsum_workspace_floats(int32_t N);
 int icka_gate_bwd(const void* dout, int64_t lddout, const void* g, const void* cross, int64_t ldcross,
                   const void* dcross_in, int64_t lddci, void* du, void* dcross, int64_t lddc, int32_t M, int32_t H,
                   void* stream);
+/* Per-sample gates (fusion.hip).  a / c / out are token-major bf16 [B*S, H] with row strides.
+ *  mode 0 (Cross_Modal_Interaction_Module.py:1029-1036): g_b = sigmoid(gate[b]);  out = g_b*a + (1-g_b)*c
+ *  mode 1 (gate_cl_modeling.py:1369-1373): g_b = softmax(gate[b,0..1])[1];        out = g_b*a   (c = NULL)
+ * Backward: da = g*dout, dc = (1-g)*dout (mode 0), and dgate (f32 [B] or [B,2], ZEROED BY THE CALLER) += its gradient. */
+int icka_sample_gate_fwd(const void* a, int64_t lda, const void* c, int64_t ldc, const float* gate, int32_t mode,
+                         void* out, int64_t ldo, int32_t B, int32_t S, int32_t H, void* stream);
+int icka_sample_gate_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* c, int64_t ldc,
+                         const float* gate, int32_t mode, void* da, int64_t ldda, void* dc, int64_t lddc, float* dgate,
+                         int32_t B, int32_t S, int32_t H, void* stream);
+/* crs_classifier of gate_cl (gate_cl_modeling.py:1258,:1364-1366): crs[b,:] (f32 [B,2], ZEROED BY THE CALLER) +=
+ * W[2, S*2H] . cat(seq,cross)[b].view(-1) + bias.  W bf16 (shadow), bias f32[2].  Backward: dseq / dcross (bf16
+ * contiguous [B*S,H]) are the input gradients, dW f32 [2, S*2H] and dbias f32[2] follow `accumulate`. */
+int icka_crs_fwd(const void* seq, int64_t lds, const void* cross, int64_t ldc, const void* W, const float* bias,
+                 float* crs, int32_t B, int32_t S, int32_t H, void* stream);
+int icka_crs_bwd(const float* dcrs, const void* seq, int64_t lds, const void* cross, int64_t ldc, const void* W,
+                 void* dseq, void* dcross, float* dW, float* dbias, int32_t B, int32_t S, int32_t H,
+                 int32_t accumulate, void* stream);
 /* c = a + b (bf16, contiguous n elements; gradient fan-in). */
 int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, void* stream);
 /* Token-level cross-entropy over valid tokens (benchmark loss), fused forward + backward:

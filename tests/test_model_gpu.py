@@ -12,14 +12,14 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 2e-2   # bf16 tolerance stated by BASELINE.json:north_star
 
 
-def _build(cfg, regions=49):
+def _build(cfg, regions=49, variant="cl", max_seq_length=128):
     from icka_amd.config import BertConfig
     from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
     c = BertConfig(cfg["vocab_size"], hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
                    num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
                    max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=cfg["type_vocab_size"])
     m = MTCCMBertForMMTokenClassificationCRF(c, layer_num1=cfg["layer_num1"], num_labels=cfg["num_labels"],
-                                             regions=regions)
+                                             regions=regions, variant=variant, max_seq_length=max_seq_length)
     synth.fill_module_(m)
     return m.cuda()
 
@@ -30,11 +30,13 @@ def _run(model, batch, labels=True):
                  g["visual_embeds_mean"], g["visual_embeds_att"], labels=g["labels"] if labels else None)
 
 
-@pytest.mark.parametrize("name", ["tiny_cl_r49", "tiny_cl_masks", "base_cl_s64_r36", "base_cl_s128_r49"])
+@pytest.mark.parametrize("name", ["tiny_cl_r49", "tiny_cl_masks", "tiny_gatecl_s128", "base_cl_s64_r36",
+                                  "base_cl_s128_r49"])
 def test_logits_loss_and_grads_match_reference_fixture(name):
     case = load_case(name)
     exp = case["expected"]
-    model = _build(case["cfg"], case["cfg"]["regions"]).eval()
+    model = _build(case["cfg"], case["cfg"]["regions"], variant=case["variant"],
+                   max_seq_length=case["batch"]["input_ids"].shape[1]).eval()
     logits = _run(model, case["batch"], labels=False)
     assert logits.dtype == torch.float32 and tuple(logits.shape) == exp["logits"].shape
     err = np.abs(logits.detach().cpu().numpy() - exp["logits"]).max()
@@ -94,6 +96,39 @@ def test_blocks_against_fixture():
         assert np.abs(c.detach().float().cpu().numpy() - z["cross"][i]).max() < 3e-2
     last_only = m.bert(ids, seg, msk, output_all_encoded_layers=False)[0]
     assert torch.equal(last_only, layers[-1])
+
+
+def test_scalar_gate_fusion_against_fixture():
+    """Cross_Modal form of the gate (cls_layer_both + aux_head, :1029-1036) with token_embedding as an input."""
+    from icka_amd.modeling import cls_layer_both, scalar_gate_fusion
+    z = np.load(GOLDEN_DIR + "/tiny_blocks.npz")
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cls_layer = cls_layer_both(128, 128)
+            self.aux_head = torch.nn.Linear(128, 1)
+
+    m = Holder()
+    synth.fill_module_(m)          # same key-seeded values (and the same proj_norm/LayerNorm aliasing) as the fixture
+    m = m.cuda()
+    cross = torch.from_numpy(z["cross"][-1]).cuda().requires_grad_(True)
+    tok = torch.from_numpy(z["tok"]).cuda().requires_grad_(True)
+    out = scalar_gate_fusion(m, cross, tok)
+    assert np.abs(out.detach().float().cpu().numpy() - z["blended"]).max() < 3e-2
+    out.float().sum().backward()
+    # reference math on the same bf16-rounded inputs (fp32 torch) for the gradients
+    c32 = cross.detach().to(torch.bfloat16).float().requires_grad_(True)
+    t32 = tok.detach().to(torch.bfloat16).float().requires_grad_(True)
+    P = {k: v.detach().float() for k, v in m.state_dict().items()}
+    feat = torch.nn.functional.layer_norm(c32[:, 0] + t32[:, 0], (128,), P["cls_layer.proj_norm.weight"],
+                                          P["cls_layer.proj_norm.bias"], 1e-5)
+    g = torch.sigmoid((feat @ P["cls_layer.proj.weight"].t() + P["cls_layer.proj.bias"]) @ P["aux_head.weight"].t()
+                      + P["aux_head.bias"]).view(-1, 1, 1)
+    (g * t32 + (1 - g) * c32).sum().backward()
+    for mine, ref in ((cross.grad, c32.grad), (tok.grad, t32.grad)):
+        assert ((mine.float() - ref).norm() / ref.norm()).item() < 3e-2
+    assert m.aux_head.weight.grad is not None and torch.isfinite(m.aux_head.weight.grad).all()
 
 
 def test_train_mode_dropout_statistics_and_determinism():
