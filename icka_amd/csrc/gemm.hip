@@ -620,7 +620,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, con
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,6 +631,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
     const int nk = g.K / BK;
     const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * 64;
+#ifdef ICKA_GEMM_STAMP
+    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ph1 = 0, ph2 = 0;
+#endif
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -712,6 +716,30 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         // (tools/probe/mfma_probe): LDS read latency at one wave per SIMD is hundreds of cycles once LDS-DMA writes
         // share the LDS pipe, far more than one half (272 cycles) covers.  Barrier kt+1 (tile kt+1 published, tile
         // kt fully in registers -> its buffer may be re-staged) is taken at the TOP of iteration kt.
+        if constexpr (DIST == 1) {
+            // two blocks per CU (ring of 2, <= 128 VGPRs): fragments are read per 32-deep step right before their
+            // MFMAs; the co-resident block's waves cover the LDS latency and this block's epilogue/prologue
+            int cur = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* sA = smem + cur * 2 * TILE_BYTES;
+                const char* sB = sA + TILE_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 fa[4], fb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) fa[t] = read_frag<A_KM>(sA, wr + 16 * t, ks, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+                }
+                cur = cur + 1 == NBUF ? 0 : cur + 1;
+            }
+        } else {
         bf16x8 pa0[4], pb0[4], pa1[4], pb1[4], qa0[4], qb0[4], qa1[4], qb1[4];
 #define ICKA_READ(FA, FB, BUFI, KS)                                                                  \
     if (ABL != 1) do {                                                                               \
@@ -734,6 +762,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     } while (0)
         __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
         asm volatile("" ::: "memory");
+#ifdef ICKA_GEMM_STAMP
+        ph1 = __builtin_amdgcn_s_memtime();
+#endif
         ICKA_READ(pa0, pb0, 0, 0);
         ICKA_READ(pa1, pb1, 0, 1);
         int nxt = NBUF > 1 ? 1 : 0;     // ring slot of tile kt+1
@@ -768,6 +799,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #undef ICKA_READ
 #undef ICKA_MMA
 #undef ICKA_SYNC
+        }
+#ifdef ICKA_GEMM_STAMP
+        ph2 = __builtin_amdgcn_s_memtime();
+#endif
     }
     __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
 
@@ -785,6 +820,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     }
     __syncthreads();
     epilogue_rows<32>(g, smem, m0, n0, tid);
+#ifdef ICKA_GEMM_STAMP
+    if (g.stamp && lane == 0 && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = g.stamp + (size_t)bid * 16 + 11;
+        o[0] = ph1 - ph0; o[1] = ph2 - ph1; o[2] = __builtin_amdgcn_s_memtime() - ph2;
+        o[3] = ph0; o[4] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 template <bool A_KM, bool B_KM, int NBUF, int ABL = 0>
@@ -792,6 +835,16 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
     gemm_ws_body<A_KM, B_KM, NBUF, ABL>(g, smem, blockIdx.x, gridDim.x);
+}
+
+// Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
+// tiles per CU one block's prologue (first DMA latency, ~2.8k cycles) and epilogue (~5.5k) overlap the other
+// block's main loop (stamps: at K = 768 they are 40 % of a tile's time).
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 4) void gemm_ws2_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
+    gemm_ws_body<A_KM, B_KM, 2, 0, 1>(g, smem, blockIdx.x, gridDim.x);
 }
 
 template <bool A_KM, bool B_KM, int NBUF, int ABL>
@@ -851,7 +904,11 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
 #endif
-                if (g_nbuf == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
+                // measured (tools/gemm_bench.py): two co-resident blocks win only for short reductions on grids of
+                // >= ~2 tiles per CU (qkv, ffn-up, d-ffn-down); long-K shapes prefer the deeper ring of one block
+                if ((g_ws == 2 || (g_ws == 1 && nb >= 448 && g.K <= 1024)) && !A_KM)
+                    hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM>), dim3(nb), dim3(512), 0, st, g);
+                else if (g_nbuf == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
                 else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3>), dim3(nb), dim3(512), 0, st, g);
                 ICKA_CHECK_LAUNCH();
                 return 0;
@@ -890,7 +947,7 @@ inline bool vec_ok(const void* p, int64_t ld) { return (ld % 8 == 0) && ((reinte
 }  // namespace
 
 extern "C" int icka_gemm_set_warp_specialized(int on) {
-    g_ws = on ? 1 : 0;
+    g_ws = on;   // 0: single-role kernel, 1: warp-specialised (two blocks per CU for large grids), 2: force two blocks, 3: never
     return 0;
 }
 

@@ -13,9 +13,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 lib = _lib.load()
 ring = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 lib.icka_gemm_set_ring(ring)
-for name, op, M, N, Kd in (("Wo TN", K.GEMM_TN, 768, 768, 4096), ("W1 TN", K.GEMM_TN, 3072, 768, 4096),
-                           ("ffndn NT", K.GEMM_NT, 4096, 768, 3072), ("qkv NT", K.GEMM_NT, 4096, 2304, 768),
-                           ("dffnup NN", K.GEMM_NN, 4096, 768, 3072)):
+for name, op, M, N, Kd in (("Wo TN", K.GEMM_TN, 768, 768, 4096), ("ffndn NT", K.GEMM_NT, 4096, 768, 3072),
+                           ("qkv NT", K.GEMM_NT, 4096, 2304, 768), ("outproj NT", K.GEMM_NT, 4096, 768, 768),
+                           ("ffnup NT", K.GEMM_NT, 4096, 3072, 768), ("dffnup NN", K.GEMM_NN, 4096, 768, 3072)):
     if op == K.GEMM_NT:
         A, B = torch.randn(M, Kd, device="cuda").to(BF16), torch.randn(N, Kd, device="cuda").to(BF16)
     elif op == K.GEMM_NN:
@@ -36,6 +36,10 @@ for name, op, M, N, Kd in (("Wo TN", K.GEMM_TN, 768, 768, 4096), ("W1 TN", K.GEM
     tot = b[:, 4]
     clk = (b[:, 4] / b[:, 5] * 100.0).median().item()   # MHz
     per = b[:, :4].mean(0) / nk
+    ph = b[:, 11:14].mean(0)
+    span = (b[:, 15].max() - b[:, 14].min()).item()
+    print("%-10s phases (cycles, mean over blocks): prologue %6.0f  loop %7.0f  epilogue %6.0f | whole grid span %8.0f cycles, "
+          "sum of phases %7.0f, rounds %.2f" % (name, ph[0], ph[1], ph[2], span, ph.sum().item(), nb / 256.0))
     cper = b[:, 8:10].mean(0) / nk
     print("%-10s ring %d blocks %4d nk %3d | LOADER per k-tile: vmcnt-wait %5.0f barrier %5.0f dma-issue %5.0f (loop %7.0f cyc) | "
           "COMPUTE per k-tile: F1-reads+MFMA(F0) %5.0f barrier-wait %5.0f (loop %7.0f cyc) | clock %.0f MHz"
