@@ -264,12 +264,19 @@ def main():
             model.zero_grad()
             step()
         torch.cuda.synchronize()
-        flops, ms, launches = K.profile_gemm(False)
+        flops, ms, launches, abytes = K.profile_gemm(False)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath):   # PMC passes cannot run inside this process: taken from the committed rocprofv3 runs
+            tj = json.load(open(tpath))
+            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_kernel<NT|NN|TN> (128x128x64 bf16 MFMA)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(abytes / launches),
+                    "algorithmic_flop_per_launch": round(flops / launches),
                     "launches_per_step": launches // nprof, "avg_launch_us": round(1e3 * ms / launches, 2),
                     "gemm_ms_per_step": round(ms / nprof, 3),
                     "whole_step_tflops": round(samples_per_s / world * fl_sample / 1e12, 2),

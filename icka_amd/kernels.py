@@ -59,9 +59,14 @@ def profile_gemm(enable: bool):
         return None
     rec, _PROF = _PROF or [], None
     torch.cuda.synchronize()
-    flops = sum(f for _, _, f in rec)
-    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-    return flops, ms, len(rec)
+    flops = sum(r[2] for r in rec)
+    ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+    return flops, ms, len(rec), sum(r[3] for r in rec)
+
+
+def _gemm_bytes(d) -> float:
+    """algorithmic HBM bytes of one GEMM: both operands once + the output once (bf16 in, bf16/f32 out)"""
+    return 2.0 * (d.M * d.K + d.N * d.K) + d.M * d.N * (4.0 if d.c_is_f32 else 2.0)
 
 
 def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
@@ -122,7 +127,7 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> 
         e0.record()
         check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
         e1.record()
-        _PROF.append((e0, e1, 2.0 * d.M * d.N * d.K))
+        _PROF.append((e0, e1, 2.0 * d.M * d.N * d.K, _gemm_bytes(d)))
         return out
     check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
     return out
@@ -139,7 +144,7 @@ def gemm_grouped(descs) -> None:
         e0.record()
         check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
         e1.record()
-        _PROF.append((e0, e1, sum(2.0 * d.M * d.N * d.K for d in descs)))
+        _PROF.append((e0, e1, sum(2.0 * d.M * d.N * d.K for d in descs), sum(_gemm_bytes(d) for d in descs)))
         return
     check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
 
