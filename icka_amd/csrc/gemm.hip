@@ -348,6 +348,27 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
 }
 
+// Block -> output tile.  Blocks b and b+8 share an XCD (round-robin dispatch); each XCD has a private 4 MiB L2.
+//  * few column tiles: every XCD takes a contiguous run of row-major tiles (its A row panels + all of B stay in L2);
+//  * many column tiles (N >= 1536): the 8 XCDs form a 4 x 2 grid over the tile matrix, so an XCD touches nbm/4 A
+//    panels and nbn/2 B panels instead of nbm/8 and ALL nbn (B alone would overflow its L2 and be re-fetched from
+//    the Infinity Cache for every tile row: rocprofv3 FETCH_SIZE was 3-4x the algorithmic bytes).
+// Placement only affects speed: every tile is produced exactly once for any dispatch order.
+__device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, int& m0, int& n0) {
+    const int xcd = bid & 7, li = bid >> 3;
+    if (nbn >= 12 && (nb & 7) == 0 && (nbm & 3) == 0 && (nbn & 1) == 0) {
+        const int sm = nbm >> 2, sn = nbn >> 1;
+        const int xi = xcd >> 1, xj = xcd & 1;
+        m0 = (xi * sm + li / sn) * BM;
+        n0 = (xj * sn + li % sn) * BN;
+        return;
+    }
+    const int qn = nb >> 3, rn = nb & 7;
+    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + li;
+    m0 = (sw / nbn) * BM;
+    n0 = (sw % nbn) * BN;
+}
+
 // Second half of the LDS-staged epilogue: thread t finishes 8 consecutive columns (c8 = t & 15) of rows
 // (t >> 4) + RSTEP*i; 16 lanes cover a whole 128-column row -> 16-byte row-contiguous global accesses.
 template <int RSTEP>
@@ -433,10 +454,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    const int nbn = g.N / BN;
-    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
-    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
+    int m0, n0;
+    tile_origin(bid, nb, g.M / BM, g.N / BN, m0, n0);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -625,10 +644,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
-    const int nbn = g.N / BN;
-    const int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
-    const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-    const int m0 = (sw / nbn) * BM, n0 = (sw % nbn) * BN;
+    int m0, n0;
+    tile_origin(bid, nb, g.M / BM, g.N / BN, m0, n0);
     const int nk = g.K / BK;
     const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * 64;
 #ifdef ICKA_GEMM_STAMP
