@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("bias", c_vp), ("bias2", c_vp),
         ("alpha", c_f32), ("beta", c_f32),
         ("epilogue", c_i32),
+        ("colsum_out", c_vp), ("colsum_accumulate", c_i32),
     ]
 
 

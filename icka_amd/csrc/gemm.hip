@@ -28,6 +28,7 @@ struct GemmArgs {
     int epi, c_f32;
     int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
     int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
+    float* colsum; int colsum_acc;  // TN fast path: colsum[m] (+)= sum_k A[k,m] (bias gradient fused into dW = dY^T.X)
     unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
 };
@@ -659,6 +660,15 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Bias gradient for free: in the blocks of the first tile column the compute waves that own columns 0..63 also
+    // multiply the A fragments (dY, rows = output features) by an all-ones operand: D[i][j] = sum_k A[j][k], i.e. the
+    // column sums of dY over the tokens, 4 extra MFMAs per 16 (only in 1/nbn of the blocks).
+    const bool do_cs = A_KM && g.colsum != nullptr && n0 == 0 && wave < 4 && wc == 0;
+    f32x4 cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f)};
+
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------------- loader waves
         const int lw = wave - 4;
@@ -753,6 +763,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+                    if (do_cs) {
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, fa[mi], cs[mi]);
+                    }
                 }
                 cur = cur + 1 == NBUF ? 0 : cur + 1;
             }
@@ -769,6 +783,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     if (ABL != 1) do {                                                                               \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(FB[ni], FA[mi], acc[mi][ni]); \
+        if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, FA[mi], cs[mi]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
 #define ICKA_SYNC()                                          \
@@ -823,6 +838,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     }
     __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
 
+    if (do_cs && lane < 16) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            float* p = g.colsum + m0 + wr + 16 * mi + lane;
+            *p = g.colsum_acc ? *p + cs[mi][0] : cs[mi][0];
+        }
+    }
     // ---- epilogue through LDS: compute waves deposit their accumulators, all 8 waves finish rows
     if (wave < 4) {
 #pragma unroll
@@ -1000,12 +1022,15 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
     g.abl = g_abl;
     g.stamp = g_stamp;
+    g.colsum = d->colsum_out;
+    g.colsum_acc = d->colsum_accumulate;
     g.ksplit = 1;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
     auto al = [](const void* p, int64_t ld, int64_t mod) {
         return !p || (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ld % mod == 0);
     };
+    if (d->colsum_out && d->op != ICKA_GEMM_TN) return ICKA_E_ARG;
     aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
               al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
               al(d->bias, 4, 4) && al(d->bias2, 4, 4);
@@ -1017,6 +1042,7 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     bool aligned = false;
     const int rc = convert(d, g, aligned);
     if (rc) return rc;
+    if (g.colsum && !(aligned && g_ws)) return ICKA_E_ARG;   // fused column sums exist on the warp-specialised path
     hipStream_t st = (hipStream_t)stream;
     switch (d->op) {
         case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st);
@@ -1064,6 +1090,7 @@ extern "C" int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* s
             bool aligned = false;
             const int rc = convert(&descs[i + cnt], ga.p[cnt], aligned);
             if (rc) return rc;
+            if (ga.p[cnt].colsum && !(aligned && g_ws)) return ICKA_E_ARG;
             if (!aligned) break;
             ga.start[cnt] = total;
             total += (ga.p[cnt].M / BM) * (ga.p[cnt].N / BN);

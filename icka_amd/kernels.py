@@ -72,7 +72,8 @@ def _gemm_bytes(d) -> float:
 def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
               epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
               alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
-              B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None) -> GemmDesc:
+              B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
+              colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> GemmDesc:
     """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched)."""
     _mat(A, "A"); _mat(B, "B")
     if op == GEMM_NT:
@@ -115,6 +116,12 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
         raise ValueError("bias2 must be contiguous device f32 [N]")
     d.bias2 = _ptr(bias2)
     d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
+    if colsum_out is not None:
+        if op != GEMM_TN or colsum_out.dtype != F32 or colsum_out.numel() != M or not colsum_out.is_contiguous():
+            raise ValueError("colsum_out: contiguous f32 [M] with op TN")
+        if M % 128 or N % 128 or K % 64:
+            raise ValueError("fused column sums need the aligned fast path (M, N % 128 == 0, K % 64 == 0)")
+    d.colsum_out, d.colsum_accumulate = _ptr(colsum_out), int(colsum_accumulate)
     return d
 
 

@@ -46,8 +46,20 @@ class Dims(object):
 # Weight gradients (dW = dY^T . X, reduction over the tokens) have no consumer inside backward: each block queues
 # them and launches the whole batch as ONE grouped GEMM at the end of its backward (4 GEMMs of 36..144 tiles each
 # fill the 256 CUs together instead of one after the other).
-def _wgrad(A: ParamArena, dy, x, gout, beta: float) -> None:
-    A.pending_wgrad.append((K.gemm_desc(K.GEMM_TN, dy, x, gout, beta=beta), dy, x, gout))
+def _wgrad(A: ParamArena, dy, x, gout, beta: float, bias=None) -> None:
+    """Queue dW (+)= dy^T . x; with ``bias`` (parameter or tuple of adjacent parameters) also db (+)= colsum(dy),
+    fused into the same GEMM when the shape is on the fast path, else by the column-sum kernel."""
+    bout, bacc = None, False
+    if bias is not None:
+        bacc = A.grad_beta(bias) > 0
+        bout = A.g_cat(bias) if isinstance(bias, tuple) else A.g(bias)
+        M, N, Kt = dy.shape[1], x.shape[1], dy.shape[0]
+        if M % 128 or N % 128 or Kt % 64:
+            csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(M))
+            K.colsum(dy, bout, csw, accumulate=bacc)
+            bout = None
+    A.pending_wgrad.append((K.gemm_desc(K.GEMM_TN, dy, x, gout, beta=beta, colsum_out=bout, colsum_accumulate=bacc),
+                            dy, x, gout, bout))
 
 
 def _flush_wgrad(A: ParamArena) -> None:
@@ -110,7 +122,6 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     dctx = _empty(x, M, H)
     K.gemm(K.GEMM_NN, dao, A.w(so.dense.weight), dctx)
     delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
-    csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(3 * H))
     if kv_src is None:
         dqkv = _empty(x, M, 3 * H)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
@@ -118,8 +129,7 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
                    d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
         wg = (sa.query.weight, sa.key.weight, sa.value.weight)
         bg = (sa.query.bias, sa.key.bias, sa.value.bias)
-        _wgrad(A, dqkv, x, A.g_cat(wg), A.grad_beta(wg))
-        K.colsum(dqkv, A.g_cat(bg), csw, accumulate=A.grad_beta(bg) > 0)
+        _wgrad(A, dqkv, x, A.g_cat(wg), A.grad_beta(wg), bias=bg)
         dx = _empty(x, M, H)
         K.gemm(K.GEMM_NN, dqkv, A.w_cat(wg), dx, epilogue=K.EPI_ADD, aux=dres)
         return dx, None
@@ -127,12 +137,10 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     dkv = _empty(x, kv_src.shape[0], 2 * H)
     K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
                d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
-    _wgrad(A, dq, x, A.g(sa.query.weight), A.grad_beta(sa.query.weight))
-    K.colsum(dq, A.g(sa.query.bias), csw, accumulate=A.grad_beta(sa.query.bias) > 0)
+    _wgrad(A, dq, x, A.g(sa.query.weight), A.grad_beta(sa.query.weight), bias=sa.query.bias)
     wg = (sa.key.weight, sa.value.weight)
     bg = (sa.key.bias, sa.value.bias)
-    _wgrad(A, dkv, kv_src, A.g_cat(wg), A.grad_beta(wg))
-    K.colsum(dkv, A.g_cat(bg), csw, accumulate=A.grad_beta(bg) > 0)
+    _wgrad(A, dkv, kv_src, A.g_cat(wg), A.grad_beta(wg), bias=bg)
     dx = _empty(x, M, H)
     K.gemm(K.GEMM_NN, dq, A.w(sa.query.weight), dx, epilogue=K.EPI_ADD, aux=dres)
     dsrc = None
@@ -178,9 +186,7 @@ def _ffn_block_bwd(A: ParamArena, layer, x, d: Dims, saved, dy, dy2=None):
     _wgrad(A, dfo, g, A.g(out.dense.weight), A.grad_beta(out.dense.weight))
     dz = _empty(x, M, I)
     K.gemm(K.GEMM_NN, dfo, A.w(out.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)
-    _wgrad(A, dz, x, A.g(inter.dense.weight), A.grad_beta(inter.dense.weight))
-    csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(I))
-    K.colsum(dz, A.g(inter.dense.bias), csw, accumulate=A.grad_beta(inter.dense.bias) > 0)
+    _wgrad(A, dz, x, A.g(inter.dense.weight), A.grad_beta(inter.dense.weight), bias=inter.dense.bias)
     dx = _empty(x, M, H)
     K.gemm(K.GEMM_NN, dz, A.w(inter.dense.weight), dx, epilogue=K.EPI_ADD, aux=dres)
     return dx

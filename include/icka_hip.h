@@ -60,6 +60,9 @@ typedef struct icka_gemm_desc {
     const float* bias2;                         /* optional second f32 [N] bias (two Linear layers summed) */
     float alpha, beta;
     int32_t epilogue;      /* ICKA_EPI_* */
+    float* colsum_out;     /* op TN only, fast path (M,N %128, K %64): colsum_out[m] (+)= sum_k A[k,m]  -- the bias
+                              gradient db = colsum(dY) produced by the weight-gradient GEMM dW = dY^T.X itself */
+    int32_t colsum_accumulate;
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that

@@ -140,9 +140,19 @@ def test_gemm_grouped_matches_individual_launches():
         descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=1.0))
         keep.append((A, B)); outs.append(out)
         refs.append(A.float().t() @ B.float() + 0.5)
+    # the first two also produce their bias gradient (column sums of the dY operand) inside the GEMM
+    cs = [torch.full((H,), 2.0, dtype=F32, device="cuda"), torch.zeros(I, dtype=F32, device="cuda")]
+    descs[0] = k.gemm_desc(k.GEMM_TN, keep[0][0], keep[0][1], outs[0], beta=1.0, colsum_out=cs[0], colsum_accumulate=True)
+    descs[1] = k.gemm_desc(k.GEMM_TN, keep[1][0], keep[1][1], outs[1], beta=1.0, colsum_out=cs[1], colsum_accumulate=False)
     k.gemm_grouped(descs)
     for o, r in zip(outs, refs):
         assert rel_err(o, r) < 1e-4
+    assert rel_err(cs[0], keep[0][0].float().sum(0) + 2.0) < 1e-4
+    assert rel_err(cs[1], keep[1][0].float().sum(0)) < 1e-4
+    single = torch.zeros(I, dtype=F32, device="cuda")
+    o2 = torch.empty(I, H, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_TN, keep[1][0], keep[1][1], o2, colsum_out=single)
+    assert rel_err(single, keep[1][0].float().sum(0)) < 1e-4 and rel_err(o2, keep[1][0].float().t() @ keep[1][1].float()) < 1e-4
 
 
 def test_gemm_bad_args():
