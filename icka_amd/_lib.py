@@ -56,6 +56,7 @@ PROTOTYPES = {
                                c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
     "icka_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_attn_set_whole_head": (None, [c_i32]),
     "icka_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
                               c_vp]),
@@ -95,11 +96,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("ICKA_HIP_LIB", LIB_PATH)   # diagnostic builds (tools/*_bench.py); default: the in-tree .so
+    if not os.path.exists(path):
         raise IckaLibraryError(
             "libicka_hip.so not found at %s: build it with `make -C icka_amd/csrc` "
-            "(or __graft_entry__.build()).  icka_amd has no CPU / eager fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "(or __graft_entry__.build()).  icka_amd has no CPU / eager fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res

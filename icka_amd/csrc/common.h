@@ -84,12 +84,17 @@ __host__ __device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed) {
     }
     return d;
 }
-__host__ __device__ __forceinline__ uint32_t icka_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
-    uint32_t x = idx * 0x9E3779B1u + s0;
+// hash(idx) = tail(idx * C0 + s0): kernels whose element index is base + compile-time offset keep base*C0 + s0 in a
+// register and add offset*C0 (a constant), which removes one quarter-rate 32-bit multiply per element.
+constexpr uint32_t ICKA_HASH_C0 = 0x9E3779B1u;
+__host__ __device__ __forceinline__ uint32_t icka_hash_tail(uint32_t x, uint32_t s1) {
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x = x * 0x846ca68bu + s1;
     x ^= x >> 16;
     return x;
+}
+__host__ __device__ __forceinline__ uint32_t icka_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
+    return icka_hash_tail(idx * ICKA_HASH_C0 + s0, s1);
 }
 // fold the device nonce into the seed (call once at kernel entry)
 __device__ __forceinline__ DropCfg drop_resolve(DropCfg d) {
@@ -99,6 +104,19 @@ __device__ __forceinline__ DropCfg drop_resolve(DropCfg d) {
 // multiplier applied to a kept element: scale if kept, 0 if dropped
 __device__ __forceinline__ float drop_mul(const DropCfg& d, uint32_t idx) {
     return (d.thr == 0u || icka_hash(d.s0, d.s1, idx) >= d.thr) ? d.scale : 0.f;
+}
+
+// same, with the "dropout off" case resolved at compile time (branch-free inner loops)
+template <bool DROP>
+__device__ __forceinline__ float drop_mul_t(const DropCfg& d, uint32_t idx) {
+    if (!DROP) return 1.f;
+    return icka_hash(d.s0, d.s1, idx) >= d.thr ? d.scale : 0.f;
+}
+// x = idx * ICKA_HASH_C0 + s0 already formed by the caller
+template <bool DROP>
+__device__ __forceinline__ float drop_mul_x(const DropCfg& d, uint32_t x) {
+    if (!DROP) return 1.f;
+    return icka_hash_tail(x, d.s1) >= d.thr ? d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -366,6 +366,11 @@ __device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, i
     }
     const int qn = nb >> 3, rn = nb & 7;
     const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + li;
+    if (nbn > nbm) {  // runs go along the SHORTER side, so an XCD's run is a squarish patch (fewer operand panels)
+        m0 = (sw % nbm) * BM;
+        n0 = (sw / nbm) * BN;
+        return;
+    }
     m0 = (sw / nbn) * BM;
     n0 = (sw % nbn) * BN;
 }

@@ -47,21 +47,41 @@ def _ld(t: Optional[torch.Tensor]) -> int:
 
 
 # ------------------------------------------------------------------------------------------------------- GEMM
-_PROF = None   # None, or a list of (start_event, stop_event, flops) while profile_gemm(True) is active
+_PROF = None   # None, or the list of GEMM launches recorded while profile_gemm(True) is active
 
 
-def profile_gemm(enable: bool):
-    """Instrument every GEMM launch with a pair of HIP events on the launch stream (bench.py roofline leg).
-    profile_gemm(True) starts collecting; profile_gemm(False) returns (algorithmic FLOPs, summed ms, launches)."""
+def profile_gemm(enable: bool, reps: int = 5):
+    """bench.py roofline leg.  profile_gemm(True): start recording every GEMM launch (descriptor + operand tensors,
+    kept alive).  profile_gemm(False): re-issue the recorded launches back to back, ``reps`` times, between ONE pair
+    of HIP events on the launch stream (so no host gap or per-launch event cost is inside the bracket) and return
+    (algorithmic FLOPs, elapsed ms, launches, algorithmic bytes) of what ran inside the bracket."""
     global _PROF
     if enable:
         _PROF = []
         return None
     rec, _PROF = _PROF or [], None
+    lib = _lib.load()
+    if not rec:
+        return 0.0, 0.0, 0, 0.0
+
+    def replay():
+        for kind, payload, n, _keep in rec:
+            if kind == 0:
+                check(lib.icka_gemm(C.byref(payload), _stream()), "icka_gemm")
+            else:
+                check(lib.icka_gemm_grouped(payload, n, _stream()), "icka_gemm_grouped")
+
+    replay()   # warm
     torch.cuda.synchronize()
-    flops = sum(r[2] for r in rec)
-    ms = sum(r[0].elapsed_time(r[1]) for r in rec)
-    return flops, ms, len(rec), sum(r[3] for r in rec)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        replay()
+    e1.record()
+    torch.cuda.synchronize()
+    flops = reps * sum(2.0 * d.M * d.N * d.K for _, _, _, ds in rec for d in ds)
+    nbytes = reps * sum(_gemm_bytes(d) for _, _, _, ds in rec for d in ds)
+    return flops, e0.elapsed_time(e1), reps * len(rec), nbytes
 
 
 def _gemm_bytes(d) -> float:
@@ -122,6 +142,8 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
         if M % 128 or N % 128 or K % 64:
             raise ValueError("fused column sums need the aligned fast path (M, N % 128 == 0, K % 64 == 0)")
     d.colsum_out, d.colsum_accumulate = _ptr(colsum_out), int(colsum_accumulate)
+    if _PROF is not None:   # the recorded launch is re-issued later: its operands must outlive the step
+        d._keep = (A, B, out, bias, aux, out2, A2, B2, bias2, colsum_out)
     return d
 
 
@@ -130,12 +152,7 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> 
     lib = _lib.load()
     d = gemm_desc(op, A, B, out, **kw)
     if _PROF is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
-        e1.record()
-        _PROF.append((e0, e1, 2.0 * d.M * d.N * d.K, _gemm_bytes(d)))
-        return out
+        _PROF.append((0, d, 1, [d]))
     check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
     return out
 
@@ -147,12 +164,7 @@ def gemm_grouped(descs) -> None:
     lib = _lib.load()
     arr = (GemmDesc * len(descs))(*descs)
     if _PROF is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
-        e1.record()
-        _PROF.append((e0, e1, sum(2.0 * d.M * d.N * d.K for d in descs), sum(_gemm_bytes(d) for d in descs)))
-        return
+        _PROF.append((1, arr, len(descs), list(descs)))
     check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
 
 
@@ -238,6 +250,11 @@ def attn_bwd(q, k, v, add_mask, out, dout, lse, delta, dq, dk, dv, B, heads, Sq,
                             lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
                             dk.stride(0), dv.data_ptr(), dv.stride(0), B, heads, Sq, Skv, scale, p_drop, seed,
                             _stream()), "icka_attn_bwd")
+
+
+def attn_set_whole_head(on: bool) -> None:
+    """False forces the tiled attention kernels for every shape (tests exercise both paths)."""
+    _lib.load().icka_attn_set_whole_head(int(bool(on)))
 
 
 # ------------------------------------------------------------------------------------------------- helpers

@@ -130,7 +130,11 @@ int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type
 int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const float* add_mask, void* O, int64_t ldo, float* lse, int32_t B, int32_t heads, int32_t Sq,
                   int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
-/* delta f32 [B,heads,Sq] is workspace (rowsum(dO*O)). */
+/* Heads with Sq <= 128 and Skv <= 128 (the reference's max_seq_length 128 and 36/49 regions) take the whole-head
+ * kernels: one block per (batch, head), forward without online-softmax rescaling, backward (dQ, dK, dV, delta) in
+ * one launch.  icka_attn_set_whole_head(0) forces the tiled flash-style kernels for every shape (default 1). */
+void icka_attn_set_whole_head(int32_t on);
+/* delta f32 [B,heads,Sq] is workspace (rowsum(dO*O) = rowsum(P.dP)); it is written by the call. */
 int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const float* add_mask, const void* O, int64_t ldo, const void* dO, int64_t lddo, const float* lse,
                   float* delta, void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int32_t B,

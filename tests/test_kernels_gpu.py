@@ -229,9 +229,15 @@ def _attn_ref(q, k_, v, add_mask, dmask, B, h, Sq, Skv):
 
 @pytest.mark.parametrize("B,h,Sq,Skv,p", [(2, 2, 64, 64, 0.0), (2, 12, 128, 128, 0.0), (3, 2, 100, 49, 0.0),
                                           (2, 4, 128, 36, 0.1), (2, 3, 128, 128, 0.1), (1, 2, 32, 200, 0.0),
-                                          (1, 16, 256, 256, 0.1)])
-def test_attention_fwd_bwd(B, h, Sq, Skv, p):
+                                          (1, 16, 256, 256, 0.1), (2, 2, 49, 128, 0.1), (1, 2, 5, 7, 0.0),
+                                          (2, 2, 128, 49, 0.1), (1, 3, 65, 65, 0.1)])
+@pytest.mark.parametrize("whole_head", [True, False])
+def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
     k = _k()
+    if whole_head and (Sq > 128 or Skv > 128):
+        pytest.skip("whole-head kernels cover Sq, Skv <= 128")
+    k.attn_set_whole_head(whole_head)
+    request.addfinalizer(lambda: k.attn_set_whole_head(True))
     H = h * 64
     fused = rnd(B * Sq, 3 * H, seed=1)          # q lives inside a fused [M,3H] buffer (strided view)
     q = fused[:, H:2 * H]
@@ -259,6 +265,8 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p):
     assert rel_err(dq, qf.grad) < 3e-2
     assert rel_err(dkv[:, :H], kf.grad) < 3e-2
     assert rel_err(dkv[:, H:], vf.grad) < 3e-2
+    dref = (oref.detach() * dout.float()).view(B, Sq, h, 64).sum(-1).permute(0, 2, 1)
+    assert (delta - dref).abs().max().item() < 3e-2 * max(dref.abs().max().item(), 1.0)
 
 
 def test_attention_fully_masked_row_matches_reference_softmax():
