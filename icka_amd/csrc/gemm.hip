@@ -29,6 +29,7 @@ struct GemmArgs {
     int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
     int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
     float* colsum; int colsum_acc;  // TN fast path: colsum[m] (+)= sum_k A[k,m] (bias gradient fused into dW = dY^T.X)
+    int n96ok;                  // fast path + N % 96 == 0: the 128x96 tile is an option
     unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
 };
@@ -289,19 +290,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
 // 16-byte, row-contiguous accesses (whole 256-B rows per 16 lanes) instead of 8-byte stores scattered over 16 rows.
 // Per-lane SOURCE pointers of the 4 one-KiB pieces a wave stages per operand tile (k-tile 0).  They advance by a
 // wave-uniform stride per k-tile, so the k-loop carries no address arithmetic beyond 8 pointer bumps.
-template <bool KM>
+// NCOL = operand rows (k-contiguous) / columns (k-major) the tile really has: 128, or 96 for the narrow-N tile.  The
+// LDS image keeps the 128-wide geometry; with 96 the k-contiguous image simply has no pieces 12..15 and the k-major
+// image leaves chunks 12..15 of every row unused (their lanes re-fetch a valid chunk of the same row instead).
+template <bool KM, int NCOL = 128>
 __device__ __forceinline__ void dma_init(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int row0,
                                          int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = wave + 4 * j;  // 1-KiB piece: 8 tile rows (k-contiguous image) or 4 k-rows (k-major image)
         if (!KM) {
-            const int row = 8 * p + (lane >> 3);
+            const int row = (8 * p + (lane >> 3)) % NCOL;   // pieces past NCOL/8 are never issued
             const int lc = (lane & 7) ^ ((row >> 1) & 7);
             ptr[j] = P + (int64_t)(row0 + row) * ld + 8 * lc;
         } else {
             const int kr = 4 * p + (lane >> 4);
-            const int lc = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+            int lc = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+            if (lc >= NCOL / 8) lc &= 7;
             ptr[j] = P + (int64_t)kr * ld + row0 + 8 * lc;
         }
     }
@@ -310,8 +315,29 @@ __device__ __forceinline__ void dma_init(const bf16_t* (&ptr)[4], const bf16_t* 
 // ASM: hipcc treats a compiler-visible LDS-DMA as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the
 // next ds_read_b64_tr_b16, which serialises the whole pipeline; hidden in asm, the ring is ordered only by our own
 // counted vmcnt + s_barrier (cdna guide section 5.7).  M0 (LDS destination base) is saved/restored inside.
+template <int NJ = 4>
 __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t stride, uint32_t lds_base) {
     uint32_t keep;
+    if constexpr (NJ == 3) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %3, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "s"(lds_base)
+            : "memory", "scc");
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ptr[j] += stride;
+        return;
+    }
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %5\n\t"
@@ -355,31 +381,34 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
 //    panels and nbn/2 B panels instead of nbm/8 and ALL nbn (B alone would overflow its L2 and be re-fetched from
 //    the Infinity Cache for every tile row: rocprofv3 FETCH_SIZE was 3-4x the algorithmic bytes).
 // Placement only affects speed: every tile is produced exactly once for any dispatch order.
-__device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, int& m0, int& n0) {
+__device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, int& m0, int& n0, int bn = BN) {
     const int xcd = bid & 7, li = bid >> 3;
     if (nbn >= 12 && (nb & 7) == 0 && (nbm & 3) == 0 && (nbn & 1) == 0) {
         const int sm = nbm >> 2, sn = nbn >> 1;
         const int xi = xcd >> 1, xj = xcd & 1;
         m0 = (xi * sm + li / sn) * BM;
-        n0 = (xj * sn + li % sn) * BN;
+        n0 = (xj * sn + li % sn) * bn;
         return;
     }
     const int qn = nb >> 3, rn = nb & 7;
     const int sw = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + li;
     if (nbn > nbm) {  // runs go along the SHORTER side, so an XCD's run is a squarish patch (fewer operand panels)
         m0 = (sw % nbm) * BM;
-        n0 = (sw / nbm) * BN;
+        n0 = (sw / nbm) * bn;
         return;
     }
     m0 = (sw / nbn) * BM;
-    n0 = (sw % nbn) * BN;
+    n0 = (sw % nbn) * bn;
 }
 
 // Second half of the LDS-staged epilogue: thread t finishes 8 consecutive columns (c8 = t & 15) of rows
 // (t >> 4) + RSTEP*i; 16 lanes cover a whole 128-column row -> 16-byte row-contiguous global accesses.
-template <int RSTEP>
+template <int RSTEP, int NC8 = 16>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
-    const int c8 = tid & 15;           // 8-column group of the row
+    // NC8 = 8-column groups per tile row: 16 (128-wide tile) or 12 (96-wide: 12 lanes per row, 384 of 512 threads)
+    if (NC8 != 16 && tid >= RSTEP * NC8) return;
+    const int c8 = NC8 == 16 ? (tid & 15) : tid % NC8;   // 8-column group of the row
+    const int rb = NC8 == 16 ? (tid >> 4) : tid / NC8;
     const int n = n0 + 8 * c8;
     float bias[8];
 #pragma unroll
@@ -396,7 +425,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
     }
 #pragma unroll
     for (int i = 0; i < 128 / RSTEP; ++i) {
-        const int row = (tid >> 4) + RSTEP * i;
+        const int row = rb + RSTEP * i;
         const int m = m0 + row;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8 + 1));
@@ -645,25 +674,30 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, con
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
     int m0, n0;
-    tile_origin(bid, nb, g.M / BM, g.N / BN, m0, n0);
+    // BNT = tile width: 128, or 96 when that fills the 256 CUs better (N = 768 -> 256 tiles instead of 192)
+    constexpr int NTN = BNT / 32;                  // 16-column MFMA tiles per compute wave (4 or 3)
+    constexpr int NJB = B_KM ? 4 : BNT / 32;       // LDS-DMA pieces of the B tile per loader wave
+    constexpr int ND = 4 + NJB;                    // DMA instructions per k-tile per loader wave
+    static_assert(BNT == 128 || BNT == 96, "tile width");
+    tile_origin(bid, nb, g.M / BM, g.N / BNT, m0, n0, BNT);
     const int nk = g.K / BK;
-    const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * 64;
+    const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * (BNT / 2);
 #ifdef ICKA_GEMM_STAMP
     const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
     unsigned long long ph1 = 0, ph2 = 0;
 #endif
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NTN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Bias gradient for free: in the blocks of the first tile column the compute waves that own columns 0..63 also
     // multiply the A fragments (dY, rows = output features) by an all-ones operand: D[i][j] = sum_k A[j][k], i.e. the
@@ -681,19 +715,19 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         const bf16_t* pa[4];
         const bf16_t* pb[4];
         dma_init<A_KM>(pa, g.A, g.lda, m0, lw, lane);
-        dma_init<B_KM>(pb, g.B, g.ldb, n0, lw, lane);
+        dma_init<B_KM, BNT>(pb, g.B, g.ldb, n0, lw, lane);
         int64_t sa = A_KM ? (int64_t)BK * g.lda : BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
 #define ICKA_WS_STAGE(KT, BUF)                                          \
     do {                                                                \
         if ((KT) == k1t) {                                              \
             dma_init<A_KM>(pa, g.A2, g.lda2, m0, lw, lane);             \
-            dma_init<B_KM>(pb, g.B2, g.ldb2, n0, lw, lane);             \
+            dma_init<B_KM, BNT>(pb, g.B2, g.ldb2, n0, lw, lane);        \
             sa = A_KM ? (int64_t)BK * g.lda2 : BK;                      \
             sb = B_KM ? (int64_t)BK * g.ldb2 : BK;                      \
         }                                                               \
         if (ABL != 2) {                                                 \
             dma_issue(pa, sa, lds0 + (BUF) + lw * 1024);                \
-            dma_issue(pb, sb, lds0 + (BUF) + TILE_BYTES + lw * 1024);   \
+            dma_issue<NJB>(pb, sb, lds0 + (BUF) + TILE_BYTES + lw * 1024); \
         }                                                               \
     } while (0)
 #pragma unroll
@@ -711,9 +745,16 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
             int ahead = nk - 1 - kt;
             ahead = ahead > NBUF - 2 ? NBUF - 2 : ahead;
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (ND == 8) {
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                static_assert(ND == 8 || ND == 7, "DMA count per k-tile");
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[0] += tB - tA; tA = tB;
 #endif
@@ -763,11 +804,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #pragma unroll
                     for (int t = 0; t < 4; ++t) fa[t] = read_frag<A_KM>(sA, wr + 16 * t, ks, lane);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
+                    for (int t = 0; t < NTN; ++t) fb[t] = read_frag<B_KM>(sB, wc + 16 * t, ks, lane);
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+                        for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
                     if (do_cs) {
 #pragma unroll
                         for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, fa[mi], cs[mi]);
@@ -781,13 +822,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     if (ABL != 1) do {                                                                               \
         const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) FA[t] = read_frag<A_KM>(b_, wr + 16 * t, KS, lane);              \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) FB[t] = read_frag<B_KM>(b_ + TILE_BYTES, wc + 16 * t, KS, lane); \
+        _Pragma("unroll") for (int t = 0; t < NTN; ++t) FB[t] = read_frag<B_KM>(b_ + TILE_BYTES, wc + 16 * t, KS, lane); \
         __builtin_amdgcn_sched_barrier(0); /* keep the reads AHEAD of the next MFMA group (hipcc sinks them) */     \
     } while (0)
 #define ICKA_MMA(FA, FB)                                                                             \
     if (ABL != 1) do {                                                                               \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(FB[ni], FA[mi], acc[mi][ni]); \
+            _Pragma("unroll") for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16(FB[ni], FA[mi], acc[mi][ni]); \
         if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, FA[mi], cs[mi]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
@@ -837,6 +878,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #undef ICKA_MMA
 #undef ICKA_SYNC
         }
+        // MFMA -> VALU read-after-write needs software wait states on gfx950 (8-pass MFMA: ~11).  hipcc's hazard
+        // recognizer missed one across a block boundary here (<TN, 96-wide>, odd k-tile count: a v_mov of the last
+        // accumulator element right behind the branch that follows the last MFMA -> one stale element per lane, found
+        // by tools/gemm_tile_check.py), so the compute waves always idle 16 states before anything reads acc.
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #ifdef ICKA_GEMM_STAMP
         ph2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -856,14 +902,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         for (int mi = 0; mi < 4; ++mi) {
             const int row = wr + 16 * mi + (lane & 15);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < NTN; ++ni) {
                 const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
                 *reinterpret_cast<f32x4*>(smem + off_c(row, ch)) = acc[mi][ni] * g.alpha;
             }
         }
     }
     __syncthreads();
-    epilogue_rows<32>(g, smem, m0, n0, tid);
+    epilogue_rows<32, BNT / 8>(g, smem, m0, n0, tid);
 #ifdef ICKA_GEMM_STAMP
     if (g.stamp && lane == 0 && wave == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -874,21 +920,21 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL>(g, smem, blockIdx.x, gridDim.x);
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
 // tiles per CU one block's prologue (first DMA latency, ~2.8k cycles) and epilogue (~5.5k) overlap the other
 // block's main loop (stamps: at K = 768 they are 40 % of a tile's time).
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, int BNT = 128>
 __global__ __launch_bounds__(512, 4) void gemm_ws2_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, 2, 0, 1>(g, smem, blockIdx.x, gridDim.x);
+    gemm_ws_body<A_KM, B_KM, 2, 0, 1, BNT>(g, smem, blockIdx.x, gridDim.x);
 }
 
 template <bool A_KM, bool B_KM, int NBUF, int ABL>
@@ -920,6 +966,7 @@ __global__ __launch_bounds__(256) void gemm_dma_group_kernel(const GroupArgs ga)
 int g_abl = 0;
 unsigned long long* g_stamp = nullptr;
 int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
+int g_bn = 0;    // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced (icka_gemm_set_tile_n)
 int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
 
 __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) {
@@ -948,6 +995,21 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
 #endif
+                // Tile width: 128x96 tiles when they quantise better onto the 256 CUs (N = 768: 256 tiles instead of 192).
+                if (g.n96ok && g_bn != 128) {
+                    // measured (profiles/README.md): a 128x96 tile costs ~0.9-1.0 of a 128x128 one (the k-loop is bound
+                    // by LDS / L1 traffic of the A tile, not by MFMA count), so the narrow tile only pays where it turns
+                    // an under-filled single round into a full one
+                    const int nb96 = (g.M / BM) * (g.N / 96);
+                    if (g_bn == 96 || (nb < 256 && nb96 <= 256 && nb96 > nb)) {
+                        if ((g_ws == 2 || (g_ws == 1 && nb96 >= 448 && g.K <= 1024)) && !A_KM)
+                            hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 96>), dim3(nb96), dim3(512), 0, st, g);
+                        else
+                            hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
+                        ICKA_CHECK_LAUNCH();
+                        return 0;
+                    }
+                }
                 // measured (tools/gemm_bench.py): two co-resident blocks win only for short reductions on grids of
                 // >= ~2 tiles per CU (qkv, ffn-up, d-ffn-down); long-K shapes prefer the deeper ring of one block
                 if ((g_ws == 2 || (g_ws == 1 && nb >= 448 && g.K <= 1024)) && !A_KM)
@@ -1005,6 +1067,12 @@ extern "C" int icka_gemm_set_ablation(int mode) {
     return 0;
 }
 
+extern "C" int icka_gemm_set_tile_n(int bn) {
+    if (bn != 0 && bn != 96 && bn != 128) return ICKA_E_ARG;
+    g_bn = bn;
+    return 0;
+}
+
 extern "C" int icka_gemm_set_ring(int nbuf) {
     if (nbuf != 0 && (nbuf < 2 || nbuf > 4)) return ICKA_E_ARG;
     g_nbuf = nbuf;
@@ -1030,6 +1098,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.colsum = d->colsum_out;
     g.colsum_acc = d->colsum_accumulate;
     g.ksplit = 1;
+    g.n96ok = 0;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
     auto al = [](const void* p, int64_t ld, int64_t mod) {
@@ -1039,6 +1108,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
               al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
               al(d->bias, 4, 4) && al(d->bias2, 4, 4);
+    g.n96ok = aligned && d->N % 96 == 0;
     return 0;
 }
 

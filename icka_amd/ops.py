@@ -114,11 +114,11 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(H))
     dres = _empty(x, M, H)
     dao = _empty(x, M, H)
-    b_ln = A.grad_beta((so.LayerNorm.weight, so.LayerNorm.bias, so.dense.bias))
+    b_ln = A.grad_beta((so.LayerNorm.weight, so.LayerNorm.bias))
     K.ln_bwd(dy, xhat, rstd, so.LayerNorm.weight, dy2=dy2, dres=dres, dx=dao, dgamma=A.g(so.LayerNorm.weight),
-             dbeta=A.g(so.LayerNorm.bias), dbias=A.g(so.dense.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h,
-             accumulate=b_ln > 0)
-    _wgrad(A, dao, ctx, A.g(so.dense.weight), A.grad_beta(so.dense.weight))
+             dbeta=A.g(so.LayerNorm.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h, accumulate=b_ln > 0)
+    # the dense bias gradient (column sums of dao) rides on the weight-gradient GEMM
+    _wgrad(A, dao, ctx, A.g(so.dense.weight), A.grad_beta(so.dense.weight), bias=so.dense.bias)
     dctx = _empty(x, M, H)
     K.gemm(K.GEMM_NN, dao, A.w(so.dense.weight), dctx)
     delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
@@ -179,11 +179,10 @@ def _ffn_block_bwd(A: ParamArena, layer, x, d: Dims, saved, dy, dy2=None):
     ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(H))
     dres = _empty(x, M, H)
     dfo = _empty(x, M, H)
-    b_ln = A.grad_beta((out.LayerNorm.weight, out.LayerNorm.bias, out.dense.bias))
+    b_ln = A.grad_beta((out.LayerNorm.weight, out.LayerNorm.bias))
     K.ln_bwd(dy, xhat, rstd, out.LayerNorm.weight, dy2=dy2, dres=dres, dx=dfo, dgamma=A.g(out.LayerNorm.weight),
-             dbeta=A.g(out.LayerNorm.bias), dbias=A.g(out.dense.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h,
-             accumulate=b_ln > 0)
-    _wgrad(A, dfo, g, A.g(out.dense.weight), A.grad_beta(out.dense.weight))
+             dbeta=A.g(out.LayerNorm.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h, accumulate=b_ln > 0)
+    _wgrad(A, dfo, g, A.g(out.dense.weight), A.grad_beta(out.dense.weight), bias=out.dense.bias)
     dz = _empty(x, M, I)
     K.gemm(K.GEMM_NN, dfo, A.w(out.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)
     _wgrad(A, dz, x, A.g(inter.dense.weight), A.grad_beta(inter.dense.weight), bias=inter.dense.bias)

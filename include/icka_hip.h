@@ -71,6 +71,10 @@ int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream);
 /* Tuning knob of the aligned fast path: depth of the LDS-DMA ring (2: 64 KiB LDS, two blocks per CU; 3 / 4: 96 /
  * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  Default 4. */
 int icka_gemm_set_ring(int nbuf);
+/* Output-tile width of the warp-specialised fast path: 0 (default) = per-shape choice between 128x128 and 128x96
+ * tiles (the narrower tile when it quantises better onto the 256 CUs: N = 768 gives 256 tiles instead of 192),
+ * 128 / 96 = forced where applicable (96 needs N % 96 == 0 on top of the fast-path alignment). */
+int icka_gemm_set_tile_n(int bn);
 /* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
 int icka_gemm_set_ablation(int mode);
 /* 1 (default): 512-thread warp-specialised fast path (4 loader + 4 compute waves); 0: 256-thread single-role path. */

@@ -127,6 +127,38 @@ def test_gemm_epilogues_and_dual_k():
     assert rel_err(o, 0.5 * (A.float() @ B.float().t()) + 1.0) < 1e-2
 
 
+@pytest.mark.parametrize("tile_n", [96, 128])
+@pytest.mark.parametrize("M,N,K", [(128, 384, 64), (4096, 768, 768), (512, 2304, 768), (256, 768, 3072)])
+def test_gemm_tile_widths(M, N, K, tile_n, request):
+    """128x96 and 128x128 output tiles of the warp-specialised path, all three layouts, fused epilogues."""
+    k = _k()
+    from icka_amd import _lib
+    lib = _lib.load()
+    assert lib.icka_gemm_set_tile_n(tile_n) == 0
+    request.addfinalizer(lambda: lib.icka_gemm_set_tile_n(0))
+    A, Bt, Bn = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5), rnd(K, N, seed=3, scale=0.5)
+    bias, aux = rnd(N, seed=4, dtype=F32), rnd(M, N, seed=5)
+    acc = A.float() @ Bt.float().t() + bias
+    g = torch.empty(M, N, dtype=BF16, device="cuda"); z = torch.empty_like(g)
+    k.gemm(k.GEMM_NT, A, Bt, g, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    assert rel_err(z, acc) < 1e-2 and rel_err(g, torch.nn.functional.gelu(acc)) < 1e-2
+    of = torch.full((M, N), 1.0, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NT, A, Bt, of, beta=1.0)
+    assert rel_err(of, A.float() @ Bt.float().t() + 1.0) < 1e-4
+    o = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(k.GEMM_NN, A, Bn, o, epilogue=k.EPI_ADD, aux=aux)
+    assert rel_err(o, A.float() @ Bn.float() + aux.float()) < 1e-2
+    k.gemm(k.GEMM_NN, A, Bn, of)
+    assert rel_err(of, A.float() @ Bn.float()) < 1e-4
+    # TN: dW[M2, N] = At^T . X  with the fused column sums (bias gradient) of At
+    At, X = rnd(K, 256, seed=6), rnd(K, N, seed=7)
+    dw = torch.full((256, N), 0.5, dtype=F32, device="cuda")
+    cs = torch.zeros(256, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_TN, At, X, dw, beta=1.0, colsum_out=cs)
+    assert rel_err(dw, At.float().t() @ X.float() + 0.5) < 1e-4
+    assert rel_err(cs, At.float().sum(0)) < 1e-4
+
+
 def test_gemm_grouped_matches_individual_launches():
     """The four weight-gradient GEMMs of a layer in one launch (+ a ragged one that falls back)."""
     k = _k()
