@@ -144,11 +144,11 @@ __device__ __forceinline__ void flush_columns(float (&acc)[NS][NCH][8], float* l
 // dbias) are a separate pass (ln_cols_kernel): fusing them here forced either few waves (latency-bound rows) or a
 // per-block flush of 3*H partial sums that cost more than the rows themselves (measured 28 -> 56 us at 1024 blocks).
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
+__device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int nblk) {
     LnBwdArgs a = a_;
     a.drop = drop_resolve(a.drop);
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int wid = blk * 4 + (threadIdx.x >> 6), nw = nblk * 4;
     const int nchunk = a.H >> 3;
     const float inv_h = 1.f / (float)a.H;
     for (int row = wid; row < a.M; row += nw) {
@@ -198,25 +198,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
     }
 }
 
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+    ln_rows_body<NCH>(a, blockIdx.x, gridDim.x);
+}
+
 // Column part: slab[g][0] = sum_rows dy*xhat, slab[g][1] = sum_rows dy, slab[g][2] = sum_rows dx (if dx), over the
 // rows of group g.  Block = 32 chunk-lanes (256 columns) x 8 row-lanes; 16-byte loads, consecutive lanes on
 // consecutive chunks.
 constexpr int COL_GROUPS = 128;
-__global__ __launch_bounds__(256) void ln_cols_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
-                                                      const bf16_t* __restrict__ dy2, int64_t lddy2,
-                                                      const bf16_t* __restrict__ xhat, const bf16_t* __restrict__ dx,
-                                                      int64_t lddx, float* __restrict__ partials, int M, int H,
-                                                      int rows_per_group) {
+__device__ __forceinline__ void ln_cols_body(const bf16_t* __restrict__ dy, int64_t lddy,
+                                             const bf16_t* __restrict__ dy2, int64_t lddy2,
+                                             const bf16_t* __restrict__ xhat, const bf16_t* __restrict__ dx,
+                                             int64_t lddx, float* __restrict__ partials, int M, int H,
+                                             int rows_per_group, int bx, int by) {
     __shared__ float red[3][8][32][8];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int col = (blockIdx.x * 32 + cx) * 8;
-    const int r0 = blockIdx.y * rows_per_group;
+    const int col = (bx * 32 + cx) * 8;
+    const int r0 = by * rows_per_group;
     int r1 = r0 + rows_per_group; r1 = r1 > M ? M : r1;
     float ag[8], ab[8], ax[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; ax[e] = 0.f; }
     if (col < H) {
-        for (int r = r0 + ry; r < r1; r += 8) {
+#pragma unroll 4
+        for (int r = r0 + ry; r < r1; r += 8) {   // unrolled: 4 rows of independent 16-byte loads in flight per thread
             float d[8], x[8];
             load8(dy + (int64_t)r * lddy + col, d);
             if (dy2) {
@@ -240,14 +246,40 @@ __global__ __launch_bounds__(256) void ln_cols_kernel(const bf16_t* __restrict__
     __syncthreads();
     // 3 slots x 256 columns = 768 sums per block, 3 per thread
     for (int i = threadIdx.x; i < 3 * 256; i += 256) {
-        const int slot = i >> 8, cc = i & 255, c = blockIdx.x * 256 + cc;
+        const int slot = i >> 8, cc = i & 255, c = bx * 256 + cc;
         if (c < H) {
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) t += red[slot][k][cc >> 3][cc & 7];
-            partials[((int64_t)blockIdx.y * SLOTS + slot) * H + c] = t;
+            partials[((int64_t)by * SLOTS + slot) * H + c] = t;
         }
     }
+}
+__global__ __launch_bounds__(256) void ln_cols_kernel(const bf16_t* __restrict__ dy, int64_t lddy,
+                                                      const bf16_t* __restrict__ dy2, int64_t lddy2,
+                                                      const bf16_t* __restrict__ xhat, const bf16_t* __restrict__ dx,
+                                                      int64_t lddx, float* __restrict__ partials, int M, int H,
+                                                      int rows_per_group) {
+    ln_cols_body(dy, lddy, dy2, lddy2, xhat, dx, lddx, partials, M, H, rows_per_group, blockIdx.x, blockIdx.y);
+}
+
+// Rows and columns of the LayerNorm backward in ONE launch (no dbias: the dense bias gradient rides on the
+// weight-gradient GEMM): blocks [0, nx*groups) reduce columns into slabs, the rest stream rows.  The two halves are
+// independent, so they share the machine instead of queueing behind each other; the slabs are summed by the finalize
+// launch.  (A "last block sums the slabs" variant was measured and dropped: its device-scope release fences write the
+// whole L2 back on a multi-XCD part -- 23-36 us per call against 20 us for three separate launches.)
+struct LnColsArgs {
+    int nx, groups, rows_per_group;
+};
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const LnBwdArgs a, const LnColsArgs c) {
+    const int ncol = c.nx * c.groups;
+    if ((int)blockIdx.x >= ncol) {
+        ln_rows_body<NCH>(a, blockIdx.x - ncol, gridDim.x - ncol);
+        return;
+    }
+    ln_cols_body(a.dy, a.lddy, a.dy2, a.lddy2, a.xhat, nullptr, 0, a.partials, a.M, a.H, c.rows_per_group,
+                 blockIdx.x % c.nx, blockIdx.x / c.nx);
 }
 
 // out[slot][c] (+)= sum over slabs.  Block = 64 columns x 16 slab-lanes: the slab loop is split 16 ways and combined
@@ -477,11 +509,27 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
     LnBwdArgs a{(const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2, (const bf16_t*)xhat, rstd, gamma,
                 (bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partials, M, H, make_drop(p_drop, seed)};
     hipStream_t st = (hipStream_t)stream;
+    int groups = (M + 31) / 32; groups = groups > COL_GROUPS ? COL_GROUPS : groups;
+    const int rpg = (M + groups - 1) / groups;
+    const int nx = (H + 255) / 256;
+    if ((dgamma || dbeta) && !dbias) {
+        const LnColsArgs c{nx, groups, rpg};
+        const int grid = nx * groups + row_grid(M);
+        switch (pick_nch(H)) {
+            case 1: hipLaunchKernelGGL((ln_bwd_fused_kernel<1>), dim3(grid), dim3(256), 0, st, a, c); break;
+            case 2: hipLaunchKernelGGL((ln_bwd_fused_kernel<2>), dim3(grid), dim3(256), 0, st, a, c); break;
+            case 3: hipLaunchKernelGGL((ln_bwd_fused_kernel<3>), dim3(grid), dim3(256), 0, st, a, c); break;
+            default: hipLaunchKernelGGL((ln_bwd_fused_kernel<4>), dim3(grid), dim3(256), 0, st, a, c); break;
+        }
+        ICKA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(finalize_kernel, dim3((2 * H + 63) / 64), dim3(1024), 0, st, partials, groups, H, dgamma,
+                           dbeta, (float*)nullptr, (float*)nullptr, accumulate);   // slots 0, 1 only
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
     DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, row_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
     if (dgamma || dbeta || dbias) {
-        int groups = (M + 31) / 32; groups = groups > COL_GROUPS ? COL_GROUPS : groups;
-        const int rpg = (M + groups - 1) / groups;
         hipLaunchKernelGGL(ln_cols_kernel, dim3((H + 255) / 256, groups), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)dy2, lddy2, (const bf16_t*)xhat, dbias ? (const bf16_t*)dx : nullptr, lddx,
                            partials, M, H, rpg);

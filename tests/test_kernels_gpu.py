@@ -244,7 +244,19 @@ def test_ln_fwd_bwd(M, H, p):
     # accumulate semantics (+=) and the dy2 fan-in
     k.ln_bwd(dy, xhat, rstd, gamma, dy2=dy, dres=dres, dgamma=dg, dbeta=db, partials=ws, p_drop=p, seed=seed)
     assert rel_err(db, 3 * b2.grad) < 2e-2
+    assert rel_err(dg, 3 * gf.grad) < 2e-2
     assert rel_err(dres, 2 * rf.grad) < 2e-2
+    # single-launch form (no dbias): overwrite mode, repeated launches (its device ticket re-arms itself), bitwise
+    # reproducible column sums
+    outs = []
+    for _ in range(3):
+        g2, b3 = torch.full_like(dg, 7.0), torch.full_like(db, 7.0)
+        k.ln_bwd(dy, xhat, rstd, gamma, dres=dres, dx=dx, dgamma=g2, dbeta=b3, partials=ws, p_drop=p, seed=seed,
+                 accumulate=False)
+        outs.append((g2, b3))
+    assert rel_err(outs[0][0], gf.grad) < 2e-2 and rel_err(outs[0][1], b2.grad) < 2e-2
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert rel_err(dx, xf.grad) < 2e-2
 
 
 # ----------------------------------------------------------------------------------------------- attention
