@@ -179,3 +179,42 @@ def test_cpu_inputs_are_refused():
     b = case["batch"]
     with pytest.raises(TypeError):
         model(b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"], None, b["visual_embeds_att"])
+
+
+@pytest.mark.parametrize("layout,regions", [("BRC", 50), ("BCHW", 49)])
+def test_bert_large_geometry_against_live_oracle(layout, regions):
+    """BASELINE config c4 geometry (bert-large: H 1024, 16 heads, I 4096, seq 256, 50 regions) at 2 layers / batch 2:
+    exercises the tiled (Sq, Skv > 128) attention kernels, NCH=2 LayerNorm rows of 1024 and the 50-region
+    cross-attention; compared with the CPU oracle run on the same seeded weights and inputs."""
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    from oracle import mner_oracle as O
+    S, B = 256, 2
+    cfg = BertConfig(2048, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                     max_position_embeddings=512)
+    model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=regions, max_seq_length=S)
+    synth.fill_module_(model)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    b = synth.synthetic_batch(B, S, regions, vocab_size=2048, seed=11, layout=layout)
+    logits = _run(model, b, labels=False)
+    loss = _run(model, b, labels=True)
+    loss.backward()
+    ocfg = O.OracleConfig(vocab_size=2048, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
+                          intermediate_size=4096, max_position_embeddings=512)
+    ref = O.mner_logits(P, ocfg, b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
+                        b["visual_embeds_att"], 1, regions)
+    rloss = O.token_ce_loss(ref, b["labels"], b["input_mask"])
+    rloss.backward()
+    err = (logits.float().cpu() - ref.detach()).abs().max().item()
+    assert err < LOGIT_TOL, "logits max abs err %.3e" % err
+    assert abs(loss.item() - rloss.item()) < LOGIT_TOL
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        gr = P[k].grad
+        worst = max(worst, ((p.grad.float().cpu() - gr).norm() / (gr.norm() + 1e-4 * gmax)).item())
+    assert worst < 0.1, "worst relative gradient error %.3e" % worst
+    print("\n[c4 geometry %s R=%d] logits max abs err %.3e, worst grad rel err %.3e" % (layout, regions, err, worst))
