@@ -373,7 +373,27 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* base, int64_
     }
 }
 
-template <int QT, int KT, bool DROP>
+// FP8 (BASELINE config c5): QK^T and PV on the fp8 matrix cores (v_mfma_f32_16x16x32_fp8_fp8, OCP e4m3 on gfx950).
+// The bf16 fragments are converted in registers after the same LDS reads -- an fp8 fragment has the same lane layout
+// as the bf16 one (8 consecutive k per lane).  P is scaled by 2^8 before the conversion (probabilities live far below
+// e4m3's normal range: min normal 2^-6) and the accumulators are scaled back; softmax statistics stay fp32.
+__device__ __forceinline__ long fp8x8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(a4, a5, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(a6, a7, hi, true);
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ long fp8x8(const bf16x8& v) {
+    return fp8x8(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3]), bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]));
+}
+__device__ __forceinline__ f32x4 mfma16_fp8(long a, long b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+}
+constexpr float FP8_P_SCALE = 256.f;
+
+template <int QT, int KT, bool DROP, bool FP8 = false>
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) {
     AttnArgs a = a_;
     a.drop = drop_resolve(a.drop);
@@ -415,14 +435,21 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
         }
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi) {
-            f32x4 t = mfma16(k0, qf[qi][0], f32x4{0.f, 0.f, 0.f, 0.f});
-            t = mfma16(k1, qf[qi][1], t);
+            f32x4 t;
+            if constexpr (FP8) {
+                t = mfma16_fp8(fp8x8(k0), fp8x8(qf[qi][0]), f32x4{0.f, 0.f, 0.f, 0.f});
+                t = mfma16_fp8(fp8x8(k1), fp8x8(qf[qi][1]), t);
+            } else {
+                t = mfma16(k0, qf[qi][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                t = mfma16(k1, qf[qi][1], t);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = t[r] * a.scale + mk[r];
             s[qi][kt] = t;
         }
     }
     bf16x8 pf[QT][KT / 2];
+    long pf8[QT][KT / 2];
     float inv[QT];
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
@@ -447,10 +474,17 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
             }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
-        inv[qi] = 1.f / psum;
+        inv[qi] = (FP8 ? 1.f / FP8_P_SCALE : 1.f) / psum;
         if (g == 0 && a.lse && q < a.Sq) a.lse[(int64_t)bh * a.Sq + q] = mx + logf(psum);
 #pragma unroll
-        for (int ks = 0; ks < KT / 2; ++ks) pf[qi][ks] = pack8(s[qi][2 * ks], s[qi][2 * ks + 1]);
+        for (int ks = 0; ks < KT / 2; ++ks) {
+            if constexpr (FP8) {
+                const f32x4 lo = s[qi][2 * ks] * FP8_P_SCALE, hi = s[qi][2 * ks + 1] * FP8_P_SCALE;
+                pf8[qi][ks] = fp8x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+            } else {
+                pf[qi][ks] = pack8(s[qi][2 * ks], s[qi][2 * ks + 1]);
+            }
+        }
     }
     f32x4 acc[QT][4];
 #pragma unroll
@@ -462,8 +496,14 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
 #pragma unroll
         for (int ks = 0; ks < KT / 2; ++ks) {
             const bf16x8 vt = frag_tr(sV, dt, ks, lane);
+            if constexpr (FP8) {
+                const long v8 = fp8x8(vt);
 #pragma unroll
-            for (int qi = 0; qi < QT; ++qi) acc[qi][dt] = mfma16(vt, pf[qi][ks], acc[qi][dt]);
+                for (int qi = 0; qi < QT; ++qi) acc[qi][dt] = mfma16_fp8(v8, pf8[qi][ks], acc[qi][dt]);
+            } else {
+#pragma unroll
+                for (int qi = 0; qi < QT; ++qi) acc[qi][dt] = mfma16(vt, pf[qi][ks], acc[qi][dt]);
+            }
         }
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
@@ -652,23 +692,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
 }
 
 template <int QT, int KT, bool DROP>
-static void launch_small2(const AttnArgs& a, bool bwd, hipStream_t st) {
-    if (bwd) hipLaunchKernelGGL((attn_bwd_small_kernel<QT, KT, DROP>), dim3(a.B * a.h), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP>), dim3(a.B * a.h), dim3(256), 0, st, a);
+static void launch_small2(const AttnArgs& a, int mode, hipStream_t st) {
+    if (mode == 1) hipLaunchKernelGGL((attn_bwd_small_kernel<QT, KT, DROP>), dim3(a.B * a.h), dim3(256), 0, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true>), dim3(a.B * a.h), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, false>), dim3(a.B * a.h), dim3(256), 0, st, a);
 }
 template <int QT, int KT>
-static void launch_small(const AttnArgs& a, bool bwd, hipStream_t st) {
-    if (a.drop.thr) launch_small2<QT, KT, true>(a, bwd, st);
-    else launch_small2<QT, KT, false>(a, bwd, st);
+static void launch_small(const AttnArgs& a, int mode, hipStream_t st) {
+    if (a.drop.thr) launch_small2<QT, KT, true>(a, mode, st);
+    else launch_small2<QT, KT, false>(a, mode, st);
 }
-// whole-head path when the head fits (returns false -> caller uses the tiled kernels)
-static bool try_small(const AttnArgs& a, bool bwd, hipStream_t st) {
+// whole-head path when the head fits (returns false -> caller uses the tiled kernels).
+// mode 0: forward, 1: backward, 2: forward with fp8 QK^T / PV
+static bool try_small(const AttnArgs& a, int mode, hipStream_t st) {
     if (a.Sq > 128 || a.Skv > 128) return false;
     const bool q2 = a.Sq > 64, k8 = a.Skv > 64;
-    if (q2 && k8) launch_small<2, 8>(a, bwd, st);
-    else if (q2) launch_small<2, 4>(a, bwd, st);
-    else if (k8) launch_small<1, 8>(a, bwd, st);
-    else launch_small<1, 4>(a, bwd, st);
+    if (q2 && k8) launch_small<2, 8>(a, mode, st);
+    else if (q2) launch_small<2, 4>(a, mode, st);
+    else if (k8) launch_small<1, 8>(a, mode, st);
+    else launch_small<1, 4>(a, mode, st);
     return true;
 }
 
@@ -697,12 +739,28 @@ extern "C" int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
     a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
     a.mask = add_mask; a.Ow = (bf16_t*)O; a.ldo = ldo; a.lse = lse;
     a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
-    if (g_small && try_small(a, false, (hipStream_t)stream)) {
+    if (g_small && try_small(a, 0, (hipStream_t)stream)) {
         ICKA_CHECK_LAUNCH();
         return 0;
     }
     const int grid = B * heads * ((Sq + TILE - 1) / TILE);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                                 const float* add_mask, void* O, int64_t ldo, float* lse, int32_t B, int32_t heads,
+                                 int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream) {
+    if (!Q || !K || !V || !add_mask || !O) return ICKA_E_ARG;
+    if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0 || Sq > 128 || Skv > 128) return ICKA_E_SHAPE;
+    if ((int64_t)B * heads * Sq * Skv >= (1ll << 32)) return ICKA_E_SHAPE;
+    if (!ok16(Q, ldq) || !ok16(K, ldk) || !ok16(V, ldv) || !ok16(O, ldo)) return ICKA_E_ALIGN;
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+    a.mask = add_mask; a.Ow = (bf16_t*)O; a.ldo = ldo; a.lse = lse;
+    a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
+    try_small(a, 2, (hipStream_t)stream);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
@@ -728,7 +786,7 @@ extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
 #ifdef ICKA_ATTN_STAMP
     a.stamp = g_attn_stamp;
 #endif
-    if (g_small && try_small(a, true, st)) {
+    if (g_small && try_small(a, 1, st)) {
         ICKA_CHECK_LAUNCH();
         return 0;
     }

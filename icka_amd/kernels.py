@@ -225,16 +225,18 @@ def embed_bwd(dy, ids, token_type, xhat, rstd, gamma, dword, dpos, dtype_, dgamm
 
 
 # ------------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None):
-    """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection)."""
+def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False):
+    """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection).
+    fp8=True: QK^T and PV on the fp8 matrix cores (Sq, Skv <= 128 only)."""
     lib = _lib.load()
     for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         _mat(t, n)
     if scale is None:
         scale = 1.0 / math.sqrt(64.0)
-    check(lib.icka_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                            add_mask.data_ptr(), out.data_ptr(), out.stride(0), _ptr(lse), B, heads, Sq, Skv,
-                            scale, p_drop, seed, _stream()), "icka_attn_fwd")
+    fn = lib.icka_attn_fwd_fp8 if fp8 else lib.icka_attn_fwd
+    check(fn(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), add_mask.data_ptr(),
+             out.data_ptr(), out.stride(0), _ptr(lse), B, heads, Sq, Skv, scale, p_drop, seed, _stream()),
+          "icka_attn_fwd_fp8" if fp8 else "icka_attn_fwd")
     return out
 
 

@@ -201,7 +201,9 @@ class BertSelfAttention(nn.Module):
 
 
 class BertCoAttention(BertSelfAttention):
-    """Q from s1, K/V from s2 (:568-624)."""
+    """Q from s1, K/V from s2 (:568-624).  ``fp8_scores = True`` (BASELINE config c5, not a reference feature) computes
+    QK^T and PV of this co-attention on the fp8 matrix cores; requires s1/s2 lengths <= 128."""
+    fp8_scores = False
 
 
 class BertSelfOutput(nn.Module):
@@ -499,7 +501,7 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
     """
 
     def __init__(self, config, layer_num1=1, layer_num2=1, layer_num3=1, num_labels=2, regions=49, variant="cl",
-                 max_seq_length=128):
+                 max_seq_length=128, cross_attention_fp8=False):
         super().__init__(config)
         check_config(config)
         if variant not in ("cl", "gate_cl"):
@@ -511,6 +513,9 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.vismap2text = nn.Linear(2048, config.hidden_size)
         self.txt2img_attention = BertCrossEncoder(config, layer_num1)
+        if cross_attention_fp8:   # BASELINE config c5: fp8 QK^T / PV in the text->image co-attention
+            for layer in self.txt2img_attention.layer:
+                layer.attention.self.fp8_scores = True
         if variant == "gate_cl":
             # relevance score head: nn.Linear(hidden*2*128, 2) in the reference (gate_cl_modeling.py:1258); the
             # hard-coded 128 is the max_seq_length parameter here

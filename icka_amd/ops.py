@@ -92,7 +92,9 @@ def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv:
     ctx = _empty(x, M, H)
     lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
     seed_a = A.next_seed() if d.p_attn > 0 else 0
-    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
+    # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
+    fp8 = (not self_attn) and bool(getattr(sa, "fp8_scores", False))
+    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8)
     ao = _empty(x, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra bf16 rounding)
     K.gemm(K.GEMM_NT, ctx, A.w(so.dense.weight), ao)
     y = _empty(x, M, H)

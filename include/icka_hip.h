@@ -134,6 +134,12 @@ int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type
 int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const float* add_mask, void* O, int64_t ldo, float* lse, int32_t B, int32_t heads, int32_t Sq,
                   int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
+/* BASELINE config c5: the same forward with QK^T and PV on the fp8 matrix cores (OCP e4m3, fp32 accumulate; P is
+ * scaled by 2^8 into e4m3's normal range, softmax statistics stay fp32).  Whole-head shapes only (Sq, Skv <= 128: the
+ * text->image cross-attention); the backward is icka_attn_bwd (bf16 recomputation from the saved lse). */
+int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                      const float* add_mask, void* O, int64_t ldo, float* lse, int32_t B, int32_t heads, int32_t Sq,
+                      int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
 /* Heads with Sq <= 128 and Skv <= 128 (the reference's max_seq_length 128 and 36/49 regions) take the whole-head
  * kernels: one block per (batch, head), forward without online-softmax rescaling, backward (dQ, dK, dV, delta) in
  * one launch.  icka_attn_set_whole_head(0) forces the tiled flash-style kernels for every shape (default 1). */

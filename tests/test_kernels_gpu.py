@@ -424,3 +424,28 @@ def test_token_ce():
     assert count.item() == mask.sum().item()
     assert rel_err(dl[:, :Cn], lg.grad) < 1e-2
     assert dl[:, Cn:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("B,h,Sq,Skv,p", [(2, 12, 128, 36, 0.0), (2, 4, 128, 49, 0.1), (2, 2, 128, 128, 0.0),
+                                          (1, 2, 49, 128, 0.0)])
+def test_attention_fp8_forward(B, h, Sq, Skv, p):
+    """BASELINE config c5: QK^T / PV on the fp8 (e4m3) matrix cores; diff against fp32 and against the bf16 kernel."""
+    k = _k()
+    H = h * 64
+    q, kk, v = rnd(B * Sq, H, seed=1), rnd(B * Skv, H, seed=2), rnd(B * Skv, H, seed=3)
+    add_mask = torch.zeros(B, Skv, dtype=F32, device="cuda")
+    seed = 99
+    dmask = k.dropout_mask(B * h * Sq * Skv, p, seed, "cuda").view(B, h, Sq, Skv)
+    o8 = torch.empty(B * Sq, H, dtype=BF16, device="cuda"); o16 = torch.empty_like(o8)
+    l8 = torch.empty(B, h, Sq, dtype=F32, device="cuda"); l16 = torch.empty_like(l8)
+    k.attn_fwd(q, kk, v, add_mask, o8, l8, B, h, Sq, Skv, p_drop=p, seed=seed, fp8=True)
+    k.attn_fwd(q, kk, v, add_mask, o16, l16, B, h, Sq, Skv, p_drop=p, seed=seed)
+    oref, lref = _attn_ref(q.float(), kk.float(), v.float(), add_mask, dmask, B, h, Sq, Skv)
+    e8, e16 = rel_err(o8, oref), rel_err(o16, oref)
+    print("\n[fp8 attention %dx%d p=%.1f] max rel err vs fp32: fp8 %.3e, bf16 %.3e; lse abs err fp8 %.3e"
+          % (Sq, Skv, p, e8, e16, (l8 - lref).abs().max().item()))
+    assert e8 < 0.12 and e16 < 1.5e-2        # e4m3 carries 3 mantissa bits: ~6 % per element before averaging
+    assert (l8 - lref).abs().max().item() < 0.5
+    with pytest.raises(RuntimeError):
+        k.attn_fwd(rnd(200, 64), rnd(200, 64), rnd(200, 64), torch.zeros(1, 200, dtype=F32, device="cuda"),
+                   torch.empty(200, 64, dtype=BF16, device="cuda"), None, 1, 1, 200, 200, fp8=True)

@@ -218,3 +218,38 @@ def test_bert_large_geometry_against_live_oracle(layout, regions):
         worst = max(worst, ((p.grad.float().cpu() - gr).norm() / (gr.norm() + 1e-4 * gmax)).item())
     assert worst < 0.1, "worst relative gradient error %.3e" % worst
     print("\n[c4 geometry %s R=%d] logits max abs err %.3e, worst grad rel err %.3e" % (layout, regions, err, worst))
+
+
+def test_fp8_cross_attention_reference_diff_report():
+    """BASELINE config c5 (bert-base, seq 128, 36 regions, fp8 QK^T/PV in the cross-attention): logits of the fp8
+    variant against the fp32 CPU oracle and against the bf16 path, on the by-key seeded weights.  Reports the
+    differences; the fp8 variant must stay inside the bf16 tolerance budget of north_star on this workload."""
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    from oracle import mner_oracle as O
+    B, S, R, L = 4, 128, 36, 2
+    cfg = BertConfig(4096, hidden_size=768, num_hidden_layers=L, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=512)
+    outs = {}
+    for fp8 in (False, True):
+        model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=R,
+                                                     cross_attention_fp8=fp8)
+        synth.fill_module_(model)
+        P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model = model.cuda().eval()
+        b = synth.synthetic_batch(B, S, R, vocab_size=4096, seed=5)
+        outs[fp8] = _run(model, b, labels=False).float().cpu()
+        if fp8:   # the backward of the fp8 forward runs (bf16 recomputation) and gives finite gradients
+            _run(model, b, labels=True).backward()
+            assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    ocfg = O.OracleConfig(vocab_size=4096, hidden_size=768, num_hidden_layers=L, num_attention_heads=12,
+                          intermediate_size=3072, max_position_embeddings=512)
+    with torch.no_grad():
+        ref = O.mner_logits(P, ocfg, b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
+                            b["visual_embeds_att"], 1, R)
+    e16 = (outs[False] - ref).abs().max().item()
+    e8 = (outs[True] - ref).abs().max().item()
+    d = (outs[True] - outs[False]).abs().max().item()
+    print("\n[c5 fp8 cross-attention] max |dlogits| vs fp32 oracle: bf16 path %.3e, fp8 path %.3e; fp8 vs bf16 %.3e"
+          % (e16, e8, d))
+    assert e16 < LOGIT_TOL and e8 < 2.5 * LOGIT_TOL
