@@ -30,6 +30,7 @@ struct GemmArgs {
     int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
     float* colsum; int colsum_acc;  // TN fast path: colsum[m] (+)= sum_k A[k,m] (bias gradient fused into dW = dY^T.X)
     int n96ok;                  // fast path + N % 96 == 0: the 128x96 tile is an option
+    int direct;                 // plain outputs skip the LDS-staged epilogue (icka_gemm_set_direct_epilogue)
     unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
 };
@@ -667,6 +668,12 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, con
     epilogue_rows<16>(g, smem, m0, n0, tid);
 }
 
+__device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
+    // f32 outputs only: 16 B per lane.  bf16 outputs (8 B per lane, 32-byte row pieces) measured 5 % slower than the
+    // staged 16-byte row-contiguous stores (qkv projection, profiles/README.md)
+    return g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f;
+}
+
 // =====================================================================================================================
 // Warp-specialised fast path (512 threads): waves 0-3 COMPUTE (LDS fragment reads + MFMA, 64x64 each), waves 4-7 LOAD
 // (they only issue the LDS-DMA of the ring and wait for it).  In-kernel stamps of the 4-wave kernel showed a wave
@@ -887,6 +894,37 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         ph2 = __builtin_amdgcn_s_memtime();
 #endif
     }
+    // Plain f32 outputs (no activation / fan-in operand / accumulate: the GEMM -> LayerNorm intermediates) go straight
+    // from the accumulators to HBM: a lane owns 4 consecutive columns of one row (16 B) and the 4 lane groups of an
+    // MFMA tile cover 64 contiguous bytes per row; the stores of adjacent tiles merge in L2.  This skips two block barriers and
+    // 128 KB of LDS traffic of the staged epilogue below, and the loader waves retire at once.
+    if (g_direct_epilogue(g)) {
+        if (wave < 4) {
+            if (do_cs && lane < 16) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    float* p = g.colsum + m0 + wr + 16 * mi + lane;
+                    *p = g.colsum_acc ? *p + cs[mi][0] : cs[mi][0];
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NTN; ++ni) {
+                const int n = n0 + wc + 16 * ni + 4 * (lane >> 4);
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (g.bias2) b4 += *reinterpret_cast<const f32x4*>(g.bias2 + n);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int m = m0 + wr + 16 * mi + (lane & 15);
+                    const f32x4 v = acc[mi][ni] * g.alpha + b4;
+                    if (g.c_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = v;
+                    else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) =
+                             pack4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        return;
+    }
     __syncthreads();  // every wave is done with the operand ring before it is reused as the C tile
 
     if (do_cs && lane < 16) {
@@ -966,6 +1004,7 @@ __global__ __launch_bounds__(256) void gemm_dma_group_kernel(const GroupArgs ga)
 int g_abl = 0;
 unsigned long long* g_stamp = nullptr;
 int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
+int g_direct = 1;  // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
 int g_bn = 0;    // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced (icka_gemm_set_tile_n)
 int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
 
@@ -1067,6 +1106,11 @@ extern "C" int icka_gemm_set_ablation(int mode) {
     return 0;
 }
 
+extern "C" int icka_gemm_set_direct_epilogue(int on) {
+    g_direct = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int icka_gemm_set_tile_n(int bn) {
     if (bn != 0 && bn != 96 && bn != 128) return ICKA_E_ARG;
     g_bn = bn;
@@ -1099,6 +1143,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.colsum_acc = d->colsum_accumulate;
     g.ksplit = 1;
     g.n96ok = 0;
+    g.direct = g_direct;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
     auto al = [](const void* p, int64_t ld, int64_t mod) {

@@ -75,6 +75,9 @@ int icka_gemm_set_ring(int nbuf);
  * tiles (the narrower tile when it quantises better onto the 256 CUs: N = 768 gives 256 tiles instead of 192),
  * 128 / 96 = forced where applicable (96 needs N % 96 == 0 on top of the fast-path alignment). */
 int icka_gemm_set_tile_n(int bn);
+/* 1 (default): f32 outputs without activation / fan-in operand / accumulate are stored straight from the MFMA
+ * accumulators; 0: every epilogue goes through the LDS C tile (16-byte row-contiguous stores). */
+int icka_gemm_set_direct_epilogue(int on);
 /* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
 int icka_gemm_set_ablation(int mode);
 /* 1 (default): 512-thread warp-specialised fast path (4 loader + 4 compute waves); 0: 256-thread single-role path. */

@@ -146,6 +146,13 @@ def test_gemm_tile_widths(M, N, K, tile_n, request):
     k.gemm(k.GEMM_NT, A, Bt, of, beta=1.0)
     assert rel_err(of, A.float() @ Bt.float().t() + 1.0) < 1e-4
     o = torch.empty(M, N, dtype=BF16, device="cuda")
+    for direct in (1, 0):   # plain outputs: straight from the accumulators, or through the LDS C tile
+        assert lib.icka_gemm_set_direct_epilogue(direct) == 0
+        k.gemm(k.GEMM_NT, A, Bt, o, bias=bias, alpha=0.5)
+        assert rel_err(o, 0.5 * (A.float() @ Bt.float().t()) + bias) < 1e-2
+        k.gemm(k.GEMM_NT, A, Bt, of, bias=bias)
+        assert rel_err(of, acc) < 1e-4
+    lib.icka_gemm_set_direct_epilogue(1)
     k.gemm(k.GEMM_NN, A, Bn, o, epilogue=k.EPI_ADD, aux=aux)
     assert rel_err(o, A.float() @ Bn.float() + aux.float()) < 1e-2
     k.gemm(k.GEMM_NN, A, Bn, of)
