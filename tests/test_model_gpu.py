@@ -253,3 +253,57 @@ def test_fp8_cross_attention_reference_diff_report():
     print("\n[c5 fp8 cross-attention] max |dlogits| vs fp32 oracle: bf16 path %.3e, fp8 path %.3e; fp8 vs bf16 %.3e"
           % (e16, e8, d))
     assert e16 < LOGIT_TOL and e8 < 2.5 * LOGIT_TOL
+
+
+def test_alignment_cross_encoder_single_query_token():
+    """the alignment cross-encoders (`cls_layer_Y`, Cross_Modal_Interaction_Module.py
+    :901, :981-989) call BertCrossEncoder with ONE query token per sample (the mapped CLIP feature, S_q = 1) attending
+    over the S text tokens under the ragged text mask.  Same kernels at a degenerate shape (M = B rows), forward and
+    backward, against the CPU oracle's cross_encoder."""
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import BertCrossEncoder
+    from oracle import mner_oracle as O
+    B, S, H = 6, 128, 256
+    cfg = BertConfig(512, hidden_size=H, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+                     max_position_embeddings=128)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cls_layer_Y = torch.nn.ModuleList([BertCrossEncoder(cfg, 1), BertCrossEncoder(cfg, 1)])
+
+    m = Holder()
+    synth.fill_module_(m)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    clip = torch.randn(B, 1, H, generator=g)
+    text = torch.randn(B, S, H, generator=g)
+    lens = torch.randint(S // 4, S + 1, (B,), generator=g)
+    mask01 = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ext = ((1.0 - mask01.float()) * -10000.0)[:, None, None, :]
+    c_gpu = clip.cuda().requires_grad_(True)
+    t_gpu = text.cuda().requires_grad_(True)
+    x = c_gpu
+    for enc in m.cls_layer_Y:
+        x = enc(x, t_gpu, ext.cuda())[-1]
+    assert tuple(x.shape) == (B, 1, H)
+    x.float().sum().backward()
+    ocfg = O.OracleConfig(vocab_size=512, hidden_size=H, num_hidden_layers=1, num_attention_heads=4,
+                          intermediate_size=512, max_position_embeddings=128)
+    c_ref = clip.clone().requires_grad_(True)
+    t_ref = text.clone().requires_grad_(True)
+    r = c_ref
+    for i in range(2):
+        r = O.cross_encoder(P, "cls_layer_Y.%d" % i, r, t_ref, ext, ocfg, 1, False)[-1]
+    r.sum().backward()
+    err = (x.detach().float().cpu() - r.detach()).abs().max().item()
+    assert err < 3e-2, err
+    for mine, ref in ((c_gpu.grad, c_ref.grad), (t_gpu.grad, t_ref.grad)):
+        assert ((mine.float().cpu() - ref).norm() / ref.norm()).item() < 5e-2
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        if P[k].grad is not None:
+            rel = ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item()
+            assert rel < 0.1, (k, rel)
+    print("\n[S_q=1 alignment encoders] max abs err %.3e" % err)
