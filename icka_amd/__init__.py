@@ -10,9 +10,10 @@ from .modeling import (BertAttention, BertCoAttention, BertCrossAttention, BertC
                        BertSelfOutput, MTCCMBertForMMTokenClassificationCRF, cls_layer_both, scalar_gate_fusion,
                        token_ce_loss)
 from .arena import ParamArena
+from .crf import CRF
 from .dp import GradReducer
 
-__all__ = ["BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
+__all__ = ["CRF", "BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
            "BertSelfEncoder", "BertCrossEncoder", "BertCrossAttentionLayer", "BertAttention", "BertCrossAttention",
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
            "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",

@@ -1,0 +1,270 @@
+// Linear-chain CRF on the emissions of the tagging head: log-likelihood, its gradient
+// and Viterbi decoding.  The reference calls the third-party package `torchcrf` (pytorch-crf, not vendored, un-pinned:
+// Cross_Modal_Interaction_Module.py:3, :911, :1045-1057; my_bert/cl_modeling.py:30, :1269, :1380-1386); the
+// semantics here follow that package's published algorithm (v0.7.2: CRF.forward / _compute_score /
+// _compute_normalizer / _viterbi_decode), restated for the tests in oracle/crf_oracle.py.
+//
+// Sequential over the S positions, tiny per step (C <= 64 tags, C x C transitions): ONE WAVE PER SAMPLE, tag j on
+// lane j, the running scores and the transition matrix in LDS.  fp32 throughout (log-sum-exp recursions).
+//   mask semantics of the package: step 0 is always on; at step t >= 1 the recursion advances only where mask[t] != 0
+//   (`torch.where(mask[i], next_score, score)`), the gold-path score adds transitions[tags[t-1], tags[t]] * mask[t],
+//   and the end transition is taken at position sum(mask) - 1.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CRF_MAX_SC = 12288;   // S * C floats of per-position scores kept in LDS by the gradient kernel (48 KiB)
+
+struct CrfArgs {
+    const float* e; int64_t ld_s;   // emissions [B, S, C]: element (b, t, j) at e[(b*S + t)*ld_s + j]
+    const int64_t* tags; const int64_t* mask;   // [B, S] (mask may be NULL = all on)
+    const float* start; const float* end; const float* trans;   // [C], [C], [C, C] (from, to)
+    float* llh;            // [B] log-likelihood of the gold path
+    const float* gllh;     // [B] upstream d loss / d llh (gradient kernel)
+    float* de; int64_t ld_ds;   // [B, S, C] gradient w.r.t. the emissions
+    float* dstart; float* dend; float* dtrans;   // accumulated (+=) with atomics over the samples
+    int64_t* best; float* best_score;   // Viterbi: [B, S] tags (-1 past the end), [B]
+    int B, S, C;
+};
+
+// gold tag, clamped into range (positions that are masked out may carry arbitrary pad labels)
+__device__ __forceinline__ int tag_at(const int64_t* tg, int t, int C) {
+    const int64_t y = tg[t];
+    return y < 0 ? 0 : (y >= C ? C - 1 : (int)y);
+}
+__device__ __forceinline__ bool on(const CrfArgs& a, int b, int t) {
+    return t == 0 || a.mask == nullptr || a.mask[(int64_t)b * a.S + t] != 0;
+}
+
+// log-sum-exp (or max) over i of  s_alpha[i] + s_T[i*C + j]  for this lane's tag j
+template <bool MAXONLY>
+__device__ __forceinline__ float reduce_from(const float* s_alpha, const float* s_T, int C, int j, int* arg) {
+    float m = -INFINITY;
+    int am = 0;
+    for (int i = 0; i < C; ++i) {
+        const float v = s_alpha[i] + s_T[i * C + j];
+        if (v > m) { m = v; am = i; }
+    }
+    if (MAXONLY) { *arg = am; return m; }
+    float s = 0.f;
+    for (int i = 0; i < C; ++i) s += __expf(s_alpha[i] + s_T[i * C + j] - m);
+    return m + __logf(s);
+}
+
+// gold-path score, lanes strided over the positions
+__device__ __forceinline__ float gold_score(const CrfArgs& a, int b, int lane) {
+    const int64_t* tg = a.tags + (int64_t)b * a.S;
+    float s = 0.f;
+    int cnt = 0;
+    for (int t = lane; t < a.S; t += 64) {
+        const bool act = on(a, b, t);
+        cnt += (a.mask == nullptr || a.mask[(int64_t)b * a.S + t] != 0) ? 1 : 0;
+        if (!act) continue;
+        const int y = tag_at(tg, t, a.C);
+        s += a.e[((int64_t)b * a.S + t) * a.ld_s + y];
+        s += t == 0 ? a.start[y] : a.trans[tag_at(tg, t - 1, a.C) * a.C + y];
+    }
+    s = wave_sum(s);
+    int len = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+    const int last = len > 0 ? len - 1 : 0;
+    return s + a.end[tag_at(tg, last, a.C)];
+}
+
+// ------------------------------------------------------------------------------------------------ log-likelihood
+__global__ __launch_bounds__(64) void crf_llh_kernel(const CrfArgs a) {
+    __shared__ float s_T[64 * 64];
+    __shared__ float s_alpha[64];
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C;
+    for (int i = j; i < C * C; i += 64) s_T[i] = a.trans[i];
+    const float num = gold_score(a, b, j);
+    const float* eb = a.e + (int64_t)b * a.S * a.ld_s;
+    float alpha = j < C ? a.start[j] + eb[j] : -INFINITY;
+    for (int t = 1; t < a.S; ++t) {
+        if (!on(a, b, t)) continue;   // wave-uniform
+        __syncthreads();   // block = one wave: orders the LDS exchange
+        if (j < C) s_alpha[j] = alpha;
+        __syncthreads();   // block = one wave: orders the LDS exchange
+        if (j < C) alpha = reduce_from<false>(s_alpha, s_T, C, j, nullptr) + eb[(int64_t)t * a.ld_s + j];
+    }
+    float v = j < C ? alpha + a.end[j] : -INFINITY;
+    const float m = wave_max(v);
+    const float z = m + __logf(wave_sum(j < C ? __expf(v - m) : 0.f));
+    if (j == 0) a.llh[b] = num - z;
+}
+
+// ------------------------------------------------------------------------------------------------------ gradient
+// d loss / d (emissions, start, end, transitions) = gllh[b] * d llh / d(.) with
+//   d llh / d e[t][j] = on(t) * (1[tags[t] = j] - P(y_t = j)),  pairwise marginals for the transitions.
+__global__ __launch_bounds__(64) void crf_grad_kernel(const CrfArgs a) {
+    __shared__ float s_T[64 * 64];
+    __shared__ float s_dT[64 * 64];
+    __shared__ float s_vec[64];
+    __shared__ float s_al[CRF_MAX_SC];   // alpha[t][j] after step t
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
+    for (int i = j; i < C * C; i += 64) { s_T[i] = a.trans[i]; s_dT[i] = 0.f; }
+    const float g = a.gllh[b];
+    const float* eb = a.e + (int64_t)b * S * a.ld_s;
+    const int64_t* tg = a.tags + (int64_t)b * S;
+    float* deb = a.de + (int64_t)b * S * a.ld_ds;
+
+    // forward recursion, every alpha kept
+    float alpha = j < C ? a.start[j] + eb[j] : -INFINITY;
+    if (j < C) s_al[j] = alpha;
+    int len = 1;
+    for (int t = 1; t < S; ++t) {
+        const bool act = on(a, b, t);
+        len += (a.mask == nullptr || a.mask[(int64_t)b * S + t] != 0) ? 1 : 0;
+        if (act) {
+            __syncthreads();   // block = one wave: orders the LDS exchange
+            if (j < C) alpha = reduce_from<false>(s_al + (t - 1) * C, s_T, C, j, nullptr) + eb[(int64_t)t * a.ld_s + j];
+        }
+        if (j < C) s_al[t * C + j] = alpha;
+    }
+    if (a.mask != nullptr && a.mask[(int64_t)b * S] == 0) len -= 1;   // (the package rejects this; stay consistent)
+    __syncthreads();   // block = one wave: orders the LDS exchange
+    float v = j < C ? alpha + a.end[j] : -INFINITY;
+    const float m = wave_max(v);
+    const float logz = m + __logf(wave_sum(j < C ? __expf(v - m) : 0.f));
+
+    // backward recursion: beta[j] belongs to the latest processed active step
+    float beta = j < C ? a.end[j] : -INFINITY;
+    float dend = j < C ? -__expf(v - logz) : 0.f;   // - P(y_last = j)
+    float dstart = 0.f;
+    for (int t = S - 1; t >= 0; --t) {
+        const bool act = on(a, b, t);
+        if (!act) {
+            if (j < C) deb[(int64_t)t * a.ld_ds + j] = 0.f;
+            continue;
+        }
+        const float et = j < C ? eb[(int64_t)t * a.ld_s + j] : 0.f;
+        const float marg = j < C ? __expf(s_al[t * C + j] + beta - logz) : 0.f;
+        const int y = tag_at(tg, t, C);
+        if (j < C) deb[(int64_t)t * a.ld_ds + j] = g * ((j == y ? 1.f : 0.f) - marg);
+        if (t == 0) { dstart = (j == y ? 1.f : 0.f) - marg; break; }
+        // pairwise marginals with the previous alpha, and the gold transition (literal previous position)
+        const float u = et + beta;   // e[t][j] + beta_t[j]
+        if (j < C) {
+            for (int i = 0; i < C; ++i)
+                s_dT[i * C + j] -= __expf(s_al[(t - 1) * C + i] + s_T[i * C + j] + u - logz);
+            if (j == y) s_dT[tag_at(tg, t - 1, C) * C + j] += 1.f;
+        }
+        // beta_{prev}[i] = logsumexp_j (T[i][j] + u[j]): lane i loops over j
+        __syncthreads();   // block = one wave: orders the LDS exchange
+        if (j < C) s_vec[j] = u;
+        __syncthreads();   // block = one wave: orders the LDS exchange
+        if (j < C) {
+            float mx = -INFINITY;
+            for (int k = 0; k < C; ++k) mx = fmaxf(mx, s_T[j * C + k] + s_vec[k]);
+            float s = 0.f;
+            for (int k = 0; k < C; ++k) s += __expf(s_T[j * C + k] + s_vec[k] - mx);
+            beta = mx + __logf(s);
+        }
+        __syncthreads();   // block = one wave: orders the LDS exchange
+    }
+    const int last = len > 0 ? len - 1 : 0;
+    if (j < C) {
+        if (j == tag_at(tg, last, C)) dend += 1.f;
+        atomicAdd(a.dstart + j, g * dstart);
+        atomicAdd(a.dend + j, g * dend);
+    }
+    __syncthreads();   // block = one wave: orders the LDS exchange
+    for (int i = j; i < C * C; i += 64) atomicAdd(a.dtrans + i, g * s_dT[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------- Viterbi
+__global__ __launch_bounds__(64) void crf_decode_kernel(const CrfArgs a) {
+    __shared__ float s_T[64 * 64];
+    __shared__ float s_alpha[64];
+    __shared__ unsigned char s_bp[CRF_MAX_SC];   // back-pointers [t][j]
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
+    for (int i = j; i < C * C; i += 64) s_T[i] = a.trans[i];
+    const float* eb = a.e + (int64_t)b * S * a.ld_s;
+    float score = j < C ? a.start[j] + eb[j] : -INFINITY;
+    int len = 1;
+    for (int t = 1; t < S; ++t) {
+        const bool act = on(a, b, t);
+        len += (a.mask == nullptr || a.mask[(int64_t)b * S + t] != 0) ? 1 : 0;
+        __syncthreads();   // block = one wave: orders the LDS exchange
+        if (j < C) s_alpha[j] = score;
+        __syncthreads();   // block = one wave: orders the LDS exchange
+        if (j < C) {
+            int arg = 0;
+            const float nx = reduce_from<true>(s_alpha, s_T, C, j, &arg) + eb[(int64_t)t * a.ld_s + j];
+            s_bp[t * C + j] = (unsigned char)arg;   // history is recorded for every step (as the package does)
+            if (act) score = nx;
+        }
+    }
+    __syncthreads();   // block = one wave: orders the LDS exchange
+    if (j < C) s_alpha[j] = score + a.end[j];
+    __syncthreads();   // block = one wave: orders the LDS exchange
+    if (j == 0) {
+        int bt = 0;
+        float bs = s_alpha[0];
+        for (int i = 1; i < C; ++i)
+            if (s_alpha[i] > bs) { bs = s_alpha[i]; bt = i; }
+        if (a.best_score) a.best_score[b] = bs;
+        int64_t* out = a.best + (int64_t)b * S;
+        const int last = len > 0 ? len - 1 : 0;
+        for (int t = last + 1; t < S; ++t) out[t] = -1;
+        out[last] = bt;
+        for (int t = last; t >= 1; --t) {   // history[:seq_end] reversed
+            bt = s_bp[t * C + bt];
+            out[t - 1] = bt;
+        }
+    }
+}
+
+inline int crf_check(const void* e, const void* start, const void* end, const void* trans, int B, int S, int C) {
+    if (!e || !start || !end || !trans) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || C <= 0 || C > 64) return ICKA_E_SHAPE;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int icka_crf_llh(const float* emissions, int64_t ld, const int64_t* tags, const int64_t* mask,
+                            const float* start, const float* end, const float* trans, float* llh, int32_t B,
+                            int32_t S, int32_t C, void* stream) {
+    if (int rc = crf_check(emissions, start, end, trans, B, S, C)) return rc;
+    if (!tags || !llh || ld < C) return ICKA_E_ARG;
+    CrfArgs a{};
+    a.e = emissions; a.ld_s = ld; a.tags = tags; a.mask = mask; a.start = start; a.end = end; a.trans = trans;
+    a.llh = llh; a.B = B; a.S = S; a.C = C;
+    hipLaunchKernelGGL(crf_llh_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_crf_grad(const float* emissions, int64_t ld, const int64_t* tags, const int64_t* mask,
+                             const float* start, const float* end, const float* trans, const float* gllh,
+                             float* d_emissions, int64_t ldd, float* d_start, float* d_end, float* d_trans, int32_t B,
+                             int32_t S, int32_t C, void* stream) {
+    if (int rc = crf_check(emissions, start, end, trans, B, S, C)) return rc;
+    if (!tags || !gllh || !d_emissions || !d_start || !d_end || !d_trans || ld < C || ldd < C) return ICKA_E_ARG;
+    if ((int64_t)S * C > CRF_MAX_SC) return ICKA_E_SHAPE;
+    CrfArgs a{};
+    a.e = emissions; a.ld_s = ld; a.tags = tags; a.mask = mask; a.start = start; a.end = end; a.trans = trans;
+    a.gllh = gllh; a.de = d_emissions; a.ld_ds = ldd; a.dstart = d_start; a.dend = d_end; a.dtrans = d_trans;
+    a.B = B; a.S = S; a.C = C;
+    hipLaunchKernelGGL(crf_grad_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_crf_decode(const float* emissions, int64_t ld, const int64_t* mask, const float* start,
+                               const float* end, const float* trans, int64_t* best_tags, float* best_score, int32_t B,
+                               int32_t S, int32_t C, void* stream) {
+    if (int rc = crf_check(emissions, start, end, trans, B, S, C)) return rc;
+    if (!best_tags || ld < C) return ICKA_E_ARG;
+    if ((int64_t)S * C > CRF_MAX_SC) return ICKA_E_SHAPE;
+    CrfArgs a{};
+    a.e = emissions; a.ld_s = ld; a.mask = mask; a.start = start; a.end = end; a.trans = trans;
+    a.best = best_tags; a.best_score = best_score; a.B = B; a.S = S; a.C = C;
+    hipLaunchKernelGGL(crf_decode_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}

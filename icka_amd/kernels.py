@@ -259,6 +259,56 @@ def attn_set_whole_head(on: bool) -> None:
     _lib.load().icka_attn_set_whole_head(int(bool(on)))
 
 
+# ------------------------------------------------------------------------------------------------- CRF
+def _crf_check(emissions, start, end, trans):
+    for n, t in (("emissions", emissions), ("start", start), ("end", end), ("trans", trans)):
+        _dev(t, n)
+        if t.dtype != F32 or not t.is_contiguous():
+            raise ValueError("%s must be contiguous f32" % n)
+    if emissions.dim() != 3:
+        raise ValueError("emissions must be [B,S,C]")
+    B, S, Cn = emissions.shape
+    if start.numel() != Cn or end.numel() != Cn or tuple(trans.shape) != (Cn, Cn):
+        raise ValueError("transition parameters do not match num_tags = %d" % Cn)
+    return B, S, Cn
+
+
+def _i64(t, name, shape):
+    if t is None:
+        return None
+    _dev(t, name)
+    if t.dtype != torch.int64 or tuple(t.shape) != shape or not t.is_contiguous():
+        raise ValueError("%s must be contiguous int64 %s" % (name, shape))
+    return t
+
+
+def crf_llh(emissions, tags, mask, start, end, trans, llh):
+    B, S, Cn = _crf_check(emissions, start, end, trans)
+    _i64(tags, "tags", (B, S)); _i64(mask, "mask", (B, S))
+    check(_lib.load().icka_crf_llh(emissions.data_ptr(), Cn, tags.data_ptr(), _ptr(mask), start.data_ptr(),
+                                   end.data_ptr(), trans.data_ptr(), llh.data_ptr(), B, S, Cn, _stream()),
+          "icka_crf_llh")
+    return llh
+
+
+def crf_grad(emissions, tags, mask, start, end, trans, gllh, d_emissions, d_start, d_end, d_trans):
+    B, S, Cn = _crf_check(emissions, start, end, trans)
+    _i64(tags, "tags", (B, S)); _i64(mask, "mask", (B, S))
+    check(_lib.load().icka_crf_grad(emissions.data_ptr(), Cn, tags.data_ptr(), _ptr(mask), start.data_ptr(),
+                                    end.data_ptr(), trans.data_ptr(), gllh.data_ptr(), d_emissions.data_ptr(), Cn,
+                                    d_start.data_ptr(), d_end.data_ptr(), d_trans.data_ptr(), B, S, Cn, _stream()),
+          "icka_crf_grad")
+
+
+def crf_decode(emissions, mask, start, end, trans, best_tags, best_score=None):
+    B, S, Cn = _crf_check(emissions, start, end, trans)
+    _i64(mask, "mask", (B, S)); _i64(best_tags, "best_tags", (B, S))
+    check(_lib.load().icka_crf_decode(emissions.data_ptr(), Cn, _ptr(mask), start.data_ptr(), end.data_ptr(),
+                                      trans.data_ptr(), best_tags.data_ptr(), _ptr(best_score), B, S, Cn, _stream()),
+          "icka_crf_decode")
+    return best_tags
+
+
 # ------------------------------------------------------------------------------------------------- helpers
 def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     _dev(src, "src"); _dev(dst, "dst")

@@ -211,6 +211,24 @@ int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const 
 int icka_scale_by_ratio(const void* x, void* y, const float* num, const float* den, int64_t n, void* stream);
 /* out[0] = num[0] / max(den[0], 1)   (mean loss from the two accumulators of icka_token_ce). */
 int icka_scalar_ratio(float* out, const float* num, const float* den, void* stream);
+/* ---------------------------------------------------------------------------------------------------------------
+ * Linear-chain CRF over the per-token emissions.  The reference calls the third-party
+ * `torchcrf.CRF(num_tags, batch_first=True)` (Cross_Modal_Interaction_Module.py:911, :1045-1057;
+ * my_bert/cl_modeling.py:1269, :1380-1386); these entry points follow that package's algorithm (pytorch-crf 0.7.2).
+ * emissions f32 [B,S,C] (row stride ld >= C), tags / mask int64 [B,S] (mask NULL = all on; step 0 is always on),
+ * start/end f32 [C], trans f32 [C,C] (from, to).  C <= 64; one wave per sample.
+ *   icka_crf_llh   : llh[b] = score(gold path) - log Z
+ *   icka_crf_grad  : d_emissions[b,t,:] = gllh[b] * d llh / d e  (written), d_start / d_end / d_trans += (atomics)
+ *   icka_crf_decode: Viterbi path per sample, best_tags [B,S] (-1 past sum(mask)), best_score [B] (nullable)
+ * icka_crf_grad and icka_crf_decode keep S*C values per sample in LDS: S*C <= 12288. */
+int icka_crf_llh(const float* emissions, int64_t ld, const int64_t* tags, const int64_t* mask, const float* start,
+                 const float* end, const float* trans, float* llh, int32_t B, int32_t S, int32_t C, void* stream);
+int icka_crf_grad(const float* emissions, int64_t ld, const int64_t* tags, const int64_t* mask, const float* start,
+                  const float* end, const float* trans, const float* gllh, float* d_emissions, int64_t ldd,
+                  float* d_start, float* d_end, float* d_trans, int32_t B, int32_t S, int32_t C, void* stream);
+int icka_crf_decode(const float* emissions, int64_t ld, const int64_t* mask, const float* start, const float* end,
+                    const float* trans, int64_t* best_tags, float* best_score, int32_t B, int32_t S, int32_t C,
+                    void* stream);
 /* Dropout nonce for hipGraph replay.  Every dropout-bearing kernel XORs two DEVICE words into its (by-value) seed at
  * entry when a nonce is registered.  A captured graph re-launches the same seed values, so the graph also captures
  * icka_bump_dropout_nonce at the start of a step: each replay then draws fresh masks, and the forward and backward
