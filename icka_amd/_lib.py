@@ -61,6 +61,9 @@ PROTOTYPES = {
     "icka_attn_fwd_fp8": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_set_whole_head": (None, [c_i32]),
+    "icka_lstm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_lstm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_transpose_bf16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_crf_llh": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_crf_grad": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32,
                               c_i32, c_i32, c_vp]),

@@ -1,0 +1,225 @@
+// Bidirectional single-layer LSTM of the tagging tail:
+//   self.lstm = nn.LSTM(input_size=H, hidden_size=H, batch_first=True, bidirectional=True)
+//   x, _ = self.lstm(result); emissions = self.classifier(x)      (Cross_Modal_Interaction_Module.py:905-910, :1042-1043)
+// nn.LSTM is ATen, not reference code; semantics (gate order i, f, g, o; c' = f*c + i*g; h' = o*tanh(c')) follow
+// torch.nn.LSTM.
+//
+// The input projection of all S steps and both directions is ONE GEMM of the GEMM kernels ([B*S, H] x [H, 8H], the
+// reference hoists nothing: cuDNN/ATen does the same internally).  This file holds the sequential part: one launch per
+// time step (both directions in the launch, captured in the step's hipGraph), a block per 16 hidden units:
+//   forward : G = h_{t-1} . W_hh^T for its 4 x 16 gate columns on the MFMA (one gate per wave, operands straight from
+//             L2 -- the 4H x H recurrent matrix is 4.7 MB and stays L2-resident), then the cell update for its units.
+//   backward: dh_rec = dgates_{t+1} . W_hh for its 16 units (K = 4H split over the 4 waves), then the gate
+//             derivatives of step t.  The weight / input gradients are GEMMs over all steps after the loop.
+// The state lives in the saved tensors: h_{t-1} is read from the output y, c_{t-1} from c_all.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+struct LstmArgs {
+    const float* gx; int64_t ldg;      // input projection + both biases, f32 [B*S, 8H]: col = dir*4H + gate*H + unit
+    const bf16_t* whh;                 // forward: [2][4H][H] (gate-row, k contiguous); backward: W_hh^T [2][H][4H]
+    bf16_t* y;                         // [B, S, 2H] hidden states (= LSTM output), col = dir*H + unit
+    float* c_all;                      // [B, S, 2, H] cell states
+    bf16_t* act;                       // [B, S, 2, 4H] gate activations i, f, g, o
+    bf16_t* hprev;                     // [B, S, 2H] h_{t-1} of every step (operand of the dW_hh GEMM), may be NULL
+    const bf16_t* dy;                  // [B, S, 2H] gradient of the output
+    bf16_t* dgates;                    // [B*S, 8H] gate pre-activation gradients
+    float* dc_carry;                   // [2, B, H] dc_{t+1} * f_{t+1}
+    int B, S, H, step;
+};
+
+// 16-byte fragment of a k-contiguous row (8 bf16); zero when the row is invalid
+__device__ __forceinline__ bf16x8 frag16(const bf16_t* row, bool ok) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ok) v = *reinterpret_cast<const u32x4*>(row);
+    return as_bf16x8(v);
+}
+
+constexpr int MAX_RT = 4;   // batch row tiles of 16 (B <= 64 per launch)
+
+// ---------------------------------------------------------------------------------------------------- forward step
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a) {
+    __shared__ float s_g[4][MAX_RT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
+    const int tt = d == 0 ? a.step : S - 1 - a.step;        // time index of this step
+    const int tp = d == 0 ? tt - 1 : tt + 1;                // time index of the previous step of this direction
+    const bool first = a.step == 0;
+    const int nrt = (a.B + 15) >> 4;
+    const int i15 = lane & 15, g4 = lane >> 4;
+
+    f32x4 acc[MAX_RT];
+#pragma unroll
+    for (int r = 0; r < MAX_RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+        // wave = gate: rows (wave*H + u0 + i15) of W_hh[d], against h_{t-1} rows b
+        const bf16_t* wrow = a.whh + ((int64_t)d * 4 * H + (int64_t)wave * H + u0 + i15) * H + 8 * g4;
+        const bf16_t* hbase = a.y + (int64_t)tp * 2 * H + (int64_t)d * H + 8 * g4;
+        for (int k0 = 0; k0 < H; k0 += 32) {
+            const bf16x8 wf = frag16(wrow + k0, true);
+#pragma unroll
+            for (int r = 0; r < MAX_RT; ++r) {
+                if (r < nrt) {
+                    const int b = 16 * r + i15;
+                    const bf16x8 hf = frag16(hbase + (int64_t)b * S * 2 * H + k0, b < a.B);
+                    acc[r] = mfma16(wf, hf, acc[r]);   // D[i = unit 4*g4 + q][j = batch i15]
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MAX_RT; ++r)
+        if (r < nrt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_g[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
+    __syncthreads();
+    for (int p = tid; p < nrt * 256; p += 256) {
+        const int b = p >> 4, u = p & 15;
+        if (b >= a.B) continue;
+        const int64_t row = (int64_t)b * S + tt;
+        const float* gx = a.gx + row * a.ldg + (int64_t)d * 4 * H + u0 + u;
+        const float gi = sigmoid_f(s_g[0][b][u] + gx[0]);
+        const float gf = sigmoid_f(s_g[1][b][u] + gx[H]);
+        const float gg = tanhf(s_g[2][b][u] + gx[2 * H]);
+        const float go = sigmoid_f(s_g[3][b][u] + gx[3 * H]);
+        const float cp = first ? 0.f : a.c_all[(((int64_t)b * S + tp) * 2 + d) * H + u0 + u];
+        const float c = gf * cp + gi * gg;
+        const float h = go * tanhf(c);
+        a.c_all[(row * 2 + d) * H + u0 + u] = c;
+        a.y[row * 2 * H + (int64_t)d * H + u0 + u] = f2bf(h);
+        bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
+        act[0] = f2bf(gi); act[H] = f2bf(gf); act[2 * H] = f2bf(gg); act[3 * H] = f2bf(go);
+        if (a.hprev)
+            a.hprev[row * 2 * H + (int64_t)d * H + u0 + u] =
+                first ? f2bf(0.f) : a.y[((int64_t)b * S + tp) * 2 * H + (int64_t)d * H + u0 + u];
+    }
+}
+
+// --------------------------------------------------------------------------------------------------- backward step
+// a.step counts the forward steps; the launches run step = S-1 .. 0.
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a) {
+    __shared__ float s_p[4][MAX_RT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
+    const int tt = d == 0 ? a.step : S - 1 - a.step;
+    const int tp = d == 0 ? tt - 1 : tt + 1;                // previous forward step
+    const int tn = d == 0 ? tt + 1 : tt - 1;                // next forward step (its dgates are already computed)
+    const bool last = a.step == S - 1, first = a.step == 0;
+    const int nrt = (a.B + 15) >> 4;
+    const int i15 = lane & 15, g4 = lane >> 4;
+
+    f32x4 acc[MAX_RT];
+#pragma unroll
+    for (int r = 0; r < MAX_RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!last) {
+        // dh_rec[b][u] = sum_k dgates_next[b][k] * W_hh[k][u], k over 4H: wave w takes k in [w*H, (w+1)*H)
+        const bf16_t* wrow = a.whh + ((int64_t)d * H + u0 + i15) * 4 * H + (int64_t)wave * H + 8 * g4;   // W_hh^T rows
+        const bf16_t* gbase = a.dgates + (int64_t)tn * a.ldg + (int64_t)d * 4 * H + (int64_t)wave * H + 8 * g4;
+        for (int k0 = 0; k0 < H; k0 += 32) {
+            const bf16x8 wf = frag16(wrow + k0, true);
+#pragma unroll
+            for (int r = 0; r < MAX_RT; ++r) {
+                if (r < nrt) {
+                    const int b = 16 * r + i15;
+                    const bf16x8 gf = frag16(gbase + (int64_t)b * S * a.ldg + k0, b < a.B);
+                    acc[r] = mfma16(wf, gf, acc[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MAX_RT; ++r)
+        if (r < nrt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_p[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
+    __syncthreads();
+    for (int p = tid; p < nrt * 256; p += 256) {
+        const int b = p >> 4, u = p & 15;
+        if (b >= a.B) continue;
+        const int64_t row = (int64_t)b * S + tt;
+        const float dh = bf2f(a.dy[row * 2 * H + (int64_t)d * H + u0 + u]) +
+                         (s_p[0][b][u] + s_p[1][b][u] + s_p[2][b][u] + s_p[3][b][u]);
+        const bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
+        const float gi = bf2f(act[0]), gf = bf2f(act[H]), gg = bf2f(act[2 * H]), go = bf2f(act[3 * H]);
+        const float c = a.c_all[(row * 2 + d) * H + u0 + u];
+        const float cp = first ? 0.f : a.c_all[(((int64_t)b * S + tp) * 2 + d) * H + u0 + u];
+        const float tc = tanhf(c);
+        float* carry = a.dc_carry + ((int64_t)d * a.B + b) * H + u0 + u;
+        const float dc = dh * go * (1.f - tc * tc) + (last ? 0.f : *carry);
+        *carry = dc * gf;
+        bf16_t* dg = a.dgates + row * a.ldg + (int64_t)d * 4 * H + u0 + u;
+        dg[0] = f2bf(dc * gg * gi * (1.f - gi));
+        dg[H] = f2bf(dc * cp * gf * (1.f - gf));
+        dg[2 * H] = f2bf(dc * gi * (1.f - gg * gg));
+        dg[3 * H] = f2bf(dh * tc * go * (1.f - go));
+    }
+}
+
+// W^T for both directions: in [2][R][C] -> out [2][C][R] (bf16), 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
+                                                        int C) {
+    __shared__ bf16_t tile[32][33];
+    const int64_t base = (int64_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = in[base + (int64_t)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) out[base + (int64_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+inline int lstm_check(int B, int S, int H) {
+    if (B <= 0 || S <= 0 || H <= 0) return ICKA_E_SHAPE;
+    if (B > 16 * MAX_RT || H % 32 != 0) return ICKA_E_SHAPE;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh, void* y, float* c_all, void* act,
+                             void* hprev, int32_t B, int32_t S, int32_t H, void* stream) {
+    if (!gates_x || !w_hh || !y || !c_all || !act) return ICKA_E_ARG;
+    if (int rc = lstm_check(B, S, H)) return rc;
+    if (ldg < 8 * (int64_t)H) return ICKA_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(w_hh) | reinterpret_cast<uintptr_t>(y)) & 15) return ICKA_E_ALIGN;
+    LstmArgs a{};
+    a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
+    a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
+    for (int s = 0; s < S; ++s) {
+        a.step = s;
+        hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        ICKA_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const float* c_all, void* dgates,
+                             int64_t ldg, float* dc_carry, int32_t B, int32_t S, int32_t H, void* stream) {
+    if (!dy || !w_hh_t || !act || !c_all || !dgates || !dc_carry) return ICKA_E_ARG;
+    if (int rc = lstm_check(B, S, H)) return rc;
+    if (ldg < 8 * (int64_t)H || ldg % 8) return ICKA_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(w_hh_t) | reinterpret_cast<uintptr_t>(dgates)) & 15) return ICKA_E_ALIGN;
+    LstmArgs a{};
+    a.dy = (const bf16_t*)dy; a.whh = (const bf16_t*)w_hh_t; a.act = (bf16_t*)const_cast<void*>(act);
+    a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
+    a.B = B; a.S = S; a.H = H;
+    for (int s = S - 1; s >= 0; --s) {
+        a.step = s;
+        hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        ICKA_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int icka_transpose_bf16(const void* in, void* out, int32_t batch, int32_t R, int32_t C, void* stream) {
+    if (!in || !out) return ICKA_E_ARG;
+    if (batch <= 0 || R <= 0 || C <= 0) return ICKA_E_SHAPE;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (bf16_t*)out, R, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}

@@ -259,6 +259,43 @@ def attn_set_whole_head(on: bool) -> None:
     _lib.load().icka_attn_set_whole_head(int(bool(on)))
 
 
+# ------------------------------------------------------------------------------------------------- LSTM
+def lstm_fwd(gates_x, w_hh, y, c_all, act, hprev, B, S, H):
+    """gates_x f32 [B*S, 8H]; w_hh bf16 [8H, H] (= [2][4H][H]); y bf16 [B*S, 2H]; c_all f32 [B*S, 2H];
+    act bf16 [B*S, 8H]; hprev bf16 [B*S, 2H] or None."""
+    _dev(gates_x, "gates_x")
+    if gates_x.dtype != F32 or gates_x.stride(1) != 1 or tuple(gates_x.shape) != (B * S, 8 * H):
+        raise ValueError("gates_x must be f32 [B*S, 8H]")
+    for n, t, shp, dt in (("w_hh", w_hh, (8 * H, H), BF16), ("y", y, (B * S, 2 * H), BF16),
+                          ("c_all", c_all, (B * S, 2 * H), F32), ("act", act, (B * S, 8 * H), BF16)):
+        _dev(t, n)
+        if t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous():
+            raise ValueError("%s must be contiguous %s %s" % (n, dt, shp))
+    check(_lib.load().icka_lstm_fwd(gates_x.data_ptr(), gates_x.stride(0), w_hh.data_ptr(), y.data_ptr(),
+                                    c_all.data_ptr(), act.data_ptr(), _ptr(hprev), B, S, H, _stream()), "icka_lstm_fwd")
+
+
+def lstm_bwd(dy, w_hh_t, act, c_all, dgates, dc_carry, B, S, H):
+    for n, t, shp, dt in (("dy", dy, (B * S, 2 * H), BF16), ("w_hh_t", w_hh_t, (2 * H, 4 * H), BF16),
+                          ("act", act, (B * S, 8 * H), BF16), ("c_all", c_all, (B * S, 2 * H), F32),
+                          ("dgates", dgates, (B * S, 8 * H), BF16), ("dc_carry", dc_carry, (2 * B, H), F32)):
+        _dev(t, n)
+        if t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous():
+            raise ValueError("%s must be contiguous %s %s" % (n, dt, shp))
+    check(_lib.load().icka_lstm_bwd(dy.data_ptr(), w_hh_t.data_ptr(), act.data_ptr(), c_all.data_ptr(),
+                                    dgates.data_ptr(), dgates.stride(0), dc_carry.data_ptr(), B, S, H, _stream()),
+          "icka_lstm_bwd")
+
+
+def transpose_bf16(src, dst, batch, R, Cn):
+    _dev(src, "src"); _dev(dst, "dst")
+    if src.dtype != BF16 or dst.dtype != BF16 or src.numel() != batch * R * Cn or dst.numel() != src.numel() \
+            or not src.is_contiguous() or not dst.is_contiguous():
+        raise ValueError("transpose_bf16: contiguous bf16 [batch, R, C] -> [batch, C, R]")
+    check(_lib.load().icka_transpose_bf16(src.data_ptr(), dst.data_ptr(), batch, R, Cn, _stream()), "icka_transpose_bf16")
+    return dst
+
+
 # ------------------------------------------------------------------------------------------------- CRF
 def _crf_check(emissions, start, end, trans):
     for n, t in (("emissions", emissions), ("start", start), ("end", end), ("trans", trans)):

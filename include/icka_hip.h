@@ -229,6 +229,24 @@ int icka_crf_grad(const float* emissions, int64_t ld, const int64_t* tags, const
 int icka_crf_decode(const float* emissions, int64_t ld, const int64_t* mask, const float* start, const float* end,
                     const float* trans, int64_t* best_tags, float* best_score, int32_t B, int32_t S, int32_t C,
                     void* stream);
+/* ---------------------------------------------------------------------------------------------------------------
+ * Bidirectional single-layer LSTM of the tagging tail:
+ * nn.LSTM(H, H, batch_first=True, bidirectional=True) at Cross_Modal_Interaction_Module.py:905-908, called :1042
+ * (`x, _ = self.lstm(result)`).  Gate order i, f, g, o as torch.nn.LSTM.  The input projection (x . W_ih^T + b_ih +
+ * b_hh for both directions, f32 [B*S, 8H], column = dir*4H + gate*H + unit) is an icka_gemm; these entry points run
+ * the recurrence, one launch per time step (both directions per launch), B <= 64, H % 32 == 0.
+ *   icka_lstm_fwd: w_hh bf16 [2][4H][H]; writes y bf16 [B,S,2H] (h_t, the LSTM output), c_all f32 [B,S,2,H],
+ *                  act bf16 [B,S,2,4H] (gate activations) and optionally hprev bf16 [B,S,2H] (h_{t-1} per step: the
+ *                  operand of the dW_hh GEMM).
+ *   icka_lstm_bwd: dy bf16 [B,S,2H], w_hh_t = W_hh^T bf16 [2][H][4H] (icka_transpose_bf16); writes the gate
+ *                  pre-activation gradients dgates bf16 [B*S, ldg >= 8H]; dW_ih, dW_hh, db and dx are GEMMs / column
+ *                  sums over dgates afterwards.  dc_carry f32 [2,B,H] is workspace. */
+int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh, void* y, float* c_all, void* act, void* hprev,
+                  int32_t B, int32_t S, int32_t H, void* stream);
+int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const float* c_all, void* dgates, int64_t ldg,
+                  float* dc_carry, int32_t B, int32_t S, int32_t H, void* stream);
+/* out[b][c][r] = in[b][r][c] for bf16 matrices (batch of [R,C]). */
+int icka_transpose_bf16(const void* in, void* out, int32_t batch, int32_t R, int32_t C, void* stream);
 /* Dropout nonce for hipGraph replay.  Every dropout-bearing kernel XORs two DEVICE words into its (by-value) seed at
  * entry when a nonce is registered.  A captured graph re-launches the same seed values, so the graph also captures
  * icka_bump_dropout_nonce at the start of a step: each replay then draws fresh masks, and the forward and backward
