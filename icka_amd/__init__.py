@@ -11,9 +11,11 @@ from .modeling import (BertAttention, BertCoAttention, BertCrossAttention, BertC
                        token_ce_loss)
 from .arena import ParamArena
 from .crf import CRF
+from .lstm import BiLSTM
+from .modeling import MTCCMBertForMMTokenClassificationCRF_gate_1
 from .dp import GradReducer
 
-__all__ = ["CRF", "BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
+__all__ = ["CRF", "BiLSTM", "MTCCMBertForMMTokenClassificationCRF_gate_1", "BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
            "BertSelfEncoder", "BertCrossEncoder", "BertCrossAttentionLayer", "BertAttention", "BertCrossAttention",
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
            "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",

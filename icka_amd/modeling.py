@@ -485,6 +485,48 @@ class BertModel(BertPreTrainedModel):
         return encoded_layers, pooled_output
 
 
+def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_att):
+    """Shared trunk of the MNER heads: BERT text encoder -> dropout -> region tokens -> vismap2text -> text->image cross
+    encoder (cl_modeling.py:1341-1361 = Cross_Modal_Interaction_Module.py:949-969 / :2446-2466).  ``self`` provides
+    ``config, bert, vismap2text, txt2img_attention``.  Returns (arena, seq bf16 [B*S,H], its f32 twin or None,
+    cross bf16 [B*S,H], its f32 twin)."""
+    cfg = self.config
+    B, S = input_ids.shape
+    H = cfg.hidden_size
+    A = self._arena()
+    dev = input_ids.device
+    # ---- text encoder (cl_modeling.py:1341-1344)
+    sequence_output, _ = self.bert(input_ids, token_type_ids=segment_ids, attention_mask=input_mask,
+                                   output_all_encoded_layers=False)
+    seq = sequence_output.view(B * S, H)
+    seqf = _twin(sequence_output)
+    if self.training and cfg.hidden_dropout_prob > 0:
+        seq = ops.DropoutFn.apply(seq, A, float(cfg.hidden_dropout_prob))
+        seqf = None
+    # ---- region tokens + projection (:1348-1350)
+    v = visual_embeds_att
+    if not v.is_cuda:
+        raise TypeError("visual_embeds_att must be on a ROCm device")
+    if v.dim() == 4 or (v.dim() == 3 and v.shape[1] == 2048 and v.shape[2] != 2048):
+        R = v.shape[2] * v.shape[3] if v.dim() == 4 else v.shape[2]
+        layout = 1
+    else:
+        R, layout = v.shape[1], 0
+    tokens = torch.empty(B * R, 2048, dtype=BF16, device=dev)
+    K.regions_to_tokens(v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v, tokens, B, R,
+                        2048, layout)
+    vis = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE)
+    # ---- image mask (:1353-1356)
+    img_mask = K.additive_mask(added_attention_mask if added_attention_mask.dtype == torch.int64
+                               else added_attention_mask.long(), R, torch.empty(B, R, dtype=F32, device=dev))
+    # ---- cross encoder (:1359-1361)
+    cross, crossf = seq, seqf
+    d = _dims(cfg, B, S, R, self.training)
+    for layer in self.txt2img_attention.layer:
+        cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
+    return A, seq, seqf, cross, crossf
+
+
 class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
     """Gated multimodal token classifier (my_bert/cl_modeling.py:1252-1388; gate_cl_modeling.py:1248-1400).
 
@@ -535,37 +577,8 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         cfg = self.config
         B, S = input_ids.shape
         H = cfg.hidden_size
-        A = self._arena()
-        dev = input_ids.device
-        # ---- text encoder (cl_modeling.py:1341-1344)
-        sequence_output, _ = self.bert(input_ids, token_type_ids=segment_ids, attention_mask=input_mask,
-                                       output_all_encoded_layers=False)
-        seq = sequence_output.view(B * S, H)
-        seqf = _twin(sequence_output)
-        if self.training and cfg.hidden_dropout_prob > 0:
-            seq = ops.DropoutFn.apply(seq, A, float(cfg.hidden_dropout_prob))
-            seqf = None
-        # ---- region tokens + projection (:1348-1350)
-        v = visual_embeds_att
-        if not v.is_cuda:
-            raise TypeError("visual_embeds_att must be on a ROCm device")
-        if v.dim() == 4 or (v.dim() == 3 and v.shape[1] == 2048 and v.shape[2] != 2048):
-            R = v.shape[2] * v.shape[3] if v.dim() == 4 else v.shape[2]
-            layout = 1
-        else:
-            R, layout = v.shape[1], 0
-        tokens = torch.empty(B * R, 2048, dtype=BF16, device=dev)
-        K.regions_to_tokens(v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v, tokens, B, R,
-                            2048, layout)
-        vis = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE)
-        # ---- image mask (:1353-1356)
-        img_mask = K.additive_mask(added_attention_mask if added_attention_mask.dtype == torch.int64
-                                   else added_attention_mask.long(), R, torch.empty(B, R, dtype=F32, device=dev))
-        # ---- cross encoder (:1359-1361)
-        cross, crossf = seq, seqf
-        d = _dims(cfg, B, S, R, self.training)
-        for layer in self.txt2img_attention.layer:
-            cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
+        A, seq, seqf, cross, crossf = _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask,
+                                                  visual_embeds_att)
         if self.variant == "gate_cl":
             # P = softmax(crs_classifier(cat(seq, cross).view(B,-1)))[:, -1];  cross = P * cross   (:1364-1373)
             if self.crs_classifier.weight.shape[1] != 2 * H * S:
@@ -593,6 +606,68 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         A = getattr(self, "_icka_arena", None)
         if A is not None:
             A.begin_step()   # grads dropped -> the next backward overwrites the arena slots instead of accumulating
+
+
+class MTCCMBertForMMTokenClassificationCRF_gate_1(BertPreTrainedModel):
+    """the reference's simplest complete tagger
+    (Cross_Modal_Interaction_Module.py:2383-2483): trunk -> ``x, _ = self.lstm(cross_output_layer)`` ->
+    ``emissions = self.classifier(x)`` -> CRF loss (``reduction='token_mean'``) / Viterbi decode, selected by ``mode``.
+    Same forward signature; the arguments the reference's forward never reads (input_ids, segment_ids, input_mask,
+    clip_features, visual_embeds_mean, offsets, rela_score, ...) are accepted and ignored.  ``embedding`` may be an
+    icka ``BertModel`` (default: built from ``config``); the absent RoBERTa ``last_encoder`` is not used by this
+    class's forward and is kept only as an attribute."""
+
+    def __init__(self, config, embedding=None, last_encoder=None, layer_num1=1, layer_num2=1, layer_num3=1,
+                 num_labels=2):
+        super().__init__(config)
+        check_config(config)
+        from .crf import CRF
+        from .lstm import BiLSTM
+        self.num_labels = num_labels
+        self.last_encoder = last_encoder
+        self.bert = embedding if embedding is not None else BertModel(config)
+        self.hidden_size = config.hidden_size
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.vismap2text = nn.Linear(2048, config.hidden_size)
+        self.txt2img_attention = BertCrossEncoder(config, layer_num1)
+        self.lstm = BiLSTM(input_size=config.hidden_size, hidden_size=config.hidden_size, batch_first=True,
+                           bidirectional=True)
+        self.classifier = nn.Linear(config.hidden_size * 2, num_labels)
+        self.crf = CRF(num_tags=num_labels, batch_first=True)
+        if embedding is None:
+            self.apply(self.init_bert_weights)
+            self.lstm.reset_parameters()
+            self.crf.reset_parameters()
+
+    def emissions(self, ori_input_ids, ori_segment_ids, ori_input_mask, added_attention_mask, visual_embeds_att):
+        B, S = ori_input_ids.shape
+        A, _, _, cross, _ = _mner_trunk(self, ori_input_ids, ori_segment_ids, ori_input_mask, added_attention_mask,
+                                        visual_embeds_att)
+        x, _ = self.lstm(cross.view(B, S, self.hidden_size))
+        em = ops.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * self.hidden_size), self.classifier, A, True, K.EPI_NONE)
+        return em.view(B, S, self.num_labels)
+
+    def forward(self, input_ids, segment_ids, input_mask, ori_input_ids, ori_input_mask, ori_segment_ids,
+                added_attention_mask, clip_features=None, visual_embeds_mean=None, visual_embeds_att=None, offsets=None,
+                output_mask=None, rela_score=None, temp=None, temp_lamb=None, lamb=None, labels=None,
+                negative_rate=None, mode=None):
+        emissions = self.emissions(ori_input_ids, ori_segment_ids, ori_input_mask, added_attention_mask,
+                                   visual_embeds_att)
+        output_mask = (output_mask != 0)
+        if mode == "train":
+            return -self.crf(emissions, tags=labels, mask=output_mask, reduction="token_mean")
+        if mode == "dev":
+            pred_tags = self.crf.decode(emissions, mask=output_mask)
+            return pred_tags, -self.crf(emissions, tags=labels, mask=output_mask, reduction="token_mean")
+        if mode == "test":
+            return self.crf.decode(emissions, mask=output_mask)
+        return emissions
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        A = getattr(self, "_icka_arena", None)
+        if A is not None:
+            A.begin_step()
 
 
 def token_ce_loss(logits: torch.Tensor, labels: torch.Tensor, input_mask: torch.Tensor) -> torch.Tensor:

@@ -44,3 +44,64 @@ def test_bilstm_rejects_unsupported_configurations():
         m(torch.zeros(2, 3, 64))
     with pytest.raises(ValueError):
         m(torch.zeros(2, 3, 32, device="cuda"))
+
+
+def test_gate_1_tagger_end_to_end_against_oracle_composition():
+    """trunk -> BiLSTM -> classifier -> CRF (Cross_Modal_Interaction_Module.py:2383-2483, the `_gate_1` class): emissions,
+    token_mean CRF loss, gradients and decoded tags against the CPU composition of the trunk oracle, ATen's nn.LSTM and
+    the CRF oracle on the same by-key weights."""
+    import torch.nn.functional as F
+    from icka_amd import synth
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF_gate_1
+    from oracle import crf_oracle as OC
+    from oracle import mner_oracle as O
+    B, S, H, C = 4, 32, 128, 13
+    cfg = BertConfig(512, hidden_size=H, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=64)
+    model = MTCCMBertForMMTokenClassificationCRF_gate_1(cfg, num_labels=C)
+    synth.fill_module_(model)
+    with torch.no_grad():   # LSTM weights at their usual scale (by-key N(0, 0.02) would leave the gates linear)
+        for n, p in model.lstm.named_parameters():
+            p.mul_(4.0)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    b = synth.synthetic_batch(B, S, 49, vocab_size=512, seed=3, layout="BCHW")
+    g = {k: v.cuda() for k, v in b.items()}
+    args = dict(input_ids=g["input_ids"], segment_ids=g["segment_ids"], input_mask=g["input_mask"],
+                ori_input_ids=g["input_ids"], ori_input_mask=g["input_mask"], ori_segment_ids=g["segment_ids"],
+                added_attention_mask=g["added_attention_mask"], visual_embeds_att=g["visual_embeds_att"],
+                output_mask=g["input_mask"], labels=g["labels"])
+    em = model(**args)                       # mode=None -> emissions
+    loss = model(mode="train", **args)
+    loss.backward()
+    pred, dev_loss = model(mode="dev", **args)
+    assert abs(dev_loss.item() - loss.item()) < 1e-4
+    assert model(mode="test", **args) == pred
+    # ---- CPU composition
+    ocfg = O.OracleConfig(vocab_size=512, hidden_size=H, num_hidden_layers=2, num_attention_heads=2,
+                          intermediate_size=256, max_position_embeddings=64)
+    _, cross, _ = O.mner_trunk(P, ocfg, b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
+                            b["visual_embeds_att"], 1, 49, False)
+    lstm = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
+    lstm_sd = {k[len("lstm."):]: v for k, v in P.items() if k.startswith("lstm.")}
+    x, _ = torch.func.functional_call(lstm, lstm_sd, (cross,))
+    ref_em = F.linear(x, P["classifier.weight"], P["classifier.bias"])
+    mask = b["input_mask"].bool()
+    crfP = [P["crf.start_transitions"], P["crf.end_transitions"], P["crf.transitions"]]
+    rloss = -OC.crf_reduce(OC.crf_llh(ref_em, b["labels"], mask, *crfP), mask, "token_mean")
+    rloss.backward()
+    err = (em.float().cpu() - ref_em.detach()).abs().max().item()
+    assert err < 2e-2, err
+    assert abs(loss.item() - rloss.item()) < 2e-2 * max(1.0, abs(rloss.item()))
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        worst = max(worst, ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item())
+    assert worst < 0.1, worst
+    ref_pred = OC.crf_decode(em.float().cpu(), mask, *[p.detach() for p in crfP])
+    assert pred == ref_pred
+    print("\n[_gate_1 tagger] emissions max abs err %.3e, loss %.4f (oracle %.4f), worst grad rel err %.3e"
+          % (err, loss.item(), rloss.item(), worst))
