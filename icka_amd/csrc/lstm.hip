@@ -41,6 +41,7 @@ __device__ __forceinline__ bf16x8 frag16(const bf16_t* row, bool ok) {
 constexpr int MAX_RT = 4;   // batch row tiles of 16 (B <= 64 per launch)
 
 // ---------------------------------------------------------------------------------------------------- forward step
+template <int NRT, int UB>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a) {
     __shared__ float s_g[4][MAX_RT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,44 +49,63 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a) {
     const int tt = d == 0 ? a.step : S - 1 - a.step;        // time index of this step
     const int tp = d == 0 ? tt - 1 : tt + 1;                // time index of the previous step of this direction
     const bool first = a.step == 0;
-    const int nrt = (a.B + 15) >> 4;
     const int i15 = lane & 15, g4 = lane >> 4;
 
-    f32x4 acc[MAX_RT];
+    // operands of this thread's cell updates ((b, u) pairs p = tid + 256 i), fetched before the matrix part so their
+    // latency overlaps it
+    float gxr[NRT][4], cpr[NRT];
 #pragma unroll
-    for (int r = 0; r < MAX_RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NRT; ++i) {
+        const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+        const bool ok = b < a.B;
+        const float* gx = a.gx + ((int64_t)(ok ? b : 0) * S + tt) * a.ldg + (int64_t)d * 4 * H + u0 + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gxr[i][q] = gx[q * H];
+        cpr[i] = first ? 0.f : a.c_all[(((int64_t)(ok ? b : 0) * S + tp) * 2 + d) * H + u0 + u];
+    }
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!first) {
         // wave = gate: rows (wave*H + u0 + i15) of W_hh[d], against h_{t-1} rows b
         const bf16_t* wrow = a.whh + ((int64_t)d * 4 * H + (int64_t)wave * H + u0 + i15) * H + 8 * g4;
         const bf16_t* hbase = a.y + (int64_t)tp * 2 * H + (int64_t)d * H + 8 * g4;
-        for (int k0 = 0; k0 < H; k0 += 32) {
-            const bf16x8 wf = frag16(wrow + k0, true);
+        // UB k-steps (all 24 of H = 768 for B <= 32) of independent 16-byte loads are issued before their MFMAs: the
+        // operands come from L2 / Infinity Cache and every dependent round trip costs ~2 us of a ~10 us step
+        for (int kb = 0; kb < H; kb += 32 * UB) {
+            bf16x8 wf[UB], hf[NRT][UB];
 #pragma unroll
-            for (int r = 0; r < MAX_RT; ++r) {
-                if (r < nrt) {
-                    const int b = 16 * r + i15;
-                    const bf16x8 hf = frag16(hbase + (int64_t)b * S * 2 * H + k0, b < a.B);
-                    acc[r] = mfma16(wf, hf, acc[r]);   // D[i = unit 4*g4 + q][j = batch i15]
-                }
+            for (int u = 0; u < UB; ++u) {
+                const int k0 = kb + 32 * u;
+                const bool kok = k0 < H;
+                wf[u] = frag16(wrow + k0, kok);
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                        const int b = 16 * r + i15;
+                        hf[r][u] = frag16(hbase + (int64_t)b * S * 2 * H + k0, kok && b < a.B);
+                    }
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], hf[r][u], acc[r]);   // D[i = unit 4*g4 + q][j = batch i15]
         }
     }
 #pragma unroll
-    for (int r = 0; r < MAX_RT; ++r)
-        if (r < nrt)
+    for (int r = 0; r < NRT; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) s_g[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
     __syncthreads();
-    for (int p = tid; p < nrt * 256; p += 256) {
-        const int b = p >> 4, u = p & 15;
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        const int p = tid + 256 * i, b = p >> 4, u = p & 15;
         if (b >= a.B) continue;
         const int64_t row = (int64_t)b * S + tt;
-        const float* gx = a.gx + row * a.ldg + (int64_t)d * 4 * H + u0 + u;
-        const float gi = sigmoid_f(s_g[0][b][u] + gx[0]);
-        const float gf = sigmoid_f(s_g[1][b][u] + gx[H]);
-        const float gg = tanhf(s_g[2][b][u] + gx[2 * H]);
-        const float go = sigmoid_f(s_g[3][b][u] + gx[3 * H]);
-        const float cp = first ? 0.f : a.c_all[(((int64_t)b * S + tp) * 2 + d) * H + u0 + u];
+        const float gi = sigmoid_f(s_g[0][b][u] + gxr[i][0]);
+        const float gf = sigmoid_f(s_g[1][b][u] + gxr[i][1]);
+        const float gg = tanhf(s_g[2][b][u] + gxr[i][2]);
+        const float go = sigmoid_f(s_g[3][b][u] + gxr[i][3]);
+        const float cp = cpr[i];
         const float c = gf * cp + gi * gg;
         const float h = go * tanhf(c);
         a.c_all[(row * 2 + d) * H + u0 + u] = c;
@@ -100,6 +120,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs a) {
 
 // --------------------------------------------------------------------------------------------------- backward step
 // a.step counts the forward steps; the launches run step = S-1 .. 0.
+template <int NRT, int UB>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a) {
     __shared__ float s_p[4][MAX_RT * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,48 +129,65 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a) {
     const int tp = d == 0 ? tt - 1 : tt + 1;                // previous forward step
     const int tn = d == 0 ? tt + 1 : tt - 1;                // next forward step (its dgates are already computed)
     const bool last = a.step == S - 1, first = a.step == 0;
-    const int nrt = (a.B + 15) >> 4;
     const int i15 = lane & 15, g4 = lane >> 4;
 
-    f32x4 acc[MAX_RT];
+    // this thread's elementwise operands, fetched before the matrix part
+    float dyr[NRT], actr[NRT][4], cr[NRT], cpr[NRT], carr[NRT];
 #pragma unroll
-    for (int r = 0; r < MAX_RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NRT; ++i) {
+        const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+        const int bb = b < a.B ? b : 0;
+        const int64_t row = (int64_t)bb * S + tt;
+        dyr[i] = bf2f(a.dy[row * 2 * H + (int64_t)d * H + u0 + u]);
+        const bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) actr[i][q] = bf2f(act[q * H]);
+        cr[i] = a.c_all[(row * 2 + d) * H + u0 + u];
+        cpr[i] = first ? 0.f : a.c_all[(((int64_t)bb * S + tp) * 2 + d) * H + u0 + u];
+        carr[i] = last ? 0.f : a.dc_carry[((int64_t)d * a.B + bb) * H + u0 + u];
+    }
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!last) {
         // dh_rec[b][u] = sum_k dgates_next[b][k] * W_hh[k][u], k over 4H: wave w takes k in [w*H, (w+1)*H)
         const bf16_t* wrow = a.whh + ((int64_t)d * H + u0 + i15) * 4 * H + (int64_t)wave * H + 8 * g4;   // W_hh^T rows
         const bf16_t* gbase = a.dgates + (int64_t)tn * a.ldg + (int64_t)d * 4 * H + (int64_t)wave * H + 8 * g4;
-        for (int k0 = 0; k0 < H; k0 += 32) {
-            const bf16x8 wf = frag16(wrow + k0, true);
+        for (int kb = 0; kb < H; kb += 32 * UB) {
+            bf16x8 wf[UB], gf[NRT][UB];
 #pragma unroll
-            for (int r = 0; r < MAX_RT; ++r) {
-                if (r < nrt) {
-                    const int b = 16 * r + i15;
-                    const bf16x8 gf = frag16(gbase + (int64_t)b * S * a.ldg + k0, b < a.B);
-                    acc[r] = mfma16(wf, gf, acc[r]);
-                }
+            for (int u = 0; u < UB; ++u) {
+                const int k0 = kb + 32 * u;
+                const bool kok = k0 < H;
+                wf[u] = frag16(wrow + k0, kok);
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                        const int b = 16 * r + i15;
+                        gf[r][u] = frag16(gbase + (int64_t)b * S * a.ldg + k0, kok && b < a.B);
+                    }
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], gf[r][u], acc[r]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < MAX_RT; ++r)
-        if (r < nrt)
+    for (int r = 0; r < NRT; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) s_p[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
     __syncthreads();
-    for (int p = tid; p < nrt * 256; p += 256) {
-        const int b = p >> 4, u = p & 15;
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        const int p = tid + 256 * i, b = p >> 4, u = p & 15;
         if (b >= a.B) continue;
         const int64_t row = (int64_t)b * S + tt;
-        const float dh = bf2f(a.dy[row * 2 * H + (int64_t)d * H + u0 + u]) +
-                         (s_p[0][b][u] + s_p[1][b][u] + s_p[2][b][u] + s_p[3][b][u]);
-        const bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
-        const float gi = bf2f(act[0]), gf = bf2f(act[H]), gg = bf2f(act[2 * H]), go = bf2f(act[3 * H]);
-        const float c = a.c_all[(row * 2 + d) * H + u0 + u];
-        const float cp = first ? 0.f : a.c_all[(((int64_t)b * S + tp) * 2 + d) * H + u0 + u];
+        const float dh = dyr[i] + (s_p[0][b][u] + s_p[1][b][u] + s_p[2][b][u] + s_p[3][b][u]);
+        const float gi = actr[i][0], gf = actr[i][1], gg = actr[i][2], go = actr[i][3];
+        const float c = cr[i], cp = cpr[i];
         const float tc = tanhf(c);
-        float* carry = a.dc_carry + ((int64_t)d * a.B + b) * H + u0 + u;
-        const float dc = dh * go * (1.f - tc * tc) + (last ? 0.f : *carry);
-        *carry = dc * gf;
+        const float dc = dh * go * (1.f - tc * tc) + carr[i];
+        a.dc_carry[((int64_t)d * a.B + b) * H + u0 + u] = dc * gf;
         bf16_t* dg = a.dgates + row * a.ldg + (int64_t)d * 4 * H + u0 + u;
         dg[0] = f2bf(dc * gg * gi * (1.f - gi));
         dg[H] = f2bf(dc * cp * gf * (1.f - gf));
@@ -189,9 +227,12 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     LstmArgs a{};
     a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
+    const int nrt = (B + 15) / 16;
     for (int s = 0; s < S; ++s) {
         a.step = s;
-        hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_step_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        else if (nrt == 2) hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((lstm_fwd_step_kernel<4, 8>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
         ICKA_CHECK_LAUNCH();
     }
     return 0;
@@ -207,9 +248,12 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.dy = (const bf16_t*)dy; a.whh = (const bf16_t*)w_hh_t; a.act = (bf16_t*)const_cast<void*>(act);
     a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
     a.B = B; a.S = S; a.H = H;
+    const int nrt = (B + 15) / 16;
     for (int s = S - 1; s >= 0; --s) {
         a.step = s;
-        hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        else if (nrt == 2) hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((lstm_bwd_step_kernel<4, 8>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
         ICKA_CHECK_LAUNCH();
     }
     return 0;

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Throughput of the SURVEY.md section 8(f) tail on one MI355X: the `_gate_1` tagger (trunk -> BiLSTM -> classifier ->
+CRF token_mean loss; Cross_Modal_Interaction_Module.py:2383-2483) at the c2 shape, forward + backward, and the BiLSTM
+and CRF layers on their own.  Not the headline metric (bench.py: the my_bert head with token-CE).
+usage: python tools/tail_bench.py [--steps 20] [--warmup 5] [--no-graph]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from icka_amd import BertConfig, synth  # noqa: E402
+from icka_amd.graph import GraphedStep  # noqa: E402
+from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF_gate_1  # noqa: E402
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(synth.REFERENCE_SEED)
+    cfg = BertConfig(30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
+    model = MTCCMBertForMMTokenClassificationCRF_gate_1(cfg, num_labels=13).to(dev).train()
+    b = synth.synthetic_batch(args.batch, args.seq, args.regions, num_labels=13)
+    g = {k: v.to(dev) for k, v in b.items()}
+
+    def step():
+        loss = model(g["input_ids"], g["segment_ids"], g["input_mask"], g["input_ids"], g["input_mask"],
+                     g["segment_ids"], g["added_attention_mask"], visual_embeds_att=g["visual_embeds_att"],
+                     output_mask=g["input_mask"], labels=g["labels"], mode="train")
+        loss.backward()
+        return loss
+
+    model.zero_grad()
+    step()
+    if args.no_graph:
+        def run():
+            model.zero_grad()
+            return step()
+        mode = "eager"
+    else:
+        run = GraphedStep(model, step)
+        mode = "hipgraph"
+    ms = timed(run, args.steps, args.warmup)
+    loss = float(run().item())
+    # the two tail layers on their own (eager, forward + backward)
+    x = torch.randn(args.batch, args.seq, 768, device=dev).to(torch.bfloat16).requires_grad_(True)
+
+    def lstm_only():
+        out, _ = model.lstm(x)
+        out.float().sum().backward()
+    em = torch.randn(args.batch, args.seq, 13, device=dev, requires_grad=True)
+
+    def crf_only():
+        (-model.crf(em, g["labels"], mask=g["input_mask"].byte(), reduction="token_mean")).backward()
+    lstm_ms = timed(lstm_only, args.steps, args.warmup)
+    crf_ms = timed(crf_only, args.steps, args.warmup)
+    print(json.dumps({"metric": "MNER samples/sec (fwd+bwd), _gate_1 tagger: trunk + BiLSTM + classifier + CRF",
+                      "value": round(1e3 * args.batch / ms, 2), "unit": "samples/s", "ms_per_step": round(ms, 3),
+                      "launch": mode, "loss": round(loss, 5), "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": "bert-base + %d regions, seq %d, batch %d, train mode"
+                                 % (args.regions, args.seq, args.batch)},
+                      "bilstm_fwd_bwd_ms_eager": round(lstm_ms, 3), "crf_fwd_bwd_ms_eager": round(crf_ms, 3)}))
+
+
+if __name__ == "__main__":
+    main()
