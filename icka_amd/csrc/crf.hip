@@ -218,6 +218,194 @@ __global__ __launch_bounds__(64) void crf_decode_kernel(const CrfArgs a) {
     }
 }
 
+// ============================================================================================================
+// Register / shuffle variants for C <= 16 tags (the reference has 13 / 15 labels): the transition column (and row) of
+// a lane's tag live in registers, the running scores are exchanged with wave shuffles, the mask is a bit set built
+// with one ballot per 64 positions and the next step's emissions are prefetched -- no LDS traffic or barrier inside
+// the S-step recursions (the LDS versions above spend ~3.5k cycles per step on them).
+constexpr int CM = 16;
+constexpr int MAXW = 8;   // mask words: S <= 512
+
+struct MaskBits {
+    unsigned long long w[MAXW];
+    __device__ __forceinline__ bool on(int t) const { return t == 0 || ((w[t >> 6] >> (t & 63)) & 1ull); }
+    __device__ __forceinline__ bool raw(int t) const { return (w[t >> 6] >> (t & 63)) & 1ull; }
+};
+__device__ __forceinline__ MaskBits load_mask(const CrfArgs& a, int b, int lane, int* len) {
+    MaskBits mb;
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        const int t = 64 * k + lane;
+        const bool v = t < a.S && (a.mask == nullptr || a.mask[(int64_t)b * a.S + t] != 0);
+        mb.w[k] = __ballot(v);
+        n += __popcll(mb.w[k]);
+    }
+    *len = n;
+    return mb;
+}
+
+// lse_i (x_i + col[i]) with x_i = value of lane i
+__device__ __forceinline__ float lse_shfl(float x, const float (&col)[CM]) {
+    float v[CM];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CM; ++i) { v[i] = __shfl(x, i, 64) + col[i]; m = fmaxf(m, v[i]); }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CM; ++i) s += __expf(v[i] - m);
+    return m + __logf(s);
+}
+
+__global__ __launch_bounds__(64) void crf_llh_small_kernel(const CrfArgs a) {
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
+    int len;
+    const MaskBits mb = load_mask(a, b, j, &len);
+    float Tc[CM];
+#pragma unroll
+    for (int i = 0; i < CM; ++i) Tc[i] = (j < C && i < C) ? a.trans[i * C + j] : -INFINITY;
+    const float num = gold_score(a, b, j);
+    const float* eb = a.e + (int64_t)b * S * a.ld_s;
+    const bool act_lane = j < C;
+    float alpha = act_lane ? a.start[j] + eb[j] : -INFINITY;
+    float en = (act_lane && S > 1) ? eb[a.ld_s + j] : 0.f;
+    for (int t = 1; t < S; ++t) {
+        const float et = en;
+        if (t + 1 < S) en = act_lane ? eb[(int64_t)(t + 1) * a.ld_s + j] : 0.f;
+        if (!mb.on(t)) continue;
+        const float nx = lse_shfl(alpha, Tc) + et;
+        alpha = act_lane ? nx : -INFINITY;
+    }
+    const float v = act_lane ? alpha + a.end[j] : -INFINITY;
+    const float m = wave_max(v);
+    const float z = m + __logf(wave_sum(act_lane ? __expf(v - m) : 0.f));
+    if (j == 0) a.llh[b] = num - z;
+}
+
+__global__ __launch_bounds__(64) void crf_grad_small_kernel(const CrfArgs a) {
+    __shared__ float s_al[CRF_MAX_SC];   // alpha[t][j] after step t
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
+    int len;
+    const MaskBits mb = load_mask(a, b, j, &len);
+    const bool act_lane = j < C;
+    float Tc[CM], Tr[CM], dT[CM];   // column j (into tag j), row j (out of tag j), gradient column j
+#pragma unroll
+    for (int i = 0; i < CM; ++i) {
+        Tc[i] = (act_lane && i < C) ? a.trans[i * C + j] : -INFINITY;
+        Tr[i] = (act_lane && i < C) ? a.trans[j * C + i] : -INFINITY;
+        dT[i] = 0.f;
+    }
+    const float g = a.gllh[b];
+    const float* eb = a.e + (int64_t)b * S * a.ld_s;
+    const int64_t* tg = a.tags + (int64_t)b * S;
+    float* deb = a.de + (int64_t)b * S * a.ld_ds;
+
+    float alpha = act_lane ? a.start[j] + eb[j] : -INFINITY;
+    if (act_lane) s_al[j] = alpha;
+    float en = (act_lane && S > 1) ? eb[a.ld_s + j] : 0.f;
+    for (int t = 1; t < S; ++t) {
+        const float et = en;
+        if (t + 1 < S) en = act_lane ? eb[(int64_t)(t + 1) * a.ld_s + j] : 0.f;
+        if (mb.on(t)) {
+            const float nx = lse_shfl(alpha, Tc) + et;
+            alpha = act_lane ? nx : -INFINITY;
+        }
+        if (act_lane) s_al[t * C + j] = alpha;
+    }
+    __syncthreads();
+    const float v = act_lane ? alpha + a.end[j] : -INFINITY;
+    const float m = wave_max(v);
+    const float logz = m + __logf(wave_sum(act_lane ? __expf(v - m) : 0.f));
+
+    float beta = act_lane ? a.end[j] : -INFINITY;
+    float dend = act_lane ? -__expf(v - logz) : 0.f;
+    float dstart = 0.f;
+    en = act_lane ? eb[(int64_t)(S - 1) * a.ld_s + j] : 0.f;
+    int yn = tag_at(tg, S - 1, C);
+    for (int t = S - 1; t >= 0; --t) {
+        const float et = en;
+        const int y = yn;
+        if (t > 0) { en = act_lane ? eb[(int64_t)(t - 1) * a.ld_s + j] : 0.f; yn = tag_at(tg, t - 1, C); }
+        if (!mb.on(t)) {
+            if (act_lane) deb[(int64_t)t * a.ld_ds + j] = 0.f;
+            continue;
+        }
+        const float marg = act_lane ? __expf(s_al[t * C + j] + beta - logz) : 0.f;
+        if (act_lane) deb[(int64_t)t * a.ld_ds + j] = g * ((j == y ? 1.f : 0.f) - marg);
+        if (t == 0) { dstart = (j == y ? 1.f : 0.f) - marg; break; }
+        const float u = act_lane ? et + beta : -INFINITY;   // e[t][j] + beta_t[j]
+        if (act_lane) {
+#pragma unroll
+            for (int i = 0; i < CM; ++i)
+                if (i < C) dT[i] -= __expf(s_al[(t - 1) * C + i] + Tc[i] + u - logz);
+        }
+        if (j == y) {   // gold transition (literal previous position), yn = tag at t-1
+#pragma unroll
+            for (int i = 0; i < CM; ++i) dT[i] += (i == yn) ? 1.f : 0.f;
+        }
+        const float nb = lse_shfl(u, Tr);   // beta_{prev}[j] = lse_k (T[j][k] + u[k])
+        beta = act_lane ? nb : -INFINITY;
+    }
+    const int last = len > 0 ? len - 1 : 0;
+    if (act_lane) {
+        if (j == tag_at(tg, last, C)) dend += 1.f;
+        atomicAdd(a.dstart + j, g * dstart);
+        atomicAdd(a.dend + j, g * dend);
+#pragma unroll
+        for (int i = 0; i < CM; ++i)
+            if (i < C) atomicAdd(a.dtrans + i * C + j, g * dT[i]);
+    }
+}
+
+__global__ __launch_bounds__(64) void crf_decode_small_kernel(const CrfArgs a) {
+    __shared__ unsigned char s_bp[CRF_MAX_SC];
+    __shared__ float s_fin[64];
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
+    int len;
+    const MaskBits mb = load_mask(a, b, j, &len);
+    const bool act_lane = j < C;
+    float Tc[CM];
+#pragma unroll
+    for (int i = 0; i < CM; ++i) Tc[i] = (act_lane && i < C) ? a.trans[i * C + j] : -INFINITY;
+    const float* eb = a.e + (int64_t)b * S * a.ld_s;
+    float score = act_lane ? a.start[j] + eb[j] : -INFINITY;
+    float en = (act_lane && S > 1) ? eb[a.ld_s + j] : 0.f;
+    for (int t = 1; t < S; ++t) {
+        const float et = en;
+        if (t + 1 < S) en = act_lane ? eb[(int64_t)(t + 1) * a.ld_s + j] : 0.f;
+        float m = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int i = 0; i < CM; ++i) {
+            const float v = __shfl(score, i, 64) + Tc[i];
+            if (v > m) { m = v; am = i; }
+        }
+        if (act_lane) {
+            s_bp[t * C + j] = (unsigned char)am;
+            if (mb.on(t)) score = m + et;
+        }
+    }
+    s_fin[j] = act_lane ? score + a.end[j] : -INFINITY;
+    __syncthreads();
+    if (j == 0) {
+        int bt = 0;
+        float bs = s_fin[0];
+        for (int i = 1; i < C; ++i)
+            if (s_fin[i] > bs) { bs = s_fin[i]; bt = i; }
+        if (a.best_score) a.best_score[b] = bs;
+        int64_t* out = a.best + (int64_t)b * S;
+        const int last = len > 0 ? len - 1 : 0;
+        for (int t = last + 1; t < S; ++t) out[t] = -1;
+        out[last] = bt;
+        for (int t = last; t >= 1; --t) {
+            bt = s_bp[t * C + bt];
+            out[t - 1] = bt;
+        }
+    }
+}
+
+inline bool crf_small(int S, int C) { return C <= CM && S <= 64 * MAXW; }
+
 inline int crf_check(const void* e, const void* start, const void* end, const void* trans, int B, int S, int C) {
     if (!e || !start || !end || !trans) return ICKA_E_ARG;
     if (B <= 0 || S <= 0 || C <= 0 || C > 64) return ICKA_E_SHAPE;
@@ -234,7 +422,8 @@ extern "C" int icka_crf_llh(const float* emissions, int64_t ld, const int64_t* t
     CrfArgs a{};
     a.e = emissions; a.ld_s = ld; a.tags = tags; a.mask = mask; a.start = start; a.end = end; a.trans = trans;
     a.llh = llh; a.B = B; a.S = S; a.C = C;
-    hipLaunchKernelGGL(crf_llh_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    if (crf_small(S, C)) hipLaunchKernelGGL(crf_llh_small_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(crf_llh_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
@@ -250,7 +439,8 @@ extern "C" int icka_crf_grad(const float* emissions, int64_t ld, const int64_t* 
     a.e = emissions; a.ld_s = ld; a.tags = tags; a.mask = mask; a.start = start; a.end = end; a.trans = trans;
     a.gllh = gllh; a.de = d_emissions; a.ld_ds = ldd; a.dstart = d_start; a.dend = d_end; a.dtrans = d_trans;
     a.B = B; a.S = S; a.C = C;
-    hipLaunchKernelGGL(crf_grad_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    if (crf_small(S, C)) hipLaunchKernelGGL(crf_grad_small_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(crf_grad_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
@@ -264,7 +454,8 @@ extern "C" int icka_crf_decode(const float* emissions, int64_t ld, const int64_t
     CrfArgs a{};
     a.e = emissions; a.ld_s = ld; a.mask = mask; a.start = start; a.end = end; a.trans = trans;
     a.best = best_tags; a.best_score = best_score; a.B = B; a.S = S; a.C = C;
-    hipLaunchKernelGGL(crf_decode_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    if (crf_small(S, C)) hipLaunchKernelGGL(crf_decode_small_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(crf_decode_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
