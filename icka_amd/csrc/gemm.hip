@@ -839,6 +839,30 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, FA[mi], cs[mi]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
+// ICKA_RM: one scheduling region = fragment reads of the NEXT k-step (into the idle register set) + the MFMAs of the
+// current one, with the DS reads spread between the MFMAs (sched_group_barrier: 1 MFMA, 1 DS read, ...).  Issued as a
+// block in front of the MFMAs, the reads (+ their address arithmetic) left the matrix pipe idle for 150-300 cycles
+// per k-step: there is one compute wave per SIMD, nothing else fills those slots (measured on the 256x128 kernel:
+// 80.9 -> 64.3 us per launch).
+#define ICKA_RM(RA, RB, BUFI, KS, MA, MB)                                                            \
+    if (ABL != 1) do {                                                                               \
+        constexpr int NR_ = 4 * (A_KM ? 2 : 1) + NTN * (B_KM ? 2 : 1), NM_ = 4 * NTN;                \
+        constexpr int NP_ = NR_ < NM_ ? NR_ : NM_;                                                   \
+        const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) RA[t] = read_frag<A_KM>(b_, wr + 16 * t, KS, lane);              \
+        _Pragma("unroll") for (int t = 0; t < NTN; ++t) RB[t] = read_frag<B_KM>(b_ + TILE_BYTES, wc + 16 * t, KS, lane); \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
+            _Pragma("unroll") for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16(MB[ni], MA[mi], acc[mi][ni]); \
+        if constexpr (NR_ > NM_) __builtin_amdgcn_sched_group_barrier(0x100, NR_ - NM_, 0);          \
+        _Pragma("unroll") for (int i_ = 0; i_ < NP_; ++i_) {                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+        }                                                                                            \
+        if constexpr (NM_ > NR_) __builtin_amdgcn_sched_group_barrier(0x008, NM_ - NR_, 0);          \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, MA[mi], cs[mi]); }  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
 #define ICKA_SYNC()                                          \
     do {                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
@@ -856,25 +880,19 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         int kt = 0;
         for (; kt + 2 <= nk - 1; kt += 2) {
             ICKA_SYNC();                         // barrier kt+1
-            ICKA_READ(qa0, qb0, nxt, 0);
-            ICKA_MMA(pa0, pb0);
-            ICKA_READ(qa1, qb1, nxt, 1);
-            ICKA_MMA(pa1, pb1);
+            ICKA_RM(qa0, qb0, nxt, 0, pa0, pb0);
+            ICKA_RM(qa1, qb1, nxt, 1, pa1, pb1);
             nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
             ICKA_SYNC();                         // barrier kt+2
-            ICKA_READ(pa0, pb0, nxt, 0);
-            ICKA_MMA(qa0, qb0);
-            ICKA_READ(pa1, pb1, nxt, 1);
-            ICKA_MMA(qa1, qb1);
+            ICKA_RM(pa0, pb0, nxt, 0, qa0, qb0);
+            ICKA_RM(pa1, pb1, nxt, 1, qa1, qb1);
             nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
         }
         // tail: kt is the next tile to multiply (in P); nk - kt is 1 or 2
         if (kt + 1 <= nk - 1) {
             ICKA_SYNC();
-            ICKA_READ(qa0, qb0, nxt, 0);
-            ICKA_MMA(pa0, pb0);
-            ICKA_READ(qa1, qb1, nxt, 1);
-            ICKA_MMA(pa1, pb1);
+            ICKA_RM(qa0, qb0, nxt, 0, pa0, pb0);
+            ICKA_RM(qa1, qb1, nxt, 1, pa1, pb1);
             ICKA_MMA(qa0, qb0);
             ICKA_MMA(qa1, qb1);
         } else {
@@ -883,6 +901,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         }
 #undef ICKA_READ
 #undef ICKA_MMA
+#undef ICKA_RM
 #undef ICKA_SYNC
         }
         // MFMA -> VALU read-after-write needs software wait states on gfx950 (8-pass MFMA: ~11).  hipcc's hazard
@@ -1182,6 +1201,218 @@ __global__ __launch_bounds__(512) void gemm_ws_group_kernel(const GroupArgs ga) 
     gemm_ws_body<A_KM, B_KM, NBUF>(g, smem, bid - ga.start[pi], ga.start[pi + 1] - ga.start[pi]);
 }
 
+// =====================================================================================================================
+// 256x128 output tiles for the grouped weight-gradient launch (TN, K = tokens = 4096 at c2).
+// The 128x128 loop is LDS-bound: four 64x64 wave tiles read 64 KB of fragments per k-tile and the LDS-DMA writes 32 KB
+// (96 KB at 128 B/clk = 768 cycles against 544 cycles of MFMA).  With 128x64 wave tiles on a 256x128 block tile the
+// same four compute waves issue twice the MFMAs (1024 cycles) for 96 + 48 KB of LDS traffic (1125 cycles): per FLOP
+// the LDS moves 0.73x less, and the four weight-gradient problems of a BERT layer become 216 tiles = one round of
+// the 256 CUs instead of 432 tiles = two.  The bias-gradient column sums do not ride on the MFMAs here (the compute
+// waves have no registers to spare: 128 accumulators + two fragment sets): they are extra blocks at the END of the
+// same grid, which run on the CUs the 216 tiles leave idle and stream the dY operands once.
+// Outputs are written straight from the accumulators (f32, beta = 0, no epilogue operand): the only form the
+// weight-gradient path needs; anything else uses the 128x128 group kernel.
+constexpr int BIG_STAGE = 3 * TILE_BYTES;   // A rows 0..127 | A rows 128..255 | B   (k-major images)
+constexpr int BIG_NBUF = 3;
+constexpr int CS_COLS = 64;                 // operand columns per column-sum block
+
+struct BigGroupArgs {
+    GemmArgs p[MAX_GROUP];
+    int start[MAX_GROUP + 1];     // first GEMM tile of each problem; start[n..] = total tiles
+    int cs_start[MAX_GROUP + 1];  // first column-sum block of each problem (relative to the total tiles)
+};
+
+__device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    int m0, n0;
+    tile_origin(bid, nb, g.M / 256, g.N / BN, m0, n0);
+    m0 *= 2;   // tile_origin counts rows in units of BM = 128
+    const int nk = g.K / BK;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------- loader waves
+        const int lw = wave - 4;
+        const bf16_t* pa0[4];
+        const bf16_t* pa1[4];
+        const bf16_t* pb[4];
+        dma_init<true>(pa0, g.A, g.lda, m0, lw, lane);
+        dma_init<true>(pa1, g.A, g.lda, m0 + 128, lw, lane);
+        dma_init<true>(pb, g.B, g.ldb, n0, lw, lane);
+        const int64_t sa = (int64_t)BK * g.lda, sb = (int64_t)BK * g.ldb;
+#define ICKA_BIG_STAGE(BUF)                                              \
+    do {                                                                 \
+        dma_issue(pa0, sa, lds0 + (BUF) + lw * 1024);                    \
+        dma_issue(pa1, sa, lds0 + (BUF) + TILE_BYTES + lw * 1024);       \
+        dma_issue(pb, sb, lds0 + (BUF) + 2 * TILE_BYTES + lw * 1024);    \
+    } while (0)
+#pragma unroll
+        for (int t = 0; t < BIG_NBUF - 1; ++t)
+            if (t < nk) ICKA_BIG_STAGE(t * BIG_STAGE);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            int ahead = nk - 1 - kt;
+            ahead = ahead > BIG_NBUF - 2 ? BIG_NBUF - 2 : ahead;
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // 12 DMA per k-tile per loader wave
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + BIG_NBUF - 1 < nk) {
+                int nx = cur + BIG_NBUF - 1;
+                nx = nx >= BIG_NBUF ? nx - BIG_NBUF : nx;
+                ICKA_BIG_STAGE(nx * BIG_STAGE);
+            }
+            cur = cur + 1 == BIG_NBUF ? 0 : cur + 1;
+        }
+#undef ICKA_BIG_STAGE
+        return;   // outputs are stored by the compute waves straight from their accumulators
+    }
+    // ---------------------------------------------------------------------------------------------- compute waves
+    const int wsub = wave >> 1;            // which 128-row half of the A tile
+    const int wc = (wave & 1) * 64;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];   // fragment sets of the two 32-deep k-steps of a tile
+#define ICKA_BIG_READ(FA, FB, BUFI, KS)                                                                     \
+    do {                                                                                                    \
+        const char* b_ = smem + (BUFI) * BIG_STAGE;                                                         \
+        int l_ = lane;                                                                                      \
+        asm volatile("" : "+v"(l_)); /* opaque: the 48 swizzled LDS addresses are recomputed per read (a few */ \
+        /* VALU ops) instead of being held in registers across the loop -- held, they spilled to scratch and */ \
+        /* the serialized reloads cost ~4000 cycles per k-tile */                                           \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) FA[t] = read_frag<true>(b_ + wsub * TILE_BYTES, 16 * t, KS, l_); \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) FB[t] = read_frag<true>(b_ + 2 * TILE_BYTES, wc + 16 * t, KS, l_); \
+    } while (0)
+#define ICKA_BIG_MMA(FA, FB)                                                                                \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                    \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(FB[ni], FA[mi], acc[mi][ni]); \
+    } while (0)
+// One scheduling region = 24 fragment reads (into the idle register set) + 32 MFMAs (from the other set): the reads
+// are spread between the MFMAs (1 DS read per MFMA, then the remaining MFMAs) instead of being issued as one block
+// while the matrix pipe idles -- with one compute wave per SIMD nothing else would fill those cycles.
+#define ICKA_BIG_INTERLEAVE()                                                                               \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+    __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
+    asm volatile("" ::: "memory");
+    ICKA_BIG_READ(fa0, fb0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        ICKA_BIG_READ(fa1, fb1, cur, 1);
+        ICKA_BIG_MMA(fa0, fb0);
+        ICKA_BIG_INTERLEAVE();
+        const int nxt = cur + 1 == BIG_NBUF ? 0 : cur + 1;
+        // tile kt is completely in registers: barrier kt+1 publishes tile kt+1 and frees tile kt's buffer
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ICKA_BIG_READ(fa0, fb0, nxt, 0);
+        ICKA_BIG_MMA(fa1, fb1);
+        ICKA_BIG_INTERLEAVE();
+        cur = nxt;
+    }
+    ICKA_BIG_READ(fa1, fb1, cur, 1);   // last tile
+    ICKA_BIG_MMA(fa0, fb0);
+    ICKA_BIG_INTERLEAVE();
+    ICKA_BIG_MMA(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+#undef ICKA_BIG_INTERLEAVE
+#undef ICKA_BIG_READ
+#undef ICKA_BIG_MMA
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc + 16 * ni + 4 * (lane >> 4);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wsub * 128 + 16 * mi + (lane & 15);
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = acc[mi][ni] * g.alpha;
+        }
+    }
+}
+
+// column sums of a k-major operand slice: colsum[c0 .. c0+64) (+)= sum over the K rows of A[k][m].
+// 8 chunk lanes (64 columns) x 64 row lanes, 8 independent 16-byte loads in flight per thread.
+__device__ __forceinline__ void big_colsum_block(const GemmArgs& g, char* smem, int cb) {
+    float* red = reinterpret_cast<float*>(smem);   // [64 row lanes][64 columns]
+    const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
+    const int col = cb * CS_COLS + cx * 8;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (col < g.M) {
+        const bf16_t* base = g.A + col;
+        int k = ry;
+        for (; k + 7 * 64 < g.K; k += 8 * 64) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)(k + 64 * u) * g.lda);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bf16x8 h = as_bf16x8(v[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += bf2f(h[e]);
+            }
+        }
+        for (; k < g.K; k += 64) {
+            const bf16x8 h = as_bf16x8(*reinterpret_cast<const u32x4*>(base + (int64_t)k * g.lda));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf2f(h[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ry * CS_COLS + cx * 8 + e] = s[e];
+    __syncthreads();
+    if (tid < CS_COLS) {
+        const int c = cb * CS_COLS + tid;
+        if (c < g.M) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) t += red[r * CS_COLS + tid];
+            g.colsum[c] = g.colsum_acc ? g.colsum[c] + t : t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_big_group_kernel(const BigGroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) char smem[BIG_NBUF * BIG_STAGE];
+    const int bid = blockIdx.x;
+    const int tiles = ga.start[MAX_GROUP];
+    if (bid >= tiles) {
+        const int cb = bid - tiles;
+        int pi = 0;
+#pragma unroll
+        for (int i = 1; i < MAX_GROUP; ++i) pi += cb >= ga.cs_start[i] ? 1 : 0;
+        const GemmArgs g = ga.p[pi];
+        big_colsum_block(g, smem, cb - ga.cs_start[pi]);
+        return;
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) pi += bid >= ga.start[i] ? 1 : 0;
+    const GemmArgs g = ga.p[pi];
+    gemm_big_tn_body(g, smem, bid - ga.start[pi], ga.start[pi + 1] - ga.start[pi]);
+}
+
+int g_big = 1;   // icka_gemm_set_big_tiles: 256x128 tiles for eligible grouped TN launches
+
+// eligible: fast-path TN, 256-row tiles, plain f32 overwrite
+static bool big_ok(const GemmArgs& g, bool aligned) {
+    return aligned && g.M % 256 == 0 && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f && g.K1 == 0 &&
+           !g.bias && !g.bias2 && g.direct;
+}
+
 template <bool A_KM, bool B_KM>
 static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
     if (g_ws) {
@@ -1197,11 +1428,42 @@ static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
     return 0;
 }
 
+extern "C" int icka_gemm_set_big_tiles(int on) {
+    g_big = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream) {
     if (!descs || n <= 0) return ICKA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     int i = 0;
     while (i < n) {
+        if (g_big && g_ws && descs[i].op == ICKA_GEMM_TN) {
+            // 256x128-tile launch for runs of eligible weight-gradient problems (+ their column-sum blocks)
+            BigGroupArgs ba;
+            int cnt = 0, total = 0, cs_total = 0;
+            while (i + cnt < n && cnt < MAX_GROUP && descs[i + cnt].op == ICKA_GEMM_TN) {
+                bool aligned = false;
+                GemmArgs g;
+                const int rc = convert(&descs[i + cnt], g, aligned);
+                if (rc) return rc;
+                if (!big_ok(g, aligned)) break;
+                ba.p[cnt] = g;
+                ba.start[cnt] = total;
+                ba.cs_start[cnt] = cs_total;
+                total += (g.M / 256) * (g.N / BN);
+                if (g.colsum) cs_total += (g.M + CS_COLS - 1) / CS_COLS;
+                ++cnt;
+            }
+            if (cnt >= 1 && total >= 64) {
+                for (int k = cnt; k <= MAX_GROUP; ++k) { ba.start[k] = total; ba.cs_start[k] = cs_total; }
+                for (int k = cnt; k < MAX_GROUP; ++k) ba.p[k] = ba.p[0];
+                hipLaunchKernelGGL(gemm_big_group_kernel, dim3(total + cs_total), dim3(512), 0, st, ba);
+                ICKA_CHECK_LAUNCH();
+                i += cnt;
+                continue;
+            }
+        }
         // greedily pack up to MAX_GROUP consecutive fast-path problems of the same layout into one launch
         GroupArgs ga;
         int cnt = 0, total = 0;

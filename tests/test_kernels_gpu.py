@@ -194,6 +194,34 @@ def test_gemm_grouped_matches_individual_launches():
     assert rel_err(single, keep[1][0].float().sum(0)) < 1e-4 and rel_err(o2, keep[1][0].float().t() @ keep[1][1].float()) < 1e-4
 
 
+@pytest.mark.parametrize("big", [1, 0])
+def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
+    """The four weight-gradient GEMMs of a BERT layer as one grouped launch, overwrite mode (beta = 0) with fused bias
+    gradients: 256x128-tile kernel with column-sum blocks in the same grid (big=1) vs the 128x128 group kernel."""
+    k = _k()
+    from icka_amd import _lib
+    lib = _lib.load()
+    assert lib.icka_gemm_set_big_tiles(big) == 0
+    request.addfinalizer(lambda: lib.icka_gemm_set_big_tiles(1))
+    T, H, I = 1024, 768, 3072
+    shapes = [(3 * H, H), (H, H), (I, H), (H, I)]
+    descs, outs, refs, css, keep = [], [], [], [], []
+    for i, (m, n) in enumerate(shapes):
+        A, B = rnd(T, m, seed=30 + i, scale=0.5), rnd(T, n, seed=40 + i, scale=0.5)
+        out = torch.full((m, n), 7.0, dtype=F32, device="cuda")          # must be overwritten
+        cs = torch.full((m,), 3.0, dtype=F32, device="cuda") if i != 1 else None
+        descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=0.0, colsum_out=cs, colsum_accumulate=(i == 2)))
+        keep.append((A, B)); outs.append(out); css.append(cs)
+        refs.append(A.float().t() @ B.float())
+    k.gemm_grouped(descs)
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < 1e-4
+    for i, cs in enumerate(css):
+        if cs is not None:
+            ref = keep[i][0].float().sum(0) + (3.0 if i == 2 else 0.0)
+            assert rel_err(cs, ref) < 1e-4, i
+
+
 def test_gemm_bad_args():
     k = _k()
     A, B = rnd(64, 64), rnd(64, 64)
