@@ -1210,8 +1210,8 @@ __global__ __launch_bounds__(512) void gemm_ws_group_kernel(const GroupArgs ga) 
 // the 256 CUs instead of 432 tiles = two.  The bias-gradient column sums do not ride on the MFMAs here (the compute
 // waves have no registers to spare: 128 accumulators + two fragment sets): they are extra blocks at the END of the
 // same grid, which run on the CUs the 216 tiles leave idle and stream the dY operands once.
-// Outputs are written straight from the accumulators (f32, beta = 0, no epilogue operand): the only form the
-// weight-gradient path needs; anything else uses the 128x128 group kernel.
+// Outputs are written straight from the accumulators (f32, optional beta accumulate, no epilogue operand): the only
+// form the weight-gradient path needs; anything else uses the 128x128 group kernel.
 constexpr int BIG_STAGE = 3 * TILE_BYTES;   // A rows 0..127 | A rows 128..255 | B   (k-major images)
 constexpr int BIG_NBUF = 3;
 constexpr int CS_COLS = 64;                 // operand columns per column-sum block
@@ -1337,7 +1337,10 @@ __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, 
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + wsub * 128 + 16 * mi + (lane & 15);
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = acc[mi][ni] * g.alpha;
+            f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
+            f32x4 v = acc[mi][ni] * g.alpha;
+            if (g.beta != 0.f) v += g.beta * *dst;   // gradient accumulation across micro-batches
+            *dst = v;
         }
     }
 }
@@ -1407,10 +1410,9 @@ __global__ __launch_bounds__(512) void gemm_big_group_kernel(const BigGroupArgs 
 
 int g_big = 1;   // icka_gemm_set_big_tiles: 256x128 tiles for eligible grouped TN launches
 
-// eligible: fast-path TN, 256-row tiles, plain f32 overwrite
+// eligible: fast-path TN, 256-row tiles, plain f32 output (overwrite or accumulate)
 static bool big_ok(const GemmArgs& g, bool aligned) {
-    return aligned && g.M % 256 == 0 && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f && g.K1 == 0 &&
-           !g.bias && !g.bias2 && g.direct;
+    return aligned && g.M % 256 == 0 && g.c_f32 && g.epi == ICKA_EPI_NONE && g.K1 == 0 && !g.bias && !g.bias2 && g.direct;
 }
 
 template <bool A_KM, bool B_KM>

@@ -78,8 +78,8 @@ int icka_gemm_set_tile_n(int bn);
 /* 1 (default): f32 outputs without activation / fan-in operand / accumulate are stored straight from the MFMA
  * accumulators; 0: every epilogue goes through the LDS C tile (16-byte row-contiguous stores). */
 int icka_gemm_set_direct_epilogue(int on);
-/* 1 (default): grouped TN launches whose problems are plain f32 overwrites with M % 256 == 0 (the weight gradients of a
- * layer) use 256x128 output tiles and compute their fused column sums in extra blocks of the same grid; 0: 128x128. */
+/* 1 (default): grouped TN launches whose problems are plain f32 outputs with M % 256 == 0 (the weight gradients of a
+ * layer, overwrite or beta-accumulate) use 256x128 output tiles and compute their fused column sums in extra blocks of the same grid; 0: 128x128. */
 int icka_gemm_set_big_tiles(int on);
 /* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
 int icka_gemm_set_ablation(int mode);

@@ -208,11 +208,12 @@ def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
     descs, outs, refs, css, keep = [], [], [], [], []
     for i, (m, n) in enumerate(shapes):
         A, B = rnd(T, m, seed=30 + i, scale=0.5), rnd(T, n, seed=40 + i, scale=0.5)
-        out = torch.full((m, n), 7.0, dtype=F32, device="cuda")          # must be overwritten
+        out = torch.full((m, n), 7.0, dtype=F32, device="cuda")          # overwritten, or accumulated into (i == 3)
         cs = torch.full((m,), 3.0, dtype=F32, device="cuda") if i != 1 else None
-        descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=0.0, colsum_out=cs, colsum_accumulate=(i == 2)))
+        descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=1.0 if i == 3 else 0.0, colsum_out=cs,
+                                 colsum_accumulate=(i == 2)))
         keep.append((A, B)); outs.append(out); css.append(cs)
-        refs.append(A.float().t() @ B.float())
+        refs.append(A.float().t() @ B.float() + (7.0 if i == 3 else 0.0))
     k.gemm_grouped(descs)
     for o, r in zip(outs, refs):
         assert rel_err(o, r) < 1e-4
