@@ -35,12 +35,19 @@ class GemmDesc(C.Structure):
     ]
 
 
+class SlabReduction(C.Structure):
+    """Mirror of ``icka_slab_reduction`` (include/icka_hip.h)."""
+    _fields_ = [("partials", c_vp), ("slab_stride", c_i64), ("nslab", c_i32), ("H", c_i32), ("nslots", c_i32),
+                ("accumulate", c_i32), ("out", c_vp * 4)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/icka_hip.h
 PROTOTYPES = {
     "icka_abi_version": (c_i32, []),
     "icka_build_arch": (C.c_char_p, []),
     "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "icka_gemm_grouped": (c_i32, [C.POINTER(GemmDesc), c_i32, c_vp]),
+    "icka_gemm_grouped_ex": (c_i32, [C.POINTER(GemmDesc), c_i32, C.POINTER(SlabReduction), c_i32, c_vp]),
     "icka_gemm_set_ring": (c_i32, [c_i32]),
     "icka_gemm_set_tile_n": (c_i32, [c_i32]),
     "icka_gemm_set_direct_epilogue": (c_i32, [c_i32]),
@@ -53,6 +60,10 @@ PROTOTYPES = {
     "icka_ln_bwd_workspace_floats": (c_i64, [c_i32]),
     "icka_ln_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                             c_vp, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
+    "icka_ln_bwd_slabs": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32,
+                                  c_i32, c_f32, c_u64, c_vp]),
+    "icka_ln_bwd_nslab": (c_i32, [c_i32]),
+    "icka_ln_slab_slots": (c_i32, []),
     "icka_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,

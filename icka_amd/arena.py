@@ -72,6 +72,7 @@ class ParamArena(object):
         self.reducer = None          # optional dp.GradReducer: overlaps bucket all-reduces with backward
         self._pending_final: List[Slot] = []
         self.pending_wgrad = []      # queued weight-gradient GEMM descriptors (+ keep-alive tensors), see ops._wgrad
+        self.pending_reductions = []  # LayerNorm dgamma/dbeta slab reductions riding on the next grouped launch
         self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self._seed_ctr = 0
 

@@ -1216,11 +1216,48 @@ constexpr int BIG_STAGE = 3 * TILE_BYTES;   // A rows 0..127 | A rows 128..255 |
 constexpr int BIG_NBUF = 3;
 constexpr int CS_COLS = 64;                 // operand columns per column-sum block
 
+constexpr int MAX_RED = 4;
+struct SlabRed {   // out[slot][c] (+)= sum_b partials[b*slab_stride + slot*H + c]
+    const float* partials; float* out[4];
+    int nslab, H, nslots, slab_stride, accumulate, blocks;
+};
 struct BigGroupArgs {
     GemmArgs p[MAX_GROUP];
     int start[MAX_GROUP + 1];     // first GEMM tile of each problem; start[n..] = total tiles
     int cs_start[MAX_GROUP + 1];  // first column-sum block of each problem (relative to the total tiles)
+    SlabRed red[MAX_RED];         // slab reductions riding on the launch (LayerNorm dgamma / dbeta of the layer)
+    int red_start[MAX_RED + 1];   // first block of each reduction (relative to tiles + column-sum blocks)
 };
+
+// 64 output values per block (8 slab lanes x 64 columns), fixed summation order: bitwise reproducible
+__device__ __forceinline__ void slab_reduce_block(const SlabRed& r, char* smem, int rb) {
+    float* red = reinterpret_cast<float*>(smem);   // [8][64]
+    const int tid = threadIdx.x, cx = tid & 63, sy = tid >> 6;
+    const int idx = rb * 64 + cx;
+    const bool ok = idx < r.nslots * r.H;
+    float s = 0.f;
+    if (ok) {
+        const int slot = idx / r.H, c = idx - slot * r.H;
+        const float* p = r.partials + (int64_t)slot * r.H + c;
+        for (int b = sy; b < r.nslab; b += 8) s += p[(int64_t)b * r.slab_stride];
+    }
+    red[sy * 64 + cx] = s;
+    __syncthreads();
+    if (sy == 0 && ok) {
+        const int slot = idx / r.H, c = idx - slot * r.H;
+        float* out = r.out[slot];
+        if (out) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 64 + cx];
+            out[c] = r.accumulate ? out[c] + t : t;
+        }
+    }
+}
+__global__ __launch_bounds__(512) void slab_reduce_kernel(const SlabRed r) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * 64 * 4];
+    slab_reduce_block(r, smem, blockIdx.x);
+}
 
 __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1392,6 +1429,14 @@ __global__ __launch_bounds__(512) void gemm_big_group_kernel(const BigGroupArgs 
     __shared__ __attribute__((aligned(16))) char smem[BIG_NBUF * BIG_STAGE];
     const int bid = blockIdx.x;
     const int tiles = ga.start[MAX_GROUP];
+    if (bid >= tiles + ga.cs_start[MAX_GROUP]) {
+        const int rb = bid - tiles - ga.cs_start[MAX_GROUP];
+        int ri = 0;
+#pragma unroll
+        for (int i = 1; i < MAX_RED; ++i) ri += rb >= ga.red_start[i] ? 1 : 0;
+        slab_reduce_block(ga.red[ri], smem, rb - ga.red_start[ri]);
+        return;
+    }
     if (bid >= tiles) {
         const int cb = bid - tiles;
         int pi = 0;
@@ -1435,9 +1480,36 @@ extern "C" int icka_gemm_set_big_tiles(int on) {
     return 0;
 }
 
+static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_reduction* reds, int32_t n_red,
+                        hipStream_t st);
+
 extern "C" int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream) {
     if (!descs || n <= 0) return ICKA_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
+    return grouped_impl(descs, n, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int icka_gemm_grouped_ex(const icka_gemm_desc* descs, int32_t n, const icka_slab_reduction* reds,
+                                    int32_t n_red, void* stream) {
+    if (n < 0 || n_red < 0 || (n > 0 && !descs) || (n_red > 0 && !reds) || n_red > MAX_RED) return ICKA_E_ARG;
+    for (int r = 0; r < n_red; ++r)
+        if (!reds[r].partials || reds[r].nslab <= 0 || reds[r].H <= 0 || reds[r].nslots <= 0 || reds[r].nslots > 4 ||
+            reds[r].slab_stride < (int64_t)reds[r].nslots * reds[r].H)
+            return ICKA_E_ARG;
+    return grouped_impl(descs, n, reds, n_red, (hipStream_t)stream);
+}
+
+static SlabRed to_red(const icka_slab_reduction& r) {
+    SlabRed o{};
+    o.partials = r.partials;
+    for (int k = 0; k < 4; ++k) o.out[k] = k < r.nslots ? r.out[k] : nullptr;
+    o.nslab = r.nslab; o.H = r.H; o.nslots = r.nslots; o.slab_stride = (int)r.slab_stride; o.accumulate = r.accumulate;
+    o.blocks = (r.nslots * r.H + 63) / 64;
+    return o;
+}
+
+static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_reduction* reds, int32_t n_red,
+                        hipStream_t st) {
+    bool reds_done = n_red == 0;
     int i = 0;
     while (i < n) {
         if (g_big && g_ws && descs[i].op == ICKA_GEMM_TN) {
@@ -1460,7 +1532,15 @@ extern "C" int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* s
             if (cnt >= 1 && total >= 64) {
                 for (int k = cnt; k <= MAX_GROUP; ++k) { ba.start[k] = total; ba.cs_start[k] = cs_total; }
                 for (int k = cnt; k < MAX_GROUP; ++k) ba.p[k] = ba.p[0];
-                hipLaunchKernelGGL(gemm_big_group_kernel, dim3(total + cs_total), dim3(512), 0, st, ba);
+                int red_total = 0;
+                for (int r = 0; r < MAX_RED; ++r) {
+                    ba.red_start[r] = red_total;
+                    if (!reds_done && r < n_red) { ba.red[r] = to_red(reds[r]); red_total += ba.red[r].blocks; }
+                    else ba.red[r] = SlabRed{};
+                }
+                ba.red_start[MAX_RED] = red_total;
+                reds_done = true;
+                hipLaunchKernelGGL(gemm_big_group_kernel, dim3(total + cs_total + red_total), dim3(512), 0, st, ba);
                 ICKA_CHECK_LAUNCH();
                 i += cnt;
                 continue;
@@ -1490,9 +1570,16 @@ extern "C" int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* s
             if (rc) return rc;
             i += cnt;
         } else {
-            const int rc = icka_gemm(&descs[i], stream);
+            const int rc = icka_gemm(&descs[i], (void*)st);
             if (rc) return rc;
             ++i;
+        }
+    }
+    if (!reds_done) {   // no 256x128 launch took them along: reduce the slabs with their own small launches
+        for (int r = 0; r < n_red; ++r) {
+            const SlabRed sr = to_red(reds[r]);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr.blocks), dim3(512), 0, st, sr);
+            ICKA_CHECK_LAUNCH();
         }
     }
     return 0;

@@ -641,6 +641,40 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
     return 0;
 }
 
+// Row + column halves only: the column slabs partials[nslab][SLOTS][H] (slot 0 = sum dy*xhat, slot 1 = sum dy) are
+// left for a later reduction (icka_gemm_grouped_ex folds it into the layer's weight-gradient launch).
+extern "C" int32_t icka_ln_bwd_nslab(int32_t M) {
+    int groups = (M + 31) / 32;
+    return groups > COL_GROUPS ? COL_GROUPS : groups;
+}
+extern "C" int32_t icka_ln_slab_slots(void) { return SLOTS; }
+
+extern "C" int icka_ln_bwd_slabs(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat,
+                                 const float* rstd, const float* gamma, void* dres, int64_t lddres, void* dx,
+                                 int64_t lddx, float* partials, int32_t M, int32_t H, float p_drop, uint64_t seed,
+                                 void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !partials) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
+    if (lddy % 8 || (dy2 && lddy2 % 8) || (dres && lddres % 8) || (dx && lddx % 8)) return ICKA_E_ALIGN;
+    if (!al16(dy) || (dy2 && !al16(dy2)) || !al16(xhat) || (dres && !al16(dres)) || (dx && !al16(dx)) || !al16(gamma))
+        return ICKA_E_ALIGN;
+    LnBwdArgs a{(const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2, (const bf16_t*)xhat, rstd, gamma,
+                (bf16_t*)dres, lddres, (bf16_t*)dx, lddx, partials, M, H, make_drop(p_drop, seed)};
+    const int groups = icka_ln_bwd_nslab(M);
+    const int nx = (H + 255) / 256;
+    const LnColsArgs c{nx, groups, (M + groups - 1) / groups};
+    const int grid = nx * groups + row_grid(M);
+    hipStream_t st = (hipStream_t)stream;
+    switch (pick_nch(H)) {
+        case 1: hipLaunchKernelGGL((ln_bwd_fused_kernel<1>), dim3(grid), dim3(256), 0, st, a, c); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_fused_kernel<2>), dim3(grid), dim3(256), 0, st, a, c); break;
+        case 3: hipLaunchKernelGGL((ln_bwd_fused_kernel<3>), dim3(grid), dim3(256), 0, st, a, c); break;
+        default: hipLaunchKernelGGL((ln_bwd_fused_kernel<4>), dim3(grid), dim3(256), 0, st, a, c); break;
+    }
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
                               const float* type, const float* gamma, const float* beta, void* y, float* y_f32,
                               void* xhat, float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab,

@@ -157,15 +157,40 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> 
     return out
 
 
-def gemm_grouped(descs) -> None:
-    """Launch several GEMMs (gemm_desc results) at once; same-layout fast-path problems share one launch."""
-    if not descs:
+def slab_reduction(partials: torch.Tensor, nslab: int, H: int, outs, accumulate: bool):
+    """Descriptor of  outs[slot][c] (+)= sum_b partials[b][slot][c]  over the slabs left by ln_bwd_slabs; rides on a
+    gemm_grouped launch (``reductions=``)."""
+    r = _lib.SlabReduction()
+    slots = _lib.load().icka_ln_slab_slots()
+    r.partials, r.slab_stride, r.nslab, r.H = partials.data_ptr(), slots * H, nslab, H
+    r.nslots, r.accumulate = len(outs), int(bool(accumulate))
+    for i, o in enumerate(outs):
+        _dev(o, "reduction output")
+        if o.dtype != F32 or o.numel() != H or not o.is_contiguous():
+            raise ValueError("reduction outputs must be contiguous f32 [H]")
+        r.out[i] = o.data_ptr()
+    r._keep = (partials,) + tuple(outs)
+    return r
+
+
+def gemm_grouped(descs, reductions=None) -> None:
+    """Launch several GEMMs (gemm_desc results) at once; same-layout fast-path problems share one launch.
+    ``reductions``: slab_reduction descriptors (at most 4) summed by extra blocks of the same launch."""
+    reductions = reductions or []
+    if not descs and not reductions:
         return
     lib = _lib.load()
-    arr = (GemmDesc * len(descs))(*descs)
-    if _PROF is not None:
+    arr = (GemmDesc * max(len(descs), 1))(*descs)
+    if _PROF is not None and descs:
         _PROF.append((1, arr, len(descs), list(descs)))
-    check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
+    if not reductions:
+        check(lib.icka_gemm_grouped(arr, len(descs), _stream()), "icka_gemm_grouped")
+        return
+    for i in range(0, len(reductions), 4):   # the ABI takes 4 per call; GEMMs go with the first chunk
+        chunk = reductions[i:i + 4]
+        rarr = (_lib.SlabReduction * len(chunk))(*chunk)
+        check(lib.icka_gemm_grouped_ex(arr if i == 0 else None, len(descs) if i == 0 else 0, rarr, len(chunk),
+                                       _stream()), "icka_gemm_grouped_ex")
 
 
 # ------------------------------------------------------------------------------------------------- LayerNorm
@@ -182,6 +207,18 @@ def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, y_f32=None, xhat=None,
                           y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), _ptr(y_f32), _ptr(xhat), _ptr(rstd),
                           M, H, eps, p_drop, seed, _stream()), "icka_ln_fwd")
     return y
+
+
+def ln_bwd_slabs(dy, xhat, rstd, gamma, partials, *, dy2=None, dres=None, dx=None, p_drop=0.0, seed=0) -> int:
+    """LayerNorm backward without the parameter-gradient finalize; returns the number of slabs left in ``partials``
+    (slot 0 -> dgamma, slot 1 -> dbeta) for a slab_reduction."""
+    lib = _lib.load()
+    _mat(dy, "dy"); _mat(xhat, "xhat")
+    M, H = dy.shape
+    check(lib.icka_ln_bwd_slabs(dy.data_ptr(), dy.stride(0), _ptr(dy2), _ld(dy2), xhat.data_ptr(), rstd.data_ptr(),
+                                gamma.data_ptr(), _ptr(dres), _ld(dres), _ptr(dx), _ld(dx), partials.data_ptr(), M, H,
+                                p_drop, seed, _stream()), "icka_ln_bwd_slabs")
+    return lib.icka_ln_bwd_nslab(M)
 
 
 def ln_bwd_workspace(H: int, device) -> torch.Tensor:

@@ -63,9 +63,22 @@ def _wgrad(A: ParamArena, dy, x, gout, beta: float, bias=None) -> None:
 
 
 def _flush_wgrad(A: ParamArena) -> None:
-    if A.pending_wgrad:
-        K.gemm_grouped([t[0] for t in A.pending_wgrad])
+    """One grouped launch for the block's queued weight gradients; the LayerNorm dgamma / dbeta slab reductions queued
+    by _ln_bwd_deferred are summed by extra blocks of the same launch."""
+    if A.pending_wgrad or A.pending_reductions:
+        K.gemm_grouped([t[0] for t in A.pending_wgrad], reductions=A.pending_reductions)
         A.pending_wgrad = []
+        A.pending_reductions = []
+
+
+def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres, dx, p_drop, seed) -> None:
+    """LayerNorm backward of a block: rows now, the parameter-gradient finalize with the block's weight-gradient launch
+    (saves one launch per LayerNorm).  ``tag`` keeps the slab workspaces of one block apart."""
+    H = dy.shape[1]
+    ws = A.workspace(tag, K._lib.load().icka_ln_bwd_workspace_floats(H))
+    acc = A.grad_beta((norm.weight, norm.bias)) > 0
+    nslab = K.ln_bwd_slabs(dy, xhat, rstd, norm.weight, ws, dy2=dy2, dres=dres, dx=dx, p_drop=p_drop, seed=seed)
+    A.pending_reductions.append(K.slab_reduction(ws, nslab, H, (A.g(norm.weight), A.g(norm.bias)), acc))
 
 
 # =============================================================================================== sub-blocks
@@ -113,12 +126,10 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     sa, so = att.self, att.output
     qkv, kvbuf, ctx, lse, xhat, rstd, seed_a, seed_h = saved
     M, H = x.shape
-    ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(H))
     dres = _empty(x, M, H)
     dao = _empty(x, M, H)
-    b_ln = A.grad_beta((so.LayerNorm.weight, so.LayerNorm.bias))
-    K.ln_bwd(dy, xhat, rstd, so.LayerNorm.weight, dy2=dy2, dres=dres, dx=dao, dgamma=A.g(so.LayerNorm.weight),
-             dbeta=A.g(so.LayerNorm.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h, accumulate=b_ln > 0)
+    _ln_bwd_deferred(A, "ln_attn", so.LayerNorm, dy, xhat, rstd, dy2=dy2, dres=dres, dx=dao, p_drop=d.p_hidden,
+                     seed=seed_h)
     # the dense bias gradient (column sums of dao) rides on the weight-gradient GEMM
     _wgrad(A, dao, ctx, A.g(so.dense.weight), A.grad_beta(so.dense.weight), bias=so.dense.bias)
     dctx = _empty(x, M, H)
@@ -178,12 +189,10 @@ def _ffn_block_bwd(A: ParamArena, layer, x, d: Dims, saved, dy, dy2=None):
     z, g, xhat, rstd, seed_h = saved
     M, H = x.shape
     I = z.shape[1]
-    ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(H))
     dres = _empty(x, M, H)
     dfo = _empty(x, M, H)
-    b_ln = A.grad_beta((out.LayerNorm.weight, out.LayerNorm.bias))
-    K.ln_bwd(dy, xhat, rstd, out.LayerNorm.weight, dy2=dy2, dres=dres, dx=dfo, dgamma=A.g(out.LayerNorm.weight),
-             dbeta=A.g(out.LayerNorm.bias), partials=ws, p_drop=d.p_hidden, seed=seed_h, accumulate=b_ln > 0)
+    _ln_bwd_deferred(A, "ln_ffn", out.LayerNorm, dy, xhat, rstd, dy2=dy2, dres=dres, dx=dfo, p_drop=d.p_hidden,
+                     seed=seed_h)
     _wgrad(A, dfo, g, A.g(out.dense.weight), A.grad_beta(out.dense.weight), bias=out.dense.bias)
     dz = _empty(x, M, I)
     K.gemm(K.GEMM_NN, dfo, A.w(out.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)

@@ -68,6 +68,16 @@ int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that
  * several partially-filling grids (the weight-gradient GEMMs of a layer) fill the chip together. */
 int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream);
+/* Same, plus up to 4 slab reductions  out[slot][c] (+)= sum_b partials[b*slab_stride + slot*H + c]  (b < nslab,
+ * slot < nslots <= 4, c < H; fixed summation order) that ride on the launch: the LayerNorm dgamma / dbeta slabs left
+ * by icka_ln_bwd_slabs are summed by extra blocks of the layer's weight-gradient grid instead of a launch of their
+ * own.  Without an eligible 256x128 launch (or with n == 0) they are reduced by small launches of their own. */
+typedef struct icka_slab_reduction {
+    const float* partials; int64_t slab_stride; int32_t nslab, H, nslots, accumulate;
+    float* out[4];
+} icka_slab_reduction;
+int icka_gemm_grouped_ex(const icka_gemm_desc* descs, int32_t n, const icka_slab_reduction* reds, int32_t n_red,
+                         void* stream);
 /* Tuning knob of the aligned fast path: depth of the LDS-DMA ring (2: 64 KiB LDS, two blocks per CU; 3 / 4: 96 /
  * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  Default 4. */
 int icka_gemm_set_ring(int nbuf);
@@ -111,6 +121,14 @@ int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, co
                 const float* gamma, void* dres, int64_t lddres, void* dx, int64_t lddx, float* dgamma, float* dbeta,
                 float* dbias, float* partials, int32_t M, int32_t H, float p_drop, uint64_t seed, int32_t accumulate,
                 void* stream);
+/* The same backward without the parameter-gradient finalize: only dres / dx and the column slabs
+ * partials[icka_ln_bwd_nslab(M)][icka_ln_slab_slots()][H] (slot 0: sum dy*xhat -> dgamma, slot 1: sum dy -> dbeta),
+ * to be summed later by icka_gemm_grouped_ex. */
+int icka_ln_bwd_slabs(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat, const float* rstd,
+                      const float* gamma, void* dres, int64_t lddres, void* dx, int64_t lddx, float* partials, int32_t M,
+                      int32_t H, float p_drop, uint64_t seed, void* stream);
+int32_t icka_ln_bwd_nslab(int32_t M);
+int32_t icka_ln_slab_slots(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * BertEmbeddings.forward (:398-412): y = dropout(LayerNorm(word[ids] + pos[arange(S)] + type[tt])).

@@ -36,9 +36,10 @@ def test_gemm_desc_layout_matches_c_struct():
     import ctypes
     import subprocess
     import tempfile
-    from icka_amd._lib import GemmDesc
-    src = '#include <stdio.h>\n#include "icka_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(icka_gemm_desc),' \
-          ' __builtin_offsetof(icka_gemm_desc, bias), __builtin_offsetof(icka_gemm_desc, epilogue));return 0;}\n'
+    from icka_amd._lib import GemmDesc, SlabReduction
+    src = '#include <stdio.h>\n#include "icka_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu", sizeof(icka_gemm_desc),' \
+          ' __builtin_offsetof(icka_gemm_desc, bias), __builtin_offsetof(icka_gemm_desc, epilogue),' \
+          ' sizeof(icka_slab_reduction), __builtin_offsetof(icka_slab_reduction, out));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")],
@@ -47,6 +48,8 @@ def test_gemm_desc_layout_matches_c_struct():
     assert int(out[0]) == ctypes.sizeof(GemmDesc)
     assert int(out[1]) == GemmDesc.bias.offset
     assert int(out[2]) == GemmDesc.epilogue.offset
+    assert int(out[3]) == ctypes.sizeof(SlabReduction)
+    assert int(out[4]) == SlabReduction.out.offset
 
 
 def test_no_cpu_path():

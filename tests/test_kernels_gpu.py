@@ -214,13 +214,30 @@ def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
                                  colsum_accumulate=(i == 2)))
         keep.append((A, B)); outs.append(out); css.append(cs)
         refs.append(A.float().t() @ B.float() + (7.0 if i == 3 else 0.0))
-    k.gemm_grouped(descs)
+    # two LayerNorm slab reductions ride on the launch (dgamma / dbeta of the layer's two LayerNorms)
+    slots = lib.icka_ln_slab_slots()
+    reds, red_ref, red_out = [], [], []
+    for r in range(2):
+        nslab = 128 if r == 0 else 7
+        part = rnd(nslab, slots, H, seed=60 + r, dtype=F32)
+        o = [torch.full((H,), 5.0, dtype=F32, device="cuda") for _ in range(2)]
+        reds.append(k.slab_reduction(part, nslab, H, o, accumulate=(r == 1)))
+        red_ref.append([part[:, sl].sum(0) + (5.0 if r == 1 else 0.0) for sl in range(2)])
+        red_out.append(o)
+    k.gemm_grouped(descs, reductions=reds)
     for o, r in zip(outs, refs):
         assert rel_err(o, r) < 1e-4
     for i, cs in enumerate(css):
         if cs is not None:
             ref = keep[i][0].float().sum(0) + (3.0 if i == 2 else 0.0)
             assert rel_err(cs, ref) < 1e-4, i
+    for o, r in zip(red_out, red_ref):
+        assert rel_err(o[0], r[0]) < 1e-5 and rel_err(o[1], r[1]) < 1e-5
+    # reductions alone (no GEMM to ride on): reduced by their own launches
+    alone = [torch.zeros(H, dtype=F32, device="cuda") for _ in range(2)]
+    part = rnd(33, slots, H, seed=70, dtype=F32)
+    k.gemm_grouped([], reductions=[k.slab_reduction(part, 33, H, alone, accumulate=False)])
+    assert rel_err(alone[0], part[:, 0].sum(0)) < 1e-5 and rel_err(alone[1], part[:, 1].sum(0)) < 1e-5
 
 
 def test_gemm_bad_args():
