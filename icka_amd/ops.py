@@ -325,8 +325,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.epi == K.EPI_TANH:
             raise NotImplementedError("backward through the tanh pooler is outside the hot path (pooled output only "
                                       "feeds the reference's contrastive loss, SURVEY.md section 8a a9)")
-        K.gemm(K.GEMM_TN, dyv, x, A.g(lin.weight), beta=A.grad_beta(lin.weight))
-        if lin.bias is not None:
+        fused = lin.bias is not None and N % 128 == 0 and x.shape[1] % 128 == 0 and M % 64 == 0
+        K.gemm(K.GEMM_TN, dyv, x, A.g(lin.weight), beta=A.grad_beta(lin.weight),
+               colsum_out=A.g(lin.bias) if fused else None,
+               colsum_accumulate=fused and A.grad_beta(lin.bias) > 0)   # bias gradient inside the wgrad GEMM
+        if lin.bias is not None and not fused:
             csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(N))
             K.colsum(dyv, A.g(lin.bias), csw, accumulate=A.grad_beta(lin.bias) > 0)
         dx = None
@@ -404,10 +407,11 @@ class GatedHeadFn(torch.autograd.Function):
         du = torch.empty_like(dseq_c)
         dcross_d = torch.empty_like(dseq_c)
         K.gate_bwd(dgated, gate, cross, du, dcross_d)
-        K.gemm(K.GEMM_TN, du, seq, A.g(head.Gate_text.weight), beta=A.grad_beta(head.Gate_text.weight))
-        K.gemm(K.GEMM_TN, du, cross, A.g(head.Gate_image.weight), beta=A.grad_beta(head.Gate_image.weight))
-        K.colsum(du, A.g(head.Gate_text.bias), csw, accumulate=A.grad_beta(head.Gate_text.bias) > 0)
-        K.colsum(du, A.g(head.Gate_image.bias), csw, accumulate=A.grad_beta(head.Gate_image.bias) > 0)
+        # both gate weight gradients (and their bias gradients = column sums of du) in one grouped launch
+        _wgrad(A, du, seq, A.g(head.Gate_text.weight), A.grad_beta(head.Gate_text.weight), bias=head.Gate_text.bias)
+        _wgrad(A, du, cross, A.g(head.Gate_image.weight), A.grad_beta(head.Gate_image.weight),
+               bias=head.Gate_image.bias)
+        _flush_wgrad(A)
         dseq = torch.empty_like(dseq_c)
         dcross = torch.empty_like(dseq_c)
         K.gemm(K.GEMM_NN, du, A.w(head.Gate_text.weight), dseq, epilogue=K.EPI_ADD, aux=dseq_c)
