@@ -73,6 +73,11 @@ PROTOTYPES = {
     "icka_attn_fwd_fp8": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_set_whole_head": (None, [c_i32]),
+    "icka_cls_head_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_cls_head_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                  c_vp]),
+    "icka_cls_head_bwd_slabs": (c_i32, [c_i32]),
+    "icka_cls_head_slab_floats": (c_i64, [c_i32, c_i32]),
     "icka_lstm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_lstm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_transpose_bf16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

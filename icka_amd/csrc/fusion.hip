@@ -269,3 +269,225 @@ extern "C" int icka_crs_bwd(const float* dcrs, const void* seq, int64_t lds, con
     ICKA_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ===================================================================================================================
+// Classifier of the gated head (cl_modeling.py:1371: logits = classifier(cat(seq, Gate*cross))), C <= 16 labels.
+// A 13-wide output is a poor fit for 128x128 MFMA tiles (the general GEMM path spent ~120 us per step on it: forward
+// 16 us + split-K prescale, two K = 13 dgrad GEMMs of 22 us, two M = 13 wgrad GEMMs + prescales, a column-sum pair,
+// and the gate backward pass); here it is two HBM-bound kernels:
+//   forward : a wave per token row, lanes over 16-byte chunks of [seq | gated], W (bf16 [C, 2H]) in LDS
+//   backward: a block per 32 tokens, a thread per 16-byte chunk of the 2H columns holding W[:, chunk] and dW[:, chunk]
+//             in registers: dseq_c, and -- for the gated half -- the gate backward (du, dcross) computed in place of
+//             dgated; dW / db leave as one slab per block, summed by a slab reduction (icka_gemm_grouped_ex).
+namespace {
+
+constexpr int CLS_TB = 16;      // tokens per backward block
+constexpr int CLS_MAXC = 16;
+
+__device__ __forceinline__ void cls_ld8(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+}
+__device__ __forceinline__ void cls_st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+}
+
+__global__ __launch_bounds__(256) void cls_head_fwd_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict__ gated,
+                                                           const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                           float* __restrict__ logits, int M, int H, int C) {
+    extern __shared__ __attribute__((aligned(16))) char cls_smem[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(cls_smem);   // [C][2H]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = (2 * H) >> 3, hch = H >> 3;
+    for (int i = tid; i < C * nch; i += 256)
+        *reinterpret_cast<u32x4*>(sW + (int64_t)i * 8) = *reinterpret_cast<const u32x4*>(W + (int64_t)i * 8);
+    __syncthreads();
+    const int nw = gridDim.x * 4;
+    for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < M; row0 += 2 * nw) {
+        // two token rows per pass; their (up to 4 per lane) 16-byte chunks are all requested before any use
+        u32x4 xr[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = lane + 64 * i, row = row0 + r;
+                xr[r][i] = u32x4{0u, 0u, 0u, 0u};
+                if (j < nch && row < M)
+                    xr[r][i] = *reinterpret_cast<const u32x4*>(j < hch ? seq + (int64_t)row * H + j * 8
+                                                                       : gated + (int64_t)row * H + (j - hch) * 8);
+            }
+        float acc[2][CLS_MAXC];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS_MAXC; ++c) acc[r][c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nch) {
+#pragma unroll
+                for (int c = 0; c < CLS_MAXC; ++c) {
+                    if (c < C) {
+                        float w[8];
+                        cls_ld8(sW + (int64_t)c * 2 * H + j * 8, w);
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const bf16x8 xv = as_bf16x8(xr[r][i]);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[r][c] += bf2f(xv[e]) * w[e];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int c = 0; c < CLS_MAXC; ++c)
+                if (c < C) acc[r][c] = wave_sum(acc[r][c]);
+            if (lane < C && row0 + r < M) {
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < CLS_MAXC; ++c) v = lane == c ? acc[r][c] : v;
+                logits[(int64_t)(row0 + r) * C + lane] = v + (bias ? bias[lane] : 0.f);
+            }
+        }
+    }
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void cls_head_bwd_kernel(const bf16_t* __restrict__ dl, int64_t ldd,
+                                                           const bf16_t* __restrict__ seq, const bf16_t* __restrict__ gated,
+                                                           const bf16_t* __restrict__ gate, const bf16_t* __restrict__ cross,
+                                                           const bf16_t* __restrict__ W, bf16_t* __restrict__ dseq,
+                                                           bf16_t* __restrict__ du, bf16_t* __restrict__ dcross,
+                                                           float* __restrict__ partials, int M, int H, int C) {
+    __shared__ float s_dl[CLS_TB][CLS_MAXC];
+    const int tid = threadIdx.x;
+    const int nch = (2 * H) >> 3, hch = H >> 3;
+    const int t0 = blockIdx.x * CLS_TB;
+    const int nt = M - t0 < CLS_TB ? M - t0 : CLS_TB;
+    for (int i = tid; i < CLS_TB * CLS_MAXC; i += 256) {
+        const int t = i / CLS_MAXC, c = i % CLS_MAXC;
+        s_dl[t][c] = (t < nt && c < C) ? bf2f(dl[(int64_t)(t0 + t) * ldd + c]) : 0.f;
+    }
+    __syncthreads();
+    const int64_t slab = (int64_t)C * 2 * H + CLS_MAXC;
+    float* myslab = partials + (int64_t)blockIdx.x * slab;
+    if (tid < CLS_MAXC) {   // bias gradient of this block's tokens
+        float s = 0.f;
+        for (int t = 0; t < nt; ++t) s += s_dl[t][tid];
+        myslab[(int64_t)C * 2 * H + tid] = s;
+    }
+    const int j = tid;
+    if (j >= nch) return;
+    const bool second = j >= hch;
+    const int h = (second ? j - hch : j) * 8;
+    float Wr[CC][8], dW[CC][8];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        if (c < C) cls_ld8(W + (int64_t)c * 2 * H + j * 8, Wr[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dW[c][e] = 0.f; if (c >= C) Wr[c][e] = 0.f; }
+    }
+    for (int tb = 0; tb < nt; tb += 4) {
+        // 4 tokens per pass: their x (and gate / cross) chunks are requested before the arithmetic of the first
+        u32x4 xr[4], gr[4], cr4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = t0 + (tb + u < nt ? tb + u : nt - 1);
+            xr[u] = *reinterpret_cast<const u32x4*>((second ? gated : seq) + row * H + h);
+            if (second) {
+                gr[u] = *reinterpret_cast<const u32x4*>(gate + row * H + h);
+                cr4[u] = *reinterpret_cast<const u32x4*>(cross + row * H + h);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tb + u;
+            if (t >= nt) break;
+            const int64_t row = t0 + t;
+            const bf16x8 xv = as_bf16x8(xr[u]);
+            float x[8], dx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[e] = bf2f(xv[e]); dx[e] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float d = s_dl[t][c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dx[e] += d * Wr[c][e]; dW[c][e] += d * x[e]; }
+            }
+            if (!second) {
+                cls_st8(dseq + row * H + h, dx);
+            } else {   // dx is d(gate*cross): gate backward in place (cl_modeling.py:1363-1367)
+                const bf16x8 gv = as_bf16x8(gr[u]), cv = as_bf16x8(cr4[u]);
+                float uu[8], dc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = bf2f(gv[e]);
+                    uu[e] = dx[e] * bf2f(cv[e]) * g * (1.f - g);
+                    dc[e] = dx[e] * g;
+                }
+                cls_st8(du + row * H + h, uu);
+                cls_st8(dcross + row * H + h, dc);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+        if (c < C) {
+            float* p = myslab + (int64_t)c * 2 * H + j * 8;
+            *reinterpret_cast<f32x4*>(p) = f32x4{dW[c][0], dW[c][1], dW[c][2], dW[c][3]};
+            *reinterpret_cast<f32x4*>(p + 4) = f32x4{dW[c][4], dW[c][5], dW[c][6], dW[c][7]};
+        }
+}
+
+}  // namespace
+
+extern "C" int32_t icka_cls_head_bwd_slabs(int32_t M) { return (M + CLS_TB - 1) / CLS_TB; }
+extern "C" int64_t icka_cls_head_slab_floats(int32_t H, int32_t C) { return (int64_t)C * 2 * H + CLS_MAXC; }
+
+extern "C" int icka_cls_head_fwd(const void* seq, const void* gated, const void* W, const float* bias, float* logits,
+                                 int32_t M, int32_t H, int32_t C, void* stream) {
+    if (!seq || !gated || !W || !logits) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8 || C <= 0 || C > CLS_MAXC || (int64_t)C * 2 * H * 2 > 64 * 1024) return ICKA_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(seq) | reinterpret_cast<uintptr_t>(gated) | reinterpret_cast<uintptr_t>(W)) & 15)
+        return ICKA_E_ALIGN;
+    int grid = (M + 7) / 8;   // 4 waves x 2 rows per pass
+    grid = grid > 512 ? 512 : grid;
+    hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(grid), dim3(256), (size_t)C * 2 * H * 2, (hipStream_t)stream,
+                       (const bf16_t*)seq, (const bf16_t*)gated, (const bf16_t*)W, bias, logits, M, H, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_cls_head_bwd(const void* dl, int64_t ldd, const void* seq, const void* gated, const void* gate,
+                                 const void* cross, const void* W, void* dseq, void* du, void* dcross, float* partials,
+                                 int32_t M, int32_t H, int32_t C, void* stream) {
+    if (!dl || !seq || !gated || !gate || !cross || !W || !dseq || !du || !dcross || !partials) return ICKA_E_ARG;
+    if (M <= 0 || H <= 0 || H % 8 || C <= 0 || C > CLS_MAXC || 2 * H / 8 > 256 || ldd < C) return ICKA_E_SHAPE;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(seq) | reinterpret_cast<uintptr_t>(gated) |
+                         reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(cross) |
+                         reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(dseq) |
+                         reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(dcross) |
+                         reinterpret_cast<uintptr_t>(partials);
+    if (al & 15) return ICKA_E_ALIGN;
+    const int grid = icka_cls_head_bwd_slabs(M);
+    if (C <= 13)   // the reference's label sets have 13 (cl_modeling comments) or 15 tags: 13 saves 48 registers
+        hipLaunchKernelGGL((cls_head_bwd_kernel<13>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dl, ldd, (const bf16_t*)seq, (const bf16_t*)gated, (const bf16_t*)gate,
+                           (const bf16_t*)cross, (const bf16_t*)W, (bf16_t*)dseq, (bf16_t*)du, (bf16_t*)dcross,
+                           partials, M, H, C);
+    else
+        hipLaunchKernelGGL((cls_head_bwd_kernel<CLS_MAXC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dl, ldd, (const bf16_t*)seq, (const bf16_t*)gated, (const bf16_t*)gate,
+                           (const bf16_t*)cross, (const bf16_t*)W, (bf16_t*)dseq, (bf16_t*)du, (bf16_t*)dcross,
+                           partials, M, H, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}

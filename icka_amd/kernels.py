@@ -157,20 +157,53 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> 
     return out
 
 
-def slab_reduction(partials: torch.Tensor, nslab: int, H: int, outs, accumulate: bool):
-    """Descriptor of  outs[slot][c] (+)= sum_b partials[b][slot][c]  over the slabs left by ln_bwd_slabs; rides on a
-    gemm_grouped launch (``reductions=``)."""
+def slab_reduction(partials: torch.Tensor, nslab: int, H: int, outs, accumulate: bool, slab_stride: int = 0,
+                   offset: int = 0):
+    """Descriptor of  outs[slot][c] (+)= sum_b partials[offset + b*slab_stride + slot*H + c]  (c < H); rides on a
+    gemm_grouped launch (``reductions=``).  Default stride: the LayerNorm slab layout left by ln_bwd_slabs."""
     r = _lib.SlabReduction()
-    slots = _lib.load().icka_ln_slab_slots()
-    r.partials, r.slab_stride, r.nslab, r.H = partials.data_ptr(), slots * H, nslab, H
+    if slab_stride == 0:
+        slab_stride = _lib.load().icka_ln_slab_slots() * H
+    r.partials, r.slab_stride, r.nslab, r.H = partials.data_ptr() + 4 * offset, slab_stride, nslab, H
     r.nslots, r.accumulate = len(outs), int(bool(accumulate))
     for i, o in enumerate(outs):
         _dev(o, "reduction output")
         if o.dtype != F32 or o.numel() != H or not o.is_contiguous():
-            raise ValueError("reduction outputs must be contiguous f32 [H]")
+            raise ValueError("reduction outputs must be contiguous f32 with %d elements" % H)
         r.out[i] = o.data_ptr()
     r._keep = (partials,) + tuple(outs)
     return r
+
+
+def cls_head_fwd(seq, gated, W, bias, logits):
+    """logits f32 [M,C] = [seq | gated] . W^T + bias (W bf16 [C, 2H])."""
+    _mat(seq, "seq"); _mat(gated, "gated")
+    M, H = seq.shape
+    Cn = W.shape[0]
+    if not (seq.is_contiguous() and gated.is_contiguous() and W.is_contiguous() and logits.is_contiguous()):
+        raise ValueError("cls_head_fwd: contiguous operands")
+    if W.dtype != BF16 or tuple(W.shape) != (Cn, 2 * H) or logits.dtype != F32 or tuple(logits.shape) != (M, Cn):
+        raise ValueError("cls_head_fwd: W bf16 [C,2H], logits f32 [M,C]")
+    check(_lib.load().icka_cls_head_fwd(seq.data_ptr(), gated.data_ptr(), W.data_ptr(), _ptr(bias), logits.data_ptr(),
+                                        M, H, Cn, _stream()), "icka_cls_head_fwd")
+    return logits
+
+
+def cls_head_bwd(dl, seq, gated, gate, cross, W, dseq, du, dcross, partials):
+    """Returns the number of slabs written to ``partials`` (see icka_cls_head_bwd)."""
+    M, H = seq.shape
+    Cn = W.shape[0]
+    for n, t in (("seq", seq), ("gated", gated), ("gate", gate), ("cross", cross), ("dseq", dseq), ("du", du),
+                 ("dcross", dcross)):
+        _mat(t, n)
+        if not t.is_contiguous() or tuple(t.shape) != (M, H):
+            raise ValueError("%s must be contiguous bf16 [M,H]" % n)
+    _mat(dl, "dl")
+    lib = _lib.load()
+    check(lib.icka_cls_head_bwd(dl.data_ptr(), dl.stride(0), seq.data_ptr(), gated.data_ptr(), gate.data_ptr(),
+                                cross.data_ptr(), W.data_ptr(), dseq.data_ptr(), du.data_ptr(), dcross.data_ptr(),
+                                partials.data_ptr(), M, H, Cn, _stream()), "icka_cls_head_bwd")
+    return lib.icka_cls_head_bwd_slabs(M)
 
 
 def gemm_grouped(descs, reductions=None) -> None:

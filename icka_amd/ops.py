@@ -374,7 +374,11 @@ class GatedHeadFn(torch.autograd.Function):
                bias=head.Gate_text.bias, bias2=head.Gate_image.bias, epilogue=K.EPI_GATE, aux=cross, out2=gate)
         Wc = A.w(head.classifier.weight)
         logits = torch.empty(M, C, dtype=F32, device=seq.device)
-        K.gemm(K.GEMM_NT, seq, Wc[:, :H], logits, A2=gated, B2=Wc[:, H:], bias=head.classifier.bias)
+        ctx.skinny = C <= 16 and H % 8 == 0 and 2 * H // 8 <= 256 and C * 2 * H * 2 <= 64 * 1024
+        if ctx.skinny:   # HBM-bound kernels for the 13-wide output (see icka_cls_head_fwd)
+            K.cls_head_fwd(seq, gated, Wc, head.classifier.bias, logits)
+        else:
+            K.gemm(K.GEMM_NT, seq, Wc[:, :H], logits, A2=gated, B2=Wc[:, H:], bias=head.classifier.bias)
         ctx.head, ctx.A = head, A
         ctx.save_for_backward(seq, cross, gate, gated)
         return logits
@@ -393,6 +397,21 @@ class GatedHeadFn(torch.autograd.Function):
                                    (dlogits if dlogits.stride(1) == 1 else dlogits.contiguous()), buf)
             dl = buf[:, :C]
         cls = head.classifier
+        if ctx.skinny:
+            # classifier dgrad + gate backward + dW/db slabs in one launch; the slabs are summed by extra blocks of
+            # the gate weight-gradient launch below
+            lib = K._lib.load()
+            nslab, sf = lib.icka_cls_head_bwd_slabs(M), lib.icka_cls_head_slab_floats(H, C)
+            ws = A.workspace("cls_head", nslab * sf)
+            dseq_c = torch.empty(M, H, dtype=BF16, device=seq.device)
+            du = torch.empty_like(dseq_c)
+            dcross_d = torch.empty_like(dseq_c)
+            K.cls_head_bwd(dl, seq, gated, gate, cross, A.w(cls.weight), dseq_c, du, dcross_d, ws)
+            A.pending_reductions.append(K.slab_reduction(ws, nslab, C * 2 * H, (A.g(cls.weight).view(-1),),
+                                                         A.grad_beta(cls.weight) > 0, slab_stride=sf))
+            A.pending_reductions.append(K.slab_reduction(ws, nslab, C, (A.g(cls.bias),), A.grad_beta(cls.bias) > 0,
+                                                         slab_stride=sf, offset=C * 2 * H))
+            return GatedHeadFn._gate_tail(A, head, seq, cross, du, dseq_c, dcross_d)
         gW = A.g(cls.weight)
         beta = A.grad_beta(cls.weight)
         K.gemm(K.GEMM_TN, dl, seq, gW[:, :H], beta=beta)
@@ -407,6 +426,10 @@ class GatedHeadFn(torch.autograd.Function):
         du = torch.empty_like(dseq_c)
         dcross_d = torch.empty_like(dseq_c)
         K.gate_bwd(dgated, gate, cross, du, dcross_d)
+        return GatedHeadFn._gate_tail(A, head, seq, cross, du, dseq_c, dcross_d)
+
+    @staticmethod
+    def _gate_tail(A, head, seq, cross, du, dseq_c, dcross_d):
         # both gate weight gradients (and their bias gradients = column sums of du) in one grouped launch
         _wgrad(A, du, seq, A.g(head.Gate_text.weight), A.grad_beta(head.Gate_text.weight), bias=head.Gate_text.bias)
         _wgrad(A, du, cross, A.g(head.Gate_image.weight), A.grad_beta(head.Gate_image.weight),

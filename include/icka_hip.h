@@ -203,6 +203,21 @@ int64_t icka_colsum_workspace_floats(int32_t N);
 int icka_gate_bwd(const void* dout, int64_t lddout, const void* g, const void* cross, int64_t ldcross,
                   const void* dcross_in, int64_t lddci, void* du, void* dcross, int64_t lddc, int32_t M, int32_t H,
                   void* stream);
+/* Classifier of the gated head, C <= 16 labels (cl_modeling.py:1371 `logits = self.classifier(cat(seq, Gate*cross))`),
+ * as two HBM-bound kernels instead of 128x128-tile GEMMs on a 13-wide output:
+ *   fwd: logits f32 [M,C] = [seq | gated] . W^T + bias      (seq, gated bf16 [M,H] contiguous; W bf16 [C,2H])
+ *   bwd: dl bf16 [M, ldd >= C] -> dseq bf16 [M,H] (gradient w.r.t. seq through the classifier) and, for the gated
+ *        half, the gate backward applied in place: du = dgated*cross*g*(1-g), dcross = dgated*g (as icka_gate_bwd);
+ *        dW / db leave as icka_cls_head_bwd_slabs(M) slabs of icka_cls_head_slab_floats(H,C) floats each
+ *        ([C*2H] weight part, then [16] bias part), to be summed by icka_gemm_grouped_ex slab reductions.
+ * Needs 2H/8 <= 256 (H <= 1024). */
+int icka_cls_head_fwd(const void* seq, const void* gated, const void* W, const float* bias, float* logits, int32_t M,
+                      int32_t H, int32_t C, void* stream);
+int icka_cls_head_bwd(const void* dl, int64_t ldd, const void* seq, const void* gated, const void* gate,
+                      const void* cross, const void* W, void* dseq, void* du, void* dcross, float* partials, int32_t M,
+                      int32_t H, int32_t C, void* stream);
+int32_t icka_cls_head_bwd_slabs(int32_t M);
+int64_t icka_cls_head_slab_floats(int32_t H, int32_t C);
 /* Per-sample gates (fusion.hip).  a / c / out are token-major bf16 [B*S, H] with row strides.
  *  mode 0 (Cross_Modal_Interaction_Module.py:1029-1036): g_b = sigmoid(gate[b]);  out = g_b*a + (1-g_b)*c
  *  mode 1 (gate_cl_modeling.py:1369-1373): g_b = softmax(gate[b,0..1])[1];        out = g_b*a   (c = NULL)
