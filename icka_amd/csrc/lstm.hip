@@ -210,6 +210,59 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         if (c0 + i < C && r0 + tx < R) out[base + (int64_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// y[M <= 64, N] = act(x . W^T + bias) for a handful of rows (the BERT pooler: tanh(dense(hidden[:, 0])), 32 rows):
+// the same operands-from-L2 MFMA scheme as the recurrence -- a block per 16 output columns, the K reduction split over
+// its 4 waves, every 16-byte load issued before the MFMAs.  (128x128 GEMM tiles on 32 rows are a latency chain of
+// 12 k-tiles on 6 CUs: 35 us.)
+struct SmallLinArgs {
+    const bf16_t* x; int64_t ldx; const bf16_t* W; const float* bias; bf16_t* y; int64_t ldy;
+    int M, N, K, act;   // act: 0 none, 1 tanh
+};
+template <int NRT>
+__global__ __launch_bounds__(256) void linear_small_kernel(const SmallLinArgs a) {
+    __shared__ float s_p[4][NRT * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16, i15 = lane & 15, g4 = lane >> 4;
+    const int kq = a.K / 4;   // K % 128 == 0
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wrow = a.W + (int64_t)(n0 + i15) * a.K + wave * kq + 8 * g4;
+    const bf16_t* xbase = a.x + wave * kq + 8 * g4;
+    const bool nok = n0 + i15 < a.N;
+    for (int kb = 0; kb < kq; kb += 256) {
+        bf16x8 wf[8], xf[NRT][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k0 = kb + 32 * u;
+            const bool kok = k0 < kq;
+            wf[u] = frag16(wrow + k0, kok && nok);
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const int m = 16 * r + i15;
+                xf[r][u] = frag16(xbase + (int64_t)m * a.ldx + k0, kok && m < a.M);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], xf[r][u], acc[r]);   // D[i = column 4*g4+q][j = row i15]
+    }
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_p[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
+    __syncthreads();
+    for (int p = tid; p < NRT * 256; p += 256) {
+        const int m = p >> 4, u = p & 15;
+        if (m >= a.M || n0 + u >= a.N) continue;
+        float v = s_p[0][m][u] + s_p[1][m][u] + s_p[2][m][u] + s_p[3][m][u] + (a.bias ? a.bias[n0 + u] : 0.f);
+        if (a.act == 1) v = tanhf(v);
+        a.y[(int64_t)m * a.ldy + n0 + u] = f2bf(v);
+    }
+}
+
 inline int lstm_check(int B, int S, int H) {
     if (B <= 0 || S <= 0 || H <= 0) return ICKA_E_SHAPE;
     if (B > 16 * MAX_RT || H % 32 != 0) return ICKA_E_SHAPE;
@@ -264,6 +317,21 @@ extern "C" int icka_transpose_bf16(const void* in, void* out, int32_t batch, int
     if (batch <= 0 || R <= 0 || C <= 0) return ICKA_E_SHAPE;
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, (bf16_t*)out, R, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_linear_small_m(const void* x, int64_t ldx, const void* W, const float* bias, void* y, int64_t ldy,
+                                   int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    if (!x || !W || !y) return ICKA_E_ARG;
+    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 128 != 0 || act < 0 || act > 1) return ICKA_E_SHAPE;
+    if (ldx % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15)) return ICKA_E_ALIGN;
+    const SmallLinArgs a{(const bf16_t*)x, ldx, (const bf16_t*)W, bias, (bf16_t*)y, ldy, M, N, K, act};
+    const int grid = (N + 15) / 16, nrt = (M + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (nrt == 1) hipLaunchKernelGGL((linear_small_kernel<1>), dim3(grid), dim3(256), 0, st, a);
+    else if (nrt == 2) hipLaunchKernelGGL((linear_small_kernel<2>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((linear_small_kernel<4>), dim3(grid), dim3(256), 0, st, a);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -357,6 +357,18 @@ def lstm_bwd(dy, w_hh_t, act, c_all, dgates, dc_carry, B, S, H):
           "icka_lstm_bwd")
 
 
+def linear_small_m(x, W, bias, y, act: int = 0):
+    """y bf16 [M<=64, N] = act(x . W^T + bias); x may be a strided row view (the pooler's first-token rows)."""
+    _mat(x, "x"); _mat(W, "W"); _mat(y, "y")
+    M, Kd = x.shape
+    N = W.shape[0]
+    if W.shape[1] != Kd or tuple(y.shape) != (M, N) or not W.is_contiguous():
+        raise ValueError("linear_small_m: W [N,K] contiguous, y [M,N]")
+    check(_lib.load().icka_linear_small_m(x.data_ptr(), x.stride(0), W.data_ptr(), _ptr(bias), y.data_ptr(), y.stride(0),
+                                          M, N, Kd, act, _stream()), "icka_linear_small_m")
+    return y
+
+
 def transpose_bf16(src, dst, batch, R, Cn):
     _dev(src, "src"); _dev(dst, "dst")
     if src.dtype != BF16 or dst.dtype != BF16 or src.numel() != batch * R * Cn or dst.numel() != src.numel() \

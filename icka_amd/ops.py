@@ -304,7 +304,12 @@ class LinearFn(torch.autograd.Function):
         M = x.shape[0]
         N = lin.weight.shape[0]
         y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x.device)
-        K.gemm(K.GEMM_NT, x, A.w(lin.weight), y, bias=lin.bias, epilogue=epilogue)
+        if M <= 64 and not out_f32 and x.shape[1] % 128 == 0 and x.stride(0) % 8 == 0 and \
+                epilogue in (K.EPI_NONE, K.EPI_TANH):
+            # a handful of rows (the pooler): operands-from-L2 kernel instead of 128x128 tiles on 32 rows
+            K.linear_small_m(x, A.w(lin.weight), lin.bias, y, act=1 if epilogue == K.EPI_TANH else 0)
+        else:
+            K.gemm(K.GEMM_NT, x, A.w(lin.weight), y, bias=lin.bias, epilogue=epilogue)
         ctx.lin, ctx.A, ctx.epi = lin, A, epilogue
         ctx.need_dx = x.requires_grad
         ctx.save_for_backward(x, y if epilogue == K.EPI_TANH else None)

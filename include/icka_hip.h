@@ -281,6 +281,10 @@ int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh, void* y, 
                   int32_t B, int32_t S, int32_t H, void* stream);
 int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const float* c_all, void* dgates, int64_t ldg,
                   float* dc_carry, int32_t B, int32_t S, int32_t H, void* stream);
+/* y bf16 [M <= 64, N] = act(x . W^T + bias) for a handful of rows (BertPooler.forward :675-681: tanh(dense(h[:, 0])),
+ * 32 rows at c2): x bf16 rows with stride ldx, W bf16 [N,K], K % 128 == 0; act 0 = none, 1 = tanh. */
+int icka_linear_small_m(const void* x, int64_t ldx, const void* W, const float* bias, void* y, int64_t ldy, int32_t M,
+                        int32_t N, int32_t K, int32_t act, void* stream);
 /* out[b][c][r] = in[b][r][c] for bf16 matrices (batch of [R,C]). */
 int icka_transpose_bf16(const void* in, void* out, int32_t batch, int32_t R, int32_t C, void* stream);
 /* Dropout nonce for hipGraph replay.  Every dropout-bearing kernel XORs two DEVICE words into its (by-value) seed at

@@ -502,3 +502,19 @@ def test_attention_fp8_forward(B, h, Sq, Skv, p):
     with pytest.raises(RuntimeError):
         k.attn_fwd(rnd(200, 64), rnd(200, 64), rnd(200, 64), torch.zeros(1, 200, dtype=F32, device="cuda"),
                    torch.empty(200, 64, dtype=BF16, device="cuda"), None, 1, 1, 200, 200, fp8=True)
+
+
+@pytest.mark.parametrize("M,N,Kd,act", [(32, 768, 768, 1), (1, 100, 256, 0), (50, 1024, 1024, 1), (64, 16, 128, 0)])
+def test_linear_small_m(M, N, Kd, act):
+    """A handful of rows through the operands-from-L2 kernel (BertPooler: tanh(dense(hidden[:, 0])))."""
+    k = _k()
+    S = 7
+    full = rnd(M * S, Kd, seed=1, scale=0.5)
+    x = full.view(M, S, Kd)[:, 0]                 # strided first-token rows, read in place
+    W, bias = rnd(N, Kd, seed=2, scale=0.05), rnd(N, seed=3, dtype=F32)
+    y = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.linear_small_m(x, W, bias, y, act=act)
+    ref = x.float() @ W.float().t() + bias
+    if act:
+        ref = torch.tanh(ref)
+    assert rel_err(y, ref) < 1e-2
