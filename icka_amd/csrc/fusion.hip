@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                            float* __restrict__ logits, int M, int H, int C) {
     extern __shared__ __attribute__((aligned(16))) char cls_smem[];
+    __shared__ float s_red[4][CLS_MAXC][65];
     bf16_t* sW = reinterpret_cast<bf16_t*>(cls_smem);   // [C][2H]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nch = (2 * H) >> 3, hch = H >> 3;
@@ -345,17 +346,22 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const bf16_t* __restr
                 }
             }
         }
+        // cross-lane sums through LDS (a [16 classes][64 lanes] transpose per row): 16 writes + 16 reads + 2 shuffles
+        // instead of 16 x 6 ds_bpermute shuffles
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int c = 0; c < CLS_MAXC; ++c)
-                if (c < C) acc[r][c] = wave_sum(acc[r][c]);
-            if (lane < C && row0 + r < M) {
-                float v = 0.f;
+            for (int c = 0; c < CLS_MAXC; ++c) s_red[wave][c][lane] = acc[r][c];
+            __builtin_amdgcn_wave_barrier();
+            const int c = lane >> 2, qd = lane & 3;
+            float v = 0.f;
 #pragma unroll
-                for (int c = 0; c < CLS_MAXC; ++c) v = lane == c ? acc[r][c] : v;
-                logits[(int64_t)(row0 + r) * C + lane] = v + (bias ? bias[lane] : 0.f);
-            }
+            for (int i = 0; i < 16; ++i) v += s_red[wave][c][16 * qd + i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if (qd == 0 && c < C && row0 + r < M)
+                logits[(int64_t)(row0 + r) * C + c] = v + (bias ? bias[c] : 0.f);
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -455,7 +461,7 @@ extern "C" int64_t icka_cls_head_slab_floats(int32_t H, int32_t C) { return (int
 extern "C" int icka_cls_head_fwd(const void* seq, const void* gated, const void* W, const float* bias, float* logits,
                                  int32_t M, int32_t H, int32_t C, void* stream) {
     if (!seq || !gated || !W || !logits) return ICKA_E_ARG;
-    if (M <= 0 || H <= 0 || H % 8 || C <= 0 || C > CLS_MAXC || (int64_t)C * 2 * H * 2 > 64 * 1024) return ICKA_E_SHAPE;
+    if (M <= 0 || H <= 0 || H % 8 || C <= 0 || C > CLS_MAXC || (int64_t)C * 2 * H * 2 > 44 * 1024) return ICKA_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(seq) | reinterpret_cast<uintptr_t>(gated) | reinterpret_cast<uintptr_t>(W)) & 15)
         return ICKA_E_ALIGN;
     int grid = (M + 7) / 8;   // 4 waves x 2 rows per pass

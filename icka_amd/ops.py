@@ -379,7 +379,7 @@ class GatedHeadFn(torch.autograd.Function):
                bias=head.Gate_text.bias, bias2=head.Gate_image.bias, epilogue=K.EPI_GATE, aux=cross, out2=gate)
         Wc = A.w(head.classifier.weight)
         logits = torch.empty(M, C, dtype=F32, device=seq.device)
-        ctx.skinny = C <= 16 and H % 8 == 0 and 2 * H // 8 <= 256 and C * 2 * H * 2 <= 64 * 1024
+        ctx.skinny = C <= 16 and H % 8 == 0 and 2 * H // 8 <= 256 and C * 2 * H * 2 <= 44 * 1024
         if ctx.skinny:   # HBM-bound kernels for the 13-wide output (see icka_cls_head_fwd)
             K.cls_head_fwd(seq, gated, Wc, head.classifier.bias, logits)
         else:
