@@ -403,14 +403,15 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i15 = lane & 15;
     const int bh = blockIdx.x, head = bh % a.h, b = bh / a.h;
     const float* mb = a.mask + (int64_t)b * a.Skv;
-    stage_rows<QR>(sQ, a.Q + (int64_t)b * a.Sq * a.ldq + head * HD, a.ldq, a.Sq, tid);
+    const int q0 = blockIdx.y * QR;   // query block of this head (grid.y > 1 splits a head for load balance)
+    stage_rows<QR>(sQ, a.Q + ((int64_t)b * a.Sq + q0) * a.ldq + head * HD, a.ldq, a.Sq - q0, tid);
     stage_rows<KR>(sK, a.K + (int64_t)b * a.Skv * a.ldk + head * HD, a.ldk, a.Skv, tid);
     stage_rows<KR>(sV, a.V + (int64_t)b * a.Skv * a.ldv + head * HD, a.ldv, a.Skv, tid);
     __syncthreads();
     if (ICKA_ATTN_ABLATE == 2) {   // staging + stores only
         for (int i = 0; i < QR * 8 / 256; ++i) {
             const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            if (r < a.Sq) *reinterpret_cast<u32x4*>(a.Ow + ((int64_t)b * a.Sq + r) * a.ldo + head * HD + c * 8) =
+            if (q0 + r < a.Sq) *reinterpret_cast<u32x4*>(a.Ow + ((int64_t)b * a.Sq + q0 + r) * a.ldo + head * HD + c * 8) =
                 *reinterpret_cast<const u32x4*>(sQ + off_t(r, c)) ^ *reinterpret_cast<const u32x4*>(sK + off_t(r % KR, c)) ^
                 *reinterpret_cast<const u32x4*>(sV + off_t(r % KR, c));
         }
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
     float inv[QT];
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
-        const int q = 16 * (QT * wave + qi) + i15;
+        const int q = q0 + 16 * (QT * wave + qi) + i15;
         const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
         const uint32_t hx = (idx_row + 4u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;   // + (16kt + r) * C0 per element
         float mx = -INFINITY;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
         }
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
-        const int q = 16 * (QT * wave + qi) + i15;
+        const int q = q0 + 16 * (QT * wave + qi) + i15;
         if (q < a.Sq) {
             bf16_t* orow = a.Ow + ((int64_t)b * a.Sq + q) * a.ldo + head * HD;
 #pragma unroll
@@ -693,8 +694,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
 
 template <int QT, int KT, bool DROP>
 static void launch_small2(const AttnArgs& a, int mode, hipStream_t st) {
-    if (mode == 1) hipLaunchKernelGGL((attn_bwd_small_kernel<QT, KT, DROP>), dim3(a.B * a.h), dim3(256), 0, st, a);
-    else if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true>), dim3(a.B * a.h), dim3(256), 0, st, a);
+    if (mode == 1) {
+        hipLaunchKernelGGL((attn_bwd_small_kernel<QT, KT, DROP>), dim3(a.B * a.h), dim3(256), 0, st, a);
+        return;
+    }
+    // forward: heads of more than 64 queries run as two 64-query blocks (grid.y = 2, K/V staged twice) when that
+    // balances the grid: B*h = 384 whole heads put 2 blocks on half of the 256 CUs and 1 on the rest, 768 half heads
+    // put 3 on each
+    if (QT == 2 && (a.B * a.h) % 256 != 0) {
+        if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, true>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, false>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
+        return;
+    }
+    if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true>), dim3(a.B * a.h), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, false>), dim3(a.B * a.h), dim3(256), 0, st, a);
 }
 template <int QT, int KT>
