@@ -196,6 +196,227 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmArgs a) {
     }
 }
 
+// =====================================================================================================================
+// Persistent recurrence: ONE launch walks all S steps.  Same decomposition (a block per 16 hidden units and direction,
+// a wave per gate), but the block keeps its W_hh slice (4 gates x 16 units x H, KS fragments per wave) in registers
+// for the whole sequence and its cell state in registers; per step only h_{t-1} (B x H bf16, written by the other
+// blocks of the direction) crosses HBM/L2.  Steps are separated by a per-direction grid barrier: every block
+// publishes its h slice (device-scope release fence + atomic ticket) and spins (with s_sleep) until all H/16 blocks of
+// its direction have published step t.  All blocks are co-resident by construction (H/16 * 2 <= 256 blocks, one per
+// CU: checked on the host), so the barrier cannot deadlock; the spin is bounded anyway (it gives up after ~2^22 polls,
+// raises the error word and finishes with wrong data rather than hanging the device).
+struct LstmPersist {
+    unsigned int* tickets;   // [2] per-direction step counters, zeroed by the host before the launch
+    unsigned int* err;       // [1] set to 1 if a barrier wait gave up
+};
+
+// Hand-off form (cdna_hip_programming.md Guideline 16): the payload another block reads (h_t / dgates_t) is stored
+// WRITE-THROUGH with 8-byte agent-scope atomic stores (sc1), every storing wave drains its stores (s_waitcnt vmcnt(0)),
+// the block barrier joins them and ONE lane adds the ticket; the consumer polls with one lane, that lane issues ONE
+// agent-scope acquire (invalidates this CU's L1) and drains it, the block barrier releases the other waves to plain
+// loads.  No release fence (buffer_wbl2) and no per-thread __threadfence(): those made a step ~26 us.
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+__device__ __forceinline__ void lstm_store_wt(void* p, unsigned long long v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lstm_grid_wait(unsigned int* ctr, unsigned int target, unsigned int* err) {
+    if (threadIdx.x == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1 << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void lstm_grid_signal(unsigned int* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NRT, int KS>
+__global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs a, const LstmPersist ps) {
+    __shared__ float s_g[4][NRT * 16][17];
+    __shared__ __attribute__((aligned(16))) bf16_t s_h[NRT * 16][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
+    const int i15 = lane & 15, g4 = lane >> 4;
+    const unsigned int nblk = gridDim.x;
+    bf16x8 wf[KS];   // this wave's gate rows of W_hh, resident for the whole sequence
+    {
+        const bf16_t* wrow = a.whh + ((int64_t)d * 4 * H + (int64_t)wave * H + u0 + i15) * H + 8 * g4;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) wf[u] = frag16(wrow + 32 * u, 32 * u < H);
+    }
+    float creg[NRT];   // cell state of this thread's (b, u) pairs
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) creg[i] = 0.f;
+    for (int step = 0; step < S; ++step) {
+        const int tt = d == 0 ? step : S - 1 - step;
+        const int tp = d == 0 ? tt - 1 : tt + 1;
+        float gxr[NRT][4];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            const float* gx = a.gx + ((int64_t)(b < a.B ? b : 0) * S + tt) * a.ldg + (int64_t)d * 4 * H + u0 + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gxr[i][q] = gx[q * H];
+        }
+        f32x4 acc[NRT];
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            lstm_grid_wait(ps.tickets + d, (unsigned)step * nblk, ps.err);
+            const bf16_t* hbase = a.y + (int64_t)tp * 2 * H + (int64_t)d * H + 8 * g4;
+            bf16x8 hf[NRT][KS];
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const int b = 16 * r + i15;
+                    hf[r][u] = frag16(hbase + (int64_t)b * S * 2 * H + 32 * u, 32 * u < H && b < a.B);
+                }
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], hf[r][u], acc[r]);
+        }
+        __syncthreads();   // s_g of the previous step fully consumed
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_g[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            if (b >= a.B) continue;
+            const int64_t row = (int64_t)b * S + tt;
+            const float gi = sigmoid_f(s_g[0][b][u] + gxr[i][0]);
+            const float gf = sigmoid_f(s_g[1][b][u] + gxr[i][1]);
+            const float gg = tanhf(s_g[2][b][u] + gxr[i][2]);
+            const float go = sigmoid_f(s_g[3][b][u] + gxr[i][3]);
+            const float c = gf * creg[i] + gi * gg;
+            const float h = go * tanhf(c);
+            if (a.hprev)   // h_{t-1} of this (b, u): still in s_h from the previous step (same thread wrote it)
+                a.hprev[row * 2 * H + (int64_t)d * H + u0 + u] = step == 0 ? f2bf(0.f) : s_h[b][u];
+            creg[i] = c;
+            a.c_all[(row * 2 + d) * H + u0 + u] = c;
+            s_h[b][u] = f2bf(h);
+            bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
+            act[0] = f2bf(gi); act[H] = f2bf(gf); act[2 * H] = f2bf(gg); act[3 * H] = f2bf(go);
+        }
+        __syncthreads();
+        // publish h_t: 4 units (8 bytes) per store, write-through
+        for (int p = tid; p < NRT * 16 * 4; p += 256) {
+            const int b = p >> 2, part = p & 3;
+            if (b < a.B)
+                lstm_store_wt(a.y + ((int64_t)b * S + tt) * 2 * H + (int64_t)d * H + u0 + 4 * part,
+                              *reinterpret_cast<const unsigned long long*>(&s_h[b][4 * part]));
+        }
+        if (step + 1 < S) lstm_grid_signal(ps.tickets + d);
+    }
+}
+
+template <int NRT, int KS>
+__global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs a, const LstmPersist ps) {
+    __shared__ float s_p[4][NRT * 16][17];
+    __shared__ __attribute__((aligned(16))) bf16_t s_dg[4][NRT * 16][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
+    const int i15 = lane & 15, g4 = lane >> 4;
+    const unsigned int nblk = gridDim.x;
+    bf16x8 wf[KS];   // rows u0.. of W_hh^T, this wave's quarter of the 4H reduction
+    {
+        const bf16_t* wrow = a.whh + ((int64_t)d * H + u0 + i15) * 4 * H + (int64_t)wave * H + 8 * g4;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) wf[u] = frag16(wrow + 32 * u, 32 * u < H);
+    }
+    float carry[NRT];   // dc_{t+1} * f_{t+1} of this thread's (b, u) pairs
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) carry[i] = 0.f;
+    for (int step = S - 1; step >= 0; --step) {
+        const int tt = d == 0 ? step : S - 1 - step;
+        const int tp = d == 0 ? tt - 1 : tt + 1;
+        const int tn = d == 0 ? tt + 1 : tt - 1;
+        const bool first = step == 0;
+        float dyr[NRT], actr[NRT][4], cr[NRT], cpr[NRT];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            const int bb = b < a.B ? b : 0;
+            const int64_t row = (int64_t)bb * S + tt;
+            dyr[i] = bf2f(a.dy[row * 2 * H + (int64_t)d * H + u0 + u]);
+            const bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) actr[i][q] = bf2f(act[q * H]);
+            cr[i] = a.c_all[(row * 2 + d) * H + u0 + u];
+            cpr[i] = first ? 0.f : a.c_all[(((int64_t)bb * S + tp) * 2 + d) * H + u0 + u];
+        }
+        f32x4 acc[NRT];
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step < S - 1) {
+            lstm_grid_wait(ps.tickets + d, (unsigned)(S - 1 - step) * nblk, ps.err);
+            const bf16_t* gbase = a.dgates + (int64_t)tn * a.ldg + (int64_t)d * 4 * H + (int64_t)wave * H + 8 * g4;
+            bf16x8 gf[NRT][KS];
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const int b = 16 * r + i15;
+                    gf[r][u] = frag16(gbase + (int64_t)b * S * a.ldg + 32 * u, 32 * u < H && b < a.B);
+                }
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], gf[r][u], acc[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_p[wave][16 * r + i15][4 * g4 + q] = acc[r][q];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            if (b >= a.B) continue;
+            (void)tt;
+            const float dh = dyr[i] + (s_p[0][b][u] + s_p[1][b][u] + s_p[2][b][u] + s_p[3][b][u]);
+            const float gi = actr[i][0], gf = actr[i][1], gg = actr[i][2], go = actr[i][3];
+            const float tc = tanhf(cr[i]);
+            const float dc = dh * go * (1.f - tc * tc) + carry[i];
+            carry[i] = dc * gf;
+            s_dg[0][b][u] = f2bf(dc * gg * gi * (1.f - gi));
+            s_dg[1][b][u] = f2bf(dc * cpr[i] * gf * (1.f - gf));
+            s_dg[2][b][u] = f2bf(dc * gi * (1.f - gg * gg));
+            s_dg[3][b][u] = f2bf(dh * tc * go * (1.f - go));
+        }
+        __syncthreads();
+        // publish dgates_t: 4 units (8 bytes) per store, write-through
+        for (int p = tid; p < 4 * NRT * 16 * 4; p += 256) {
+            const int gate = p / (NRT * 64), rem = p % (NRT * 64), b = rem >> 2, part = rem & 3;
+            if (b < a.B)
+                lstm_store_wt(a.dgates + ((int64_t)b * S + tt) * a.ldg + (int64_t)d * 4 * H + (int64_t)gate * H + u0 +
+                                  4 * part,
+                              *reinterpret_cast<const unsigned long long*>(&s_dg[gate][b][4 * part]));
+        }
+        if (step > 0) lstm_grid_signal(ps.tickets + d);
+    }
+}
+
+int g_lstm_persistent = 1;   // icka_lstm_set_persistent
+__device__ unsigned int g_lstm_sync[4];   // [0..1] tickets, [2] error word
+static unsigned int* lstm_sync_words() {   // address looked up once (not a stream operation: safe under graph capture)
+    static unsigned int* p = nullptr;
+    if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_sync)) != hipSuccess) p = nullptr;
+    return p;
+}
+
 // W^T for both directions: in [2][R][C] -> out [2][C][R] (bf16), 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
                                                         int C) {
@@ -281,6 +502,17 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
+    if (g_lstm_persistent && nrt <= 2 && H <= 768 && (H / 16) * 2 <= 256) {
+        LstmPersist ps;
+        unsigned int* base = lstm_sync_words();
+        if (!base) return ICKA_E_ARG;
+        ps.tickets = base; ps.err = base + 2;
+        if (hipMemsetAsync(base, 0, 2 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
+        if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_persistent_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        else hipLaunchKernelGGL((lstm_fwd_persistent_kernel<2, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
     for (int s = 0; s < S; ++s) {
         a.step = s;
         if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_step_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
@@ -302,6 +534,17 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
     a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
+    if (g_lstm_persistent && nrt <= 2 && H <= 768 && (H / 16) * 2 <= 256) {
+        LstmPersist ps;
+        unsigned int* base = lstm_sync_words();
+        if (!base) return ICKA_E_ARG;
+        ps.tickets = base; ps.err = base + 2;
+        if (hipMemsetAsync(base, 0, 2 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
+        if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_persistent_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        else hipLaunchKernelGGL((lstm_bwd_persistent_kernel<2, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
     for (int s = S - 1; s >= 0; --s) {
         a.step = s;
         if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
@@ -334,4 +577,15 @@ extern "C" int icka_linear_small_m(const void* x, int64_t ldx, const void* W, co
     else hipLaunchKernelGGL((linear_small_kernel<4>), dim3(grid), dim3(256), 0, st, a);
     ICKA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int icka_lstm_set_persistent(int32_t on) {
+    g_lstm_persistent = on ? 1 : 0;
+    return 0;
+}
+/* 1 if a grid barrier of the persistent recurrence ever gave up waiting (results of that call are invalid). */
+extern "C" int icka_lstm_barrier_error(void) {
+    unsigned int v[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_lstm_sync), sizeof(v)) != hipSuccess) return -1;
+    return (int)v[2];
 }

@@ -281,6 +281,12 @@ int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh, void* y, 
                   int32_t B, int32_t S, int32_t H, void* stream);
 int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const float* c_all, void* dgates, int64_t ldg,
                   float* dc_carry, int32_t B, int32_t S, int32_t H, void* stream);
+/* 1 (default): for B <= 32 and H <= 768 the recurrence is ONE persistent launch per direction pair -- W_hh slices and
+ * cell state resident in registers, a per-direction grid barrier (device-scope release/acquire + atomic ticket) between
+ * steps; 0: one launch per time step.  icka_lstm_barrier_error() returns 1 if a barrier wait ever gave up (bounded
+ * spin: the kernel then finishes with invalid data instead of hanging), -1 if the query itself failed. */
+int icka_lstm_set_persistent(int32_t on);
+int icka_lstm_barrier_error(void);
 /* y bf16 [M <= 64, N] = act(x . W^T + bias) for a handful of rows (BertPooler.forward :675-681: tanh(dense(h[:, 0])),
  * 32 rows at c2): x bf16 rows with stride ldx, W bf16 [N,K], K % 128 == 0; act 0 = none, 1 = tanh. */
 int icka_linear_small_m(const void* x, int64_t ldx, const void* W, const float* bias, void* y, int64_t ldy, int32_t M,

@@ -6,9 +6,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256)])
-def test_bilstm_forward_backward_against_aten(B, S, H):
+@pytest.mark.parametrize("persistent", [1, 0])
+@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64)])
+def test_bilstm_forward_backward_against_aten(B, S, H, persistent, request):
+    from icka_amd import _lib
     from icka_amd.lstm import BiLSTM
+    lib = _lib.load()
+    lib.icka_lstm_set_persistent(persistent)       # one persistent launch with grid barriers / one launch per step
+    request.addfinalizer(lambda: lib.icka_lstm_set_persistent(1))
     torch.manual_seed(B * 100 + S)
     ref = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
     mine = BiLSTM(H, H)
@@ -30,7 +35,10 @@ def test_bilstm_forward_backward_against_aten(B, S, H):
     assert rel(xg.grad, xr.grad) < 3e-2
     for n, p in mine.named_parameters():
         assert rel(p.grad, dict(ref.named_parameters())[n].grad) < 3e-2, n
-    print("\n[BiLSTM B%d S%d H%d] max abs out err %.3e, dx rel %.3e" % (B, S, H, err, rel(xg.grad, xr.grad)))
+    torch.cuda.synchronize()
+    assert lib.icka_lstm_barrier_error() == 0
+    print("\n[BiLSTM B%d S%d H%d persistent=%d] max abs out err %.3e, dx rel %.3e"
+          % (B, S, H, persistent, err, rel(xg.grad, xr.grad)))
 
 
 def test_bilstm_rejects_unsupported_configurations():
