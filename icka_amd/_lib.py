@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class GemmDesc(C.Structure):
@@ -78,6 +78,11 @@ PROTOTYPES = {
                                   c_vp]),
     "icka_cls_head_bwd_slabs": (c_i32, [c_i32]),
     "icka_cls_head_slab_floats": (c_i64, [c_i32, c_i32]),
+    "icka_conv_stem_patches": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "icka_conv_im2col3x3": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "icka_conv_subsample": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "icka_conv_maxpool3x3s2": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "icka_conv_features_out": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_lstm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_lstm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_lstm_set_persistent": (c_i32, [c_i32]),

@@ -166,6 +166,13 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
         case ICKA_EPI_TANH:
             for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
             break;
+        case ICKA_EPI_ADD_RELU:
+            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + a[r], 0.f);
+            break;
+        case ICKA_EPI_RELU:
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            break;
         default: break;
     }
     if (g.ksplit > 1) {   // partial sum of one k-range (host guarantees f32 C, plain epilogue, C pre-scaled by beta)
@@ -460,6 +467,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
             case ICKA_EPI_TANH:
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                break;
+            case ICKA_EPI_ADD_RELU:
+                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + a[e], 0.f);
+                break;
+            case ICKA_EPI_RELU:
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 break;
             default: break;
         }
@@ -1148,7 +1164,8 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     if (d->op < ICKA_GEMM_NT || d->op > ICKA_GEMM_TN) return ICKA_E_ARG;
     if (d->K1 != 0 && (d->K1 < 0 || d->K1 >= d->K || d->K1 % BK != 0 || !d->A2 || !d->B2)) return ICKA_E_ARG;
     if ((d->epilogue == ICKA_EPI_GELU) && !d->C2) return ICKA_E_ARG;
-    if ((d->epilogue == ICKA_EPI_DGELU || d->epilogue == ICKA_EPI_ADD || d->epilogue == ICKA_EPI_GATE) && !d->aux)
+    if ((d->epilogue == ICKA_EPI_DGELU || d->epilogue == ICKA_EPI_ADD || d->epilogue == ICKA_EPI_GATE ||
+         d->epilogue == ICKA_EPI_ADD_RELU) && !d->aux)
         return ICKA_E_ARG;
     g.M = d->M; g.N = d->N; g.K = d->K; g.K1 = d->K1;
     g.A = (const bf16_t*)d->A; g.lda = d->lda; g.B = (const bf16_t*)d->B; g.ldb = d->ldb;

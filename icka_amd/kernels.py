@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_ADD, EPI_DGELU, EPI_GATE, EPI_GELU, EPI_NONE, EPI_TANH, GEMM_NN, GEMM_NT, GEMM_TN,
+from ._lib import (EPI_ADD, EPI_ADD_RELU, EPI_DGELU, EPI_GATE, EPI_GELU, EPI_NONE, EPI_RELU, EPI_TANH, GEMM_NN, GEMM_NT, GEMM_TN,
                    GemmDesc, check)
 
 BF16 = torch.bfloat16

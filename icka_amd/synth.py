@@ -42,6 +42,37 @@ def fill_module_(module: torch.nn.Module, std: float = 0.02, only: Optional[Iter
             v.copy_(seeded_tensor(k, tuple(v.shape), std).to(v.dtype))
 
 
+def seeded_resnet_tensor(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
+    """By-key seeded values for the ResNet image encoder (state_dict names of resnet/resnet.py): convolution weights
+    normal(0, sqrt(2/n)) as the reference initialises them (:113-119), BatchNorm affine / running statistics drawn so
+    that eval-mode BatchNorm is a non-trivial, well-conditioned affine map (running_var in [0.5, 1.5]; the last
+    BatchNorm of a block scaled down so the residual stream of 50 blocks stays in range)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(zlib.crc32(key.encode("utf-8")))
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "running_var":
+        return 0.5 + torch.rand(shape, generator=g)
+    if leaf == "running_mean":
+        return torch.empty(shape).normal_(0.0, 0.1, generator=g)
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.int64)
+    if len(shape) == 4:   # convolution [out, in, kh, kw]
+        n = shape[2] * shape[3] * shape[0]
+        return torch.empty(shape).normal_(0.0, (2.0 / n) ** 0.5, generator=g)
+    if len(shape) == 2:   # fc
+        return torch.empty(shape).normal_(0.0, 0.01, generator=g)
+    if leaf == "weight":  # BatchNorm scale
+        last = ".bn3." in key or key.endswith("bn3.weight")
+        return (0.2 if last else 0.8) + 0.4 * torch.rand(shape, generator=g)
+    return torch.empty(shape).normal_(0.0, 0.1, generator=g)   # BatchNorm / fc bias
+
+
+def fill_resnet_(module: torch.nn.Module) -> None:
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            v.copy_(seeded_resnet_tensor(k, tuple(v.shape)).to(v.dtype))
+
+
 def synthetic_batch(batch: int, seq_len: int, regions: int, num_labels: int = 13, vocab_size: int = 30522,
                     seed: int = REFERENCE_SEED, layout: str = "BRC", ragged: bool = True,
                     min_len: Optional[int] = None) -> Dict[str, torch.Tensor]:

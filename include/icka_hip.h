@@ -43,7 +43,9 @@ enum {
     ICKA_EPI_DGELU = 2, /* C = acc * gelu'(aux)                                  (its backward)                */
     ICKA_EPI_ADD = 3,   /* C = acc (+bias) + aux                                 (gradient fan-in)             */
     ICKA_EPI_GATE = 4,  /* g = sigmoid(acc+bias) ; C2 = g ; C = g*aux            (cl_modeling.py:1363-1367)    */
-    ICKA_EPI_TANH = 5   /* C = tanh(acc+bias)                                    (BertPooler, :675-681)        */
+    ICKA_EPI_TANH = 5,  /* C = tanh(acc+bias)                                    (BertPooler, :675-681)        */
+    ICKA_EPI_RELU = 6,  /* C = max(acc+bias, 0)                 (conv+BN+ReLU, resnet/resnet.py:75-81)          */
+    ICKA_EPI_ADD_RELU = 7 /* C = max(acc+bias+aux, 0)           (bottleneck residual, resnet/resnet.py:83-90)   */
 };
 typedef struct icka_gemm_desc {
     int32_t op;            /* ICKA_GEMM_* */
@@ -293,6 +295,27 @@ int icka_linear_small_m(const void* x, int64_t ldx, const void* W, const float* 
                         int32_t N, int32_t K, int32_t act, void* stream);
 /* out[b][c][r] = in[b][r][c] for bf16 matrices (batch of [R,C]). */
 int icka_transpose_bf16(const void* in, void* out, int32_t batch, int32_t R, int32_t C, void* stream);
+/* ---------------------------------------------------------------------------------------------------------------
+ * Frozen ResNet image encoder, forward only (resnet/resnet.py:57-150 Bottleneck / ResNet,
+ * resnet/resnet_utils.py:13-53 myResnet.forward).  Convolutions run as icka_gemm calls on NHWC bf16 activations with
+ * eval-mode BatchNorm folded into weight / bias and ReLU / residual add in the epilogue (ICKA_EPI_RELU,
+ * ICKA_EPI_ADD_RELU); these entry points build the operands.  rows_padded >= B*Ho*Wo: rows past the end are zeroed so
+ * the GEMM M dimension can be a multiple of 128.
+ *   stem_patches : image f32 NCHW [B,3,H,W] -> 7x7/s2/p3 patches bf16 [rows_padded, 192], k = (ky*7+kx)*3 + c, 147..191 = 0
+ *   im2col3x3    : NHWC bf16 [B,H,W,C] -> [rows_padded, 9*C], k = (ky*3+kx)*C + c, pad 1, stride 1 or 2
+ *   subsample    : rows (stride*y, stride*x) of an NHWC map (strided 1x1 convolution input)
+ *   maxpool3x3s2 : nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+ *   features_out : x bf16 [B,P,C] -> att f32 [B,C,P] (NCHW), fc f32 [B,C] = mean over P, tokens bf16 [B*P,C] (nullable) */
+int icka_conv_stem_patches(const float* image, void* patches, int32_t B, int32_t H, int32_t W, int64_t rows_padded,
+                           void* stream);
+int icka_conv_im2col3x3(const void* src, void* patches, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
+                        int64_t rows_padded, void* stream);
+int icka_conv_subsample(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
+                        int64_t rows_padded, void* stream);
+int icka_conv_maxpool3x3s2(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int64_t rows_padded,
+                           void* stream);
+int icka_conv_features_out(const void* x, float* att, float* fc, void* tokens, int32_t B, int32_t P, int32_t C,
+                           void* stream);
 /* Dropout nonce for hipGraph replay.  Every dropout-bearing kernel XORs two DEVICE words into its (by-value) seed at
  * entry when a nonce is registered.  A captured graph re-launches the same seed values, so the graph also captures
  * icka_bump_dropout_nonce at the start of a step: each replay then draws fresh masks, and the forward and backward
