@@ -14,8 +14,10 @@ step is outside the metric and reported separately by --w
 
 Rank 0 prints ONE JSON line with the contract's keys plus
   roofline      -- the dominant kernel class (the MFMA GEMMs: >= 97 % of algorithmic FLOPs): algorithmic FLOPs of the
-                   GEMM launches of one step / their summed duration, measured with HIP events on the launch stream
-                   in an instrumented pass after the timed region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH).
+                   GEMM launches of one step / their duration, measured live after the timed region: the launches of one
+                   step are recorded and re-issued back to back between ONE pair of HIP events on the launch stream;
+                   peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH); traffic = PMC bytes per launch from the committed
+                   rocprofv3 passes (profiles/r01_gemm_traffic.json).
   cpu_baseline  -- the CPU oracle (oracle/mner_oracle.py; PyTorch CPU eager fp32, same op sequence as the reference)
                    timed on this box's host cores on a bounded sample of the same workload.
 """

@@ -1,12 +1,18 @@
-// MFMA GEMM for the ICKA hot path (gfx950).  One kernel template, three operand layouts:
+// MFMA GEMM for the ICKA hot path (gfx950), v_mfma_f32_16x16x32_bf16, fp32 accumulation.  Three operand layouts:
 //   NT: C = A[M,K] . B[N,K]^T   (both operands k-contiguous: fragments by ds_read_b128)
 //   NN: C = A[M,K] . B[K,N]     (B k-major in memory: fragments by ds_read_b64_tr_b16)
 //   TN: C = A[K,M]^T . B[K,N]   (both k-major: weight gradients, K = tokens)
-// Block = 256 threads (4 waves, 2x2), tile 128x128x64, v_mfma_f32_16x16x32_bf16, wave tile 64x64 (4x4 MFMA tiles).
-// Global -> registers -> LDS staging (next k-tile's loads are issued before the MFMAs of the current one), LDS
-// double-buffered (one barrier per k-tile).  LDS images are XOR-swizzled per layout (off_kc / off_km).
 // The MFMA is issued as D^T: a-operand = B-tile rows (n), b-operand = A-tile rows (m), so each lane ends up with
 // FOUR CONSECUTIVE n of one output row m -> 8-byte (bf16) / 16-byte (f32) row-major stores and vector epilogues.
+// Kernels in this file:
+//   gemm_kernel            general path: any M, N, K / ragged / unaligned operands, register-staged, split-K
+//   gemm_dma_kernel        aligned path, 256 threads, LDS-DMA staging (predecessor of the warp-specialised kernels)
+//   gemm_ws_kernel         aligned path, 512 threads: 4 loader waves (LDS-DMA) + 4 compute waves, ring of 3 k-tiles,
+//                          128x128 or 128x96 output tiles, LDS-staged or direct (f32) epilogue
+//   gemm_ws2_kernel        same with a ring of 2 and two co-resident blocks per CU (short-K, many-tile grids)
+//   gemm_ws_group_kernel   up to 4 problems of one layout in one launch (128x128 tiles)
+//   gemm_big_group_kernel  256x128 tiles for the grouped weight gradients + column-sum / slab-reduction blocks
+// LDS images are XOR-swizzled per layout (off_kc / off_km), the swizzle applied to the DMA source address.
 #include "common.h"
 
 namespace {

@@ -81,7 +81,8 @@ typedef struct icka_slab_reduction {
 int icka_gemm_grouped_ex(const icka_gemm_desc* descs, int32_t n, const icka_slab_reduction* reds, int32_t n_red,
                          void* stream);
 /* Tuning knob of the aligned fast path: depth of the LDS-DMA ring (2: 64 KiB LDS, two blocks per CU; 3 / 4: 96 /
- * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  Default 4. */
+ * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  0 (default) = per-shape
+ * choice: ring 2 with two co-resident blocks for short-K grids of >= ~2 tiles per CU, ring 3 otherwise. */
 int icka_gemm_set_ring(int nbuf);
 /* Output-tile width of the warp-specialised fast path: 0 (default) = per-shape choice between 128x128 and 128x96
  * tiles (the narrower tile when it quantises better onto the 256 CUs: N = 768 gives 256 tiles instead of 192),
