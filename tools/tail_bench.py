@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--regions", type=int, default=36)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--with-encoder", action="store_true",
+                    help="also run the frozen ResNet-152 image encoder on 224x224 images inside the step "
+                         "(My_cross_attention.py calls it once per batch): end-to-end image+sentence -> loss")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(synth.REFERENCE_SEED)
@@ -44,9 +47,22 @@ def main():
     b = synth.synthetic_batch(args.batch, args.seq, args.regions, num_labels=13)
     g = {k: v.to(dev) for k, v in b.items()}
 
+    enc, images = None, None
+    if args.with_encoder:
+        from icka_amd.resnet import myResnet, resnet152
+        net = resnet152().eval()
+        synth.fill_resnet_(net)
+        enc = myResnet(net.to(dev), False, dev)
+        images = torch.randn(args.batch, 3, 224, 224, device=dev)
+        g["added_attention_mask"] = torch.cat([torch.ones(args.batch, 49, dtype=torch.long, device=dev),
+                                               g["input_mask"]], 1)
+
     def step():
+        att = g["visual_embeds_att"]
+        if enc is not None:
+            _, _, att = enc(images)        # [B,2048,7,7] f32, the reference layout of visual_embeds_att
         loss = model(g["input_ids"], g["segment_ids"], g["input_mask"], g["input_ids"], g["input_mask"],
-                     g["segment_ids"], g["added_attention_mask"], visual_embeds_att=g["visual_embeds_att"],
+                     g["segment_ids"], g["added_attention_mask"], visual_embeds_att=att,
                      output_mask=g["input_mask"], labels=g["labels"], mode="train")
         loss.backward()
         return loss
@@ -79,7 +95,9 @@ def main():
                       "value": round(1e3 * args.batch / ms, 2), "unit": "samples/s", "ms_per_step": round(ms, 3),
                       "launch": mode, "loss": round(loss, 5), "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
                       "config": {"workload": "bert-base + %d regions, seq %d, batch %d, train mode"
-                                 % (args.regions, args.seq, args.batch)},
+                                 % (49 if args.with_encoder else args.regions, args.seq, args.batch)},
+                      "image_encoder": "resnet152 on 224x224 inside the step" if args.with_encoder else "none (region "
+                      "features given)",
                       "bilstm_fwd_bwd_ms_eager": round(lstm_ms, 3), "crf_fwd_bwd_ms_eager": round(crf_ms, 3)}))
 
 
