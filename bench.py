@@ -209,13 +209,39 @@ def main():
         try:
             from icka_amd.graph import GraphedStep
             log("capturing the step into a hipGraph")
+            if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallback below
+                raise RuntimeError("simulated capture failure")
             gstep = GraphedStep(model, step)
             run_step = gstep
             mode = "hipgraph"
         except Exception as e:  # noqa: BLE001
-            log("graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
+            log("graph capture failed (%s: %s)" % (type(e).__name__, e))
             torch.cuda.synchronize()
             run_step = step
+            if reducer is not None:
+                # second attempt: the collectives are what a runtime may refuse to capture -- capture forward + backward
+                # only and launch the bucket all-reduces eagerly after each replay (no overlap, but no host-bound step)
+                try:
+                    arena.reducer = None
+
+                    def compute_only():
+                        loss = model(g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"],
+                                     g["visual_embeds_mean"], g["visual_embeds_att"], labels=g["labels"])
+                        loss.backward()
+                        return loss
+                    gcomp = GraphedStep(model, compute_only)
+
+                    def run_step():
+                        loss = gcomp()
+                        reducer.reduce_all()
+                        return loss
+                    mode = "hipgraph(compute)+eager-allreduce"
+                    log("captured forward+backward only; gradient all-reduce runs eagerly after each replay")
+                except Exception as e2:  # noqa: BLE001
+                    log("compute-only capture failed too (%s: %s); running eagerly" % (type(e2).__name__, e2))
+                    torch.cuda.synchronize()
+                    arena.reducer = reducer
+                    run_step = step
 
     log("warm-up %d steps" % args.warmup)
     for _ in range(args.warmup):
