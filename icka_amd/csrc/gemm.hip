@@ -36,6 +36,7 @@ struct GemmArgs {
     int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
     float* colsum; int colsum_acc;  // TN fast path: colsum[m] (+)= sum_k A[k,m] (bias gradient fused into dW = dY^T.X)
     int n96ok;                  // fast path + N % 96 == 0: the 128x96 tile is an option
+    int n64ok;                  // everything aligned except N % 128: N % 64 == 0 -> the 128x64 tile (NT only)
     int direct;                 // plain outputs skip the LDS-staged epilogue (icka_gemm_set_direct_epilogue)
     unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
@@ -332,6 +333,23 @@ __device__ __forceinline__ void dma_init(const bf16_t* (&ptr)[4], const bf16_t* 
 template <int NJ = 4>
 __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t stride, uint32_t lds_base) {
     uint32_t keep;
+    if constexpr (NJ == 2) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(ptr[0]), "v"(ptr[1]), "s"(lds_base)
+            : "memory", "scc");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ptr[j] += stride;
+        return;
+    }
     if constexpr (NJ == 3) {
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
@@ -713,7 +731,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     constexpr int NTN = BNT / 32;                  // 16-column MFMA tiles per compute wave (4 or 3)
     constexpr int NJB = B_KM ? 4 : BNT / 32;       // LDS-DMA pieces of the B tile per loader wave
     constexpr int ND = 4 + NJB;                    // DMA instructions per k-tile per loader wave
-    static_assert(BNT == 128 || BNT == 96, "tile width");
+    static_assert(BNT == 128 || BNT == 96 || BNT == 64, "tile width");
     tile_origin(bid, nb, g.M / BM, g.N / BNT, m0, n0, BNT);
     const int nk = g.K / BK;
     const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * (BNT / 2);
@@ -778,10 +796,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                 if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                static_assert(ND == 8 || ND == 7, "DMA count per k-tile");
+            } else if constexpr (ND == 7) {
                 if (ahead >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
                 else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                static_assert(ND == 8 || ND == 7 || ND == 6, "DMA count per k-tile");
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
 #ifdef ICKA_GEMM_STAMP
@@ -1060,6 +1082,13 @@ __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) 
 template <bool A_KM, bool B_KM>
 int launch(GemmArgs g, bool aligned, hipStream_t st) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    if constexpr (!A_KM && !B_KM) {
+        if (!aligned && g.n64ok && g_ws) {   // 64-channel convolutions of the ResNet stem / layer1: 128x64 tiles
+            hipLaunchKernelGGL((gemm_ws_kernel<false, false, 3, 0, 64>), dim3((g.M / BM) * (g.N / 64)), dim3(512), 0, st, g);
+            ICKA_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (aligned) {
 #ifdef ICKA_GEMM_ABLATE
         if (g_abl == 1) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(256), 0, st, g);
@@ -1185,6 +1214,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.colsum_acc = d->colsum_accumulate;
     g.ksplit = 1;
     g.n96ok = 0;
+    g.n64ok = 0;
     g.direct = g_direct;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
@@ -1196,6 +1226,9 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
               al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
               al(d->bias, 4, 4) && al(d->bias2, 4, 4);
     g.n96ok = aligned && d->N % 96 == 0;
+    g.n64ok = !aligned && (d->M % BM == 0) && (d->N % 64 == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
+              al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
+              al(d->bias, 4, 4) && al(d->bias2, 4, 4) && d->K1 == 0 && !d->colsum_out;
     return 0;
 }
 

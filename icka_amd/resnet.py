@@ -8,8 +8,8 @@ My_cross_attention.py calls once per batch on the raw images with ``if_fine_tune
 Every convolution is a GEMM of the GEMM kernels on NHWC bf16 activations: eval-mode BatchNorm is folded into the
 (bf16) weights and an f32 bias when the module is first used (re-folded when a parameter changes), ReLU and the
 residual add live in the GEMM epilogue, 3x3 / 7x7 convolutions go through patch matrices built by `icka_conv_*`.
-Channel counts below 128 (the 64-channel stem and layer1) and the row count of every feature map are zero-padded to
-multiples of 128 so that all GEMMs take the fast path.  There is no backward: the encoder is frozen in the reference
+The row count of every feature map is zero-padded to a multiple of 128 and channel counts to 64 (stem / layer1:
+128x64 GEMM tiles) or multiples of 128, so that all GEMMs take the fast path.  There is no backward: the encoder is frozen in the reference
 run (``fine_tune_cnn`` off) and ``if_fine_tune=True`` raises."""
 from __future__ import annotations
 
@@ -26,6 +26,12 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 def _pad128(n: int) -> int:
     return (n + 127) // 128 * 128
+
+
+def _padc(c: int) -> int:
+    """Channel padding: the 64-channel stem / layer1 tensors stay 64 wide (128x64 GEMM tiles), everything else is a
+    multiple of 128."""
+    return 64 if c <= 64 else _pad128(c)
 
 
 class Bottleneck(nn.Module):
@@ -115,17 +121,17 @@ class ResNet(nn.Module):
                                "encoder frozen)")
         if self._folded is not None and self._folded_key == key:
             return self._folded
-        plan = {"stem": self._fold(self.conv1, self.bn1, 3, 128, k_pad=192), "blocks": []}
+        plan = {"stem": self._fold(self.conv1, self.bn1, 3, 64, k_pad=192), "blocks": []}
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 cin, p, cout = blk.conv1.in_channels, blk.conv1.out_channels, blk.conv3.out_channels
-                entry = {"stride": blk.stride, "p": _pad128(p), "cout": _pad128(cout), "cin": _pad128(cin),
-                         "c1": self._fold(blk.conv1, blk.bn1, _pad128(cin), _pad128(p)),
-                         "c2": self._fold(blk.conv2, blk.bn2, _pad128(p), _pad128(p)),
-                         "c3": self._fold(blk.conv3, blk.bn3, _pad128(p), _pad128(cout)),
+                entry = {"stride": blk.stride, "p": _padc(p), "cout": _padc(cout), "cin": _padc(cin),
+                         "c1": self._fold(blk.conv1, blk.bn1, _padc(cin), _padc(p)),
+                         "c2": self._fold(blk.conv2, blk.bn2, _padc(p), _padc(p)),
+                         "c3": self._fold(blk.conv3, blk.bn3, _padc(p), _padc(cout)),
                          "down": None}
                 if blk.downsample is not None:
-                    entry["down"] = self._fold(blk.downsample[0], blk.downsample[1], _pad128(cin), _pad128(cout))
+                    entry["down"] = self._fold(blk.downsample[0], blk.downsample[1], _padc(cin), _padc(cout))
                 plan["blocks"].append(entry)
         self._folded, self._folded_key = plan, key
         return plan
@@ -157,8 +163,8 @@ class ResNet(nn.Module):
         cur = gemm(patches, plan["stem"], K.EPI_RELU)                       # conv1 + bn1 + relu (:139-141)
         Hc, Wc = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         rows = _pad128(B * Hc * Wc)
-        pooled = torch.empty(rows, 128, dtype=BF16, device=dev)
-        K.check(lib.icka_conv_maxpool3x3s2(cur.data_ptr(), pooled.data_ptr(), B, Ho, Wo, 128, rows, st()),
+        pooled = torch.empty(rows, 64, dtype=BF16, device=dev)
+        K.check(lib.icka_conv_maxpool3x3s2(cur.data_ptr(), pooled.data_ptr(), B, Ho, Wo, 64, rows, st()),
                 "icka_conv_maxpool3x3s2")                                    # maxpool (:142)
         cur = pooled
         for e in plan["blocks"]:                                             # Bottleneck.forward (:74-93)

@@ -27,7 +27,7 @@ def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
 
 # --------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (4096, 768, 768), (100, 13, 1536), (77, 200, 72),
-                                   (64, 40, 13), (1152, 768, 2048)])
+                                   (64, 40, 13), (1152, 768, 2048), (256, 64, 192), (1024, 64, 576), (128, 64, 64)])
 def test_gemm_nt(M, N, K):
     k = _k()
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
