@@ -14,6 +14,8 @@
 //   gemm_big_group_kernel  256x128 tiles for the grouped weight gradients + column-sum / slab-reduction blocks
 // LDS images are XOR-swizzled per layout (off_kc / off_km), the swizzle applied to the DMA source address.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -308,6 +310,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
 // NCOL = operand rows (k-contiguous) / columns (k-major) the tile really has: 128, or 96 for the narrow-N tile.  The
 // LDS image keeps the 128-wide geometry; with 96 the k-contiguous image simply has no pieces 12..15 and the k-major
 // image leaves chunks 12..15 of every row unused (their lanes re-fetch a valid chunk of the same row instead).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <bool KM, int NCOL = 128>
 __device__ __forceinline__ void dma_init(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int row0,
                                          int wave, int lane) {
@@ -395,8 +400,24 @@ __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t strid
 // f32 C tile in LDS: [128 rows][32 chunks of 4 floats], chunk index XORed with row&31
 __device__ __forceinline__ uint32_t off_c(int row, int ch) { return row * 512 + ((ch ^ (row & 31)) << 4); }
 
+// Output stores of the fast-path epilogues are NON-TEMPORAL: an FFN launch writes 25-50 MB, which as ordinary stores
+// pushed the operand panels out of the XCD's 4 MiB L2 (rocprofv3: L2 hit rate 0.57-0.79, 3-6x the algorithmic bytes
+// fetched over the fabric).  Measured on the c2 step: GEMM class 559 -> 593 TFLOP/s.
+template <typename T>
+__device__ __forceinline__ void st_out(T* p, const T v) {
+    __builtin_nontemporal_store(v, p);
+}
+// epilogue operands that are read exactly once (GELU' input, residual / fan-in addend, accumulate-into output)
+template <typename T>
+__device__ __forceinline__ T ld_once(const T* p) {
+#ifdef ICKA_NT_AUX
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ void load8_bf16(const bf16_t* p, float (&o)[8]) {
-    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
+    const bf16x8 v = as_bf16x8(ld_once(reinterpret_cast<const u32x4*>(p)));
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
 }
@@ -404,7 +425,7 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+    st_out(reinterpret_cast<u32x4*>(p), as_u32x4(o));
 }
 
 // Block -> output tile.  Blocks b and b+8 share an XCD (round-robin dispatch); each XCD has a private 4 MiB L2.
@@ -507,11 +528,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
             float* p = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
             f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
             if (g.beta != 0.f) {
-                o0 += g.beta * *reinterpret_cast<const f32x4*>(p);
-                o1 += g.beta * *reinterpret_cast<const f32x4*>(p + 4);
+                o0 += g.beta * ld_once(reinterpret_cast<const f32x4*>(p));
+                o1 += g.beta * ld_once(reinterpret_cast<const f32x4*>(p + 4));
             }
-            *reinterpret_cast<f32x4*>(p) = o0;
-            *reinterpret_cast<f32x4*>(p + 4) = o1;
+            st_out(reinterpret_cast<f32x4*>(p), o0);
+            st_out(reinterpret_cast<f32x4*>(p + 4), o1);
         } else {
             bf16_t* p = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
             if (g.beta != 0.f) {
@@ -792,19 +813,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
             int ahead = nk - 1 - kt;
             ahead = ahead > NBUF - 2 ? NBUF - 2 : ahead;
-            if constexpr (ND == 8) {
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else if constexpr (ND == 7) {
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                static_assert(ND == 8 || ND == 7 || ND == 6, "DMA count per k-tile");
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile kt has landed once at most `ahead` younger tiles (ND DMA instructions each) are still in flight
+            static_assert(NBUF <= 5 && ND * (NBUF - 2) <= 63, "vmcnt range");
+            switch (ahead) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<ND>(); break;
+                case 2: wait_vmcnt<2 * ND>(); break;
+                default: wait_vmcnt<(NBUF > 4 ? 3 : 0) * ND>(); break;
             }
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[0] += tB - tA; tA = tB;
@@ -980,9 +995,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                 for (int mi = 0; mi < 4; ++mi) {
                     const int m = m0 + wr + 16 * mi + (lane & 15);
                     const f32x4 v = acc[mi][ni] * g.alpha + b4;
-                    if (g.c_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = v;
-                    else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) =
-                             pack4(v[0], v[1], v[2], v[3]);
+                    if (g.c_f32) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
+                    else st_out(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
+                                pack4(v[0], v[1], v[2], v[3]));
                 }
             }
         }
@@ -1113,6 +1128,10 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     if (g_bn == 96 || (nb < 256 && nb96 <= 256 && nb96 > nb)) {
                         if ((g_ws == 2 || (g_ws == 1 && nb96 >= 448 && g.K <= 1024)) && !A_KM)
                             hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 96>), dim3(nb96), dim3(512), 0, st, g);
+                        else if (g_nbuf == 4)
+                            hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
+                        else if (g_nbuf == 5)
+                            hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         ICKA_CHECK_LAUNCH();
@@ -1124,6 +1143,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 if ((g_ws == 2 || (g_ws == 1 && nb >= 448 && g.K <= 1024)) && !A_KM)
                     hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM>), dim3(nb), dim3(512), 0, st, g);
                 else if (g_nbuf == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
+                else if (g_nbuf == 5) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5>), dim3(nb), dim3(512), 0, st, g);
                 else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3>), dim3(nb), dim3(512), 0, st, g);
                 ICKA_CHECK_LAUNCH();
                 return 0;
@@ -1188,7 +1208,7 @@ extern "C" int icka_gemm_set_tile_n(int bn) {
 }
 
 extern "C" int icka_gemm_set_ring(int nbuf) {
-    if (nbuf != 0 && (nbuf < 2 || nbuf > 4)) return ICKA_E_ARG;
+    if (nbuf != 0 && (nbuf < 2 || nbuf > 5)) return ICKA_E_ARG;
     g_nbuf = nbuf;
     return 0;
 }
@@ -1210,6 +1230,16 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
     g.abl = g_abl;
     g.stamp = g_stamp;
+#ifdef ICKA_GEMM_STAMP
+    {   // diagnostic builds: ICKA_GEMM_STAMP_FILTER="op,N,K" stamps only that shape (all GEMMs share one buffer)
+        static int f_op = -2, f_n = 0, f_k = 0;
+        if (f_op == -2) {
+            f_op = -1;
+            if (const char* e = getenv("ICKA_GEMM_STAMP_FILTER")) sscanf(e, "%d,%d,%d", &f_op, &f_n, &f_k);
+        }
+        if (f_op >= 0 && !(d->op == f_op && d->N == f_n && d->K == f_k)) g.stamp = nullptr;
+    }
+#endif
     g.colsum = d->colsum_out;
     g.colsum_acc = d->colsum_accumulate;
     g.ksplit = 1;
@@ -1432,8 +1462,8 @@ __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, 
             const int m = m0 + wsub * 128 + 16 * mi + (lane & 15);
             f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
             f32x4 v = acc[mi][ni] * g.alpha;
-            if (g.beta != 0.f) v += g.beta * *dst;   // gradient accumulation across micro-batches
-            *dst = v;
+            if (g.beta != 0.f) v += g.beta * ld_once(dst);   // gradient accumulation across micro-batches
+            st_out(dst, v);
         }
     }
 }
