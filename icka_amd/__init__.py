@@ -14,10 +14,12 @@ from .crf import CRF
 from .lstm import BiLSTM
 from .modeling import MTCCMBertForMMTokenClassificationCRF_gate_1
 from .dp import GradReducer
+from . import cross_modal
+from .cross_modal import PromptRobertaModel
 
 __all__ = ["CRF", "BiLSTM", "MTCCMBertForMMTokenClassificationCRF_gate_1", "BertConfig", "BertModel", "BertEmbeddings", "BertEncoder", "BertLayer", "BertLayerNorm", "BertPooler",
            "BertSelfEncoder", "BertCrossEncoder", "BertCrossAttentionLayer", "BertAttention", "BertCrossAttention",
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
            "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",
-           "token_ce_loss", "ParamArena",
+           "token_ce_loss", "ParamArena", "cross_modal", "PromptRobertaModel",
            "GradReducer"]

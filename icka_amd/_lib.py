@@ -112,6 +112,11 @@ PROTOTYPES = {
     "icka_crs_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                              c_vp]),
     "icka_add_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "icka_tanh_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "icka_embed_prompt_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                      c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_embed_prompt_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                      c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
     "icka_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "icka_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "icka_scalar_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp]),

@@ -189,6 +189,23 @@ __global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restric
     }
 }
 
+// dx = dy * (1 - y^2): backward of y = tanh(.) (the prompt mapping networks' activation)
+__global__ void tanh_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ dx, int64_t n) {
+    const int64_t nch = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nch; i += (int64_t)gridDim.x * blockDim.x) {
+        float g[8], t[8];
+        ld8(dy + i * 8, g); ld8(y + i * 8, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] *= 1.f - t[e] * t[e];
+        st8(dx + i * 8, g);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const int64_t j = (nch << 3) + threadIdx.x;
+        const float t = bf2f(y[j]);
+        dx[j] = f2bf(bf2f(dy[j]) * (1.f - t * t));
+    }
+}
+
 __global__ __launch_bounds__(256) void token_ce_kernel(const float* __restrict__ logits, int64_t ld,
                                                        const int64_t* __restrict__ labels, const int64_t* __restrict__ mask,
                                                        float* loss_sum, float* count, bf16_t* __restrict__ dl, int64_t ldd,
@@ -348,6 +365,15 @@ extern "C" int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, v
     if (!al16(a) || !al16(b) || !al16(c)) return ICKA_E_ALIGN;
     hipLaunchKernelGGL(add_kernel, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)c, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, void* stream) {
+    if (!dy || !y || !dx) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    if (!al16(dy) || !al16(y) || !al16(dx)) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)y, (bf16_t*)dx, n);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

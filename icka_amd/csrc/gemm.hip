@@ -335,6 +335,9 @@ __device__ __forceinline__ void dma_init(const bf16_t* (&ptr)[4], const bf16_t* 
 // ASM: hipcc treats a compiler-visible LDS-DMA as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the
 // next ds_read_b64_tr_b16, which serialises the whole pipeline; hidden in asm, the ring is ordered only by our own
 // counted vmcnt + s_barrier (cdna guide section 5.7).  M0 (LDS destination base) is saved/restored inside.
+#ifndef ICKA_DMA_POL
+#define ICKA_DMA_POL ""   // cache-policy bits of the operand loads (diagnostic builds: " nt", " sc1", " sc0 sc1")
+#endif
 template <int NJ = 4>
 __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t stride, uint32_t lds_base) {
     uint32_t keep;
@@ -343,10 +346,10 @@ __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t strid
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
+            "global_load_lds_dwordx4 %1, off" ICKA_DMA_POL "\n\t"
             "s_add_u32 m0, m0, 0x1000\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, off\n\t"
+            "global_load_lds_dwordx4 %2, off" ICKA_DMA_POL "\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(ptr[0]), "v"(ptr[1]), "s"(lds_base)
@@ -360,13 +363,13 @@ __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t strid
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %4\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
+            "global_load_lds_dwordx4 %1, off" ICKA_DMA_POL "\n\t"
             "s_add_u32 m0, m0, 0x1000\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, off\n\t"
+            "global_load_lds_dwordx4 %2, off" ICKA_DMA_POL "\n\t"
             "s_add_u32 m0, m0, 0x1000\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %3, off\n\t"
+            "global_load_lds_dwordx4 %3, off" ICKA_DMA_POL "\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
             : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "s"(lds_base)
@@ -379,16 +382,16 @@ __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t strid
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %5\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off" ICKA_DMA_POL "\n\t"
         "s_add_u32 m0, m0, 0x1000\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, off\n\t"
+        "global_load_lds_dwordx4 %2, off" ICKA_DMA_POL "\n\t"
         "s_add_u32 m0, m0, 0x1000\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, off\n\t"
+        "global_load_lds_dwordx4 %3, off" ICKA_DMA_POL "\n\t"
         "s_add_u32 m0, m0, 0x1000\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, off\n\t"
+        "global_load_lds_dwordx4 %4, off" ICKA_DMA_POL "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "s"(lds_base)

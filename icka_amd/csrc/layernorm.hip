@@ -313,6 +313,9 @@ struct EmbFwdArgs {
     const int64_t* ids; const int64_t* tt; const float* word; const float* pos; const float* type;
     const float* gamma; const float* beta; bf16_t* y; float* yf; bf16_t* xhat; float* rstd;
     int M, S, H, vocab, n_type; float eps; DropCfg drop;
+    // prompt splice (icka_embed_prompt_fwd): output position t takes token src[t] of the S_in-long id row, or, for
+    // src[t] < 0, prompt vector -1-src[t] of this sample's [P,H] bf16 prompt block; position row = t + pos_offset
+    const int32_t* src; const bf16_t* prompt; int S_in, P, pos_offset;
 };
 
 template <int NCH>
@@ -324,11 +327,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a_) {
     const int nchunk = a.H >> 3;
     const float inv_h = 1.f / (float)a.H;
     for (int row = wid; row < a.M; row += nw) {
-        int64_t id = a.ids[row];
+        const int sp = row % a.S;
+        const int sidx = a.src ? a.src[sp] : sp;
+        const bf16_t* prow = sidx < 0 ? a.prompt + ((int64_t)(row / a.S) * a.P + (-1 - sidx)) * a.H : nullptr;
+        int64_t id = sidx < 0 ? 0 : a.ids[a.src ? (int64_t)(row / a.S) * a.S_in + sidx : row];
         id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
         int64_t t = a.tt ? a.tt[row] : 0;
         t = t < 0 ? 0 : (t >= a.n_type ? a.n_type - 1 : t);
-        const int sp = row % a.S;
         float s[NCH][8];
         float sum = 0.f;
 #pragma unroll
@@ -336,8 +341,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a_) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float w[8], p[8], ty[8];
-                load8f(a.word + id * a.H + c * 8, w);
-                load8f(a.pos + (int64_t)sp * a.H + c * 8, p);
+                if (prow) load8(prow + c * 8, w);
+                else load8f(a.word + id * a.H + c * 8, w);
+                load8f(a.pos + (int64_t)(sp + a.pos_offset) * a.H + c * 8, p);
                 load8f(a.type + t * a.H + c * 8, ty);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[i][e] = (w[e] + p[e]) + ty[e]; sum += s[i][e]; }
@@ -381,6 +387,7 @@ struct EmbBwdArgs {
     const bf16_t* dy; const int64_t* ids; const int64_t* tt; const bf16_t* xhat; const float* rstd;
     const float* gamma; float* dword; float* dpos; float* dtype; float* partials;
     int M, S, H, vocab, n_type, padding_idx; DropCfg drop;
+    const int32_t* src; bf16_t* dprompt; int S_in, P, pos_offset;   // prompt splice, see EmbFwdArgs (pos kernel only)
 };
 
 template <int NCH>
@@ -483,9 +490,10 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
             for (int e = 0; e < 8; ++e) acc[s][i][e] = 0.f;
     float* rowbuf = lds_f + wave * a.H;
 
+    const int sidx = a.src ? a.src[sp] : sp;
     for (int b = wave; b < B; b += 8) {
         const int row = b * a.S + sp;
-        int64_t id = a.ids[row];
+        int64_t id = sidx < 0 ? 0 : a.ids[a.src ? (int64_t)b * a.S_in + sidx : row];
         id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
         int64_t t = a.tt ? a.tt[row] : 0;
         t = t < 0 ? 0 : (t >= a.n_type ? a.n_type - 1 : t);
@@ -529,7 +537,10 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
         }
         __builtin_amdgcn_wave_barrier();
         // word-table row: lane-strided f32 atomics (64 consecutive floats per wave instruction)
-        if (id != a.padding_idx || a.n_type > 2) {
+        if (sidx < 0) {   // prompt position: the row IS the gradient of this sample's prompt vector
+            bf16_t* dp = a.dprompt + ((int64_t)b * a.P + (-1 - sidx)) * a.H;
+            for (int j = lane; j < a.H; j += 64) dp[j] = f2bf(rowbuf[j]);
+        } else if (id != a.padding_idx || a.n_type > 2) {
             for (int j = lane; j < a.H; j += 64) {
                 const float ds = rowbuf[j];
                 if (id != a.padding_idx) atomicAdd(a.dword + id * a.H + j, ds);
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += lds_f[w * a.H + j];
             if (s < 4) a.partials[((int64_t)sp * SLOTS + s) * a.H + j] = v;
-            else a.dpos[(int64_t)sp * a.H + j] += v;   // this block owns position row sp (caller zeroes / accumulates)
+            else a.dpos[(int64_t)(sp + a.pos_offset) * a.H + j] += v;   // this block owns its position row (caller zeroes / accumulates)
         }
     }
 }
@@ -685,7 +696,29 @@ extern "C" int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, con
     if (!al16(word) || !al16(pos) || !al16(type) || !al16(gamma) || !al16(beta) || !al16(y) || (xhat && !al16(xhat)))
         return ICKA_E_ALIGN;
     EmbFwdArgs a{ids, token_type, word, pos, type, gamma, beta, (bf16_t*)y, y_f32, (bf16_t*)xhat, rstd,
-                 B * S, S, H, vocab, n_type, eps, make_drop(p_drop, seed)};
+                 B * S, S, H, vocab, n_type, eps, make_drop(p_drop, seed), nullptr, nullptr, S, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_NCH(pick_nch(H), embed_fwd_kernel, row_grid(B * S), 0, st, a);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+// Embeddings of a prompt-spliced sequence (the prompt-accepting encoder stage of the current reference model,
+// Cross_Modal_Interaction_Module.py:1010-1012): out[b, t] = LN(x + pos[t + pos_offset] + type[0]) with
+// x = word[ids[b, src[t]]] for src[t] >= 0, prompt[b, -1-src[t]] otherwise; S = len(src) output positions.
+extern "C" int icka_embed_prompt_fwd(const int64_t* ids, const int32_t* src, const void* prompt, const float* word,
+                                     const float* pos, const float* type, const float* gamma, const float* beta, void* y,
+                                     float* y_f32, void* xhat, float* rstd, int32_t B, int32_t S_in, int32_t S,
+                                     int32_t P, int32_t H, int32_t vocab, int32_t pos_offset, float eps, float p_drop,
+                                     uint64_t seed, void* stream) {
+    if (!ids || !src || !prompt || !word || !pos || !type || !gamma || !beta || !y) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || S_in <= 0 || P <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || pos_offset < 0)
+        return ICKA_E_SHAPE;
+    if (!al16(word) || !al16(pos) || !al16(type) || !al16(gamma) || !al16(beta) || !al16(y) || (xhat && !al16(xhat)) ||
+        !al16(prompt))
+        return ICKA_E_ALIGN;
+    EmbFwdArgs a{ids, nullptr, word, pos, type, gamma, beta, (bf16_t*)y, y_f32, (bf16_t*)xhat, rstd,
+                 B * S, S, H, vocab, 1, eps, make_drop(p_drop, seed), src, (const bf16_t*)prompt, S_in, P, pos_offset};
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), embed_fwd_kernel, row_grid(B * S), 0, st, a);
     ICKA_CHECK_LAUNCH();
@@ -703,7 +736,7 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
         return ICKA_E_SHAPE;
     if (!al16(dy) || !al16(xhat) || !al16(gamma)) return ICKA_E_ALIGN;
     EmbBwdArgs a{(const bf16_t*)dy, ids, token_type, (const bf16_t*)xhat, rstd, gamma, dword, dpos, dtype, partials,
-                 B * S, S, H, vocab, n_type, padding_idx, make_drop(p_drop, seed)};
+                 B * S, S, H, vocab, n_type, padding_idx, make_drop(p_drop, seed), nullptr, nullptr, S, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     int grid = bwd_grid(B * S);
     if (S <= BWD_BLOCKS) {   // position-major: one block per position, S slabs
@@ -722,6 +755,36 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
     float* t1 = n_type == 2 ? dtype + H : nullptr;
     hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, grid, H, dgamma,
                        dbeta, t0, t1, accumulate);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward of icka_embed_prompt_fwd: word / position / type-row-0 table gradients, dgamma, dbeta, and the gradient of
+// the prompt block (bf16 [B,P,H], every row written exactly once).  partials: S * 4 * H floats.
+extern "C" int icka_embed_prompt_bwd(const void* dy, const int64_t* ids, const int32_t* src, const void* xhat,
+                                     const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype,
+                                     float* dgamma, float* dbeta, void* dprompt, float* partials, int32_t B,
+                                     int32_t S_in, int32_t S, int32_t P, int32_t H, int32_t vocab, int32_t pos_offset,
+                                     int32_t padding_idx, float p_drop, uint64_t seed, int32_t accumulate, void* stream) {
+    if (!dy || !ids || !src || !xhat || !rstd || !gamma || !dword || !dpos || !dtype || !dgamma || !dbeta || !dprompt ||
+        !partials)
+        return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || S > BWD_BLOCKS || S_in <= 0 || P <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH ||
+        vocab <= 0 || pos_offset < 0)
+        return ICKA_E_SHAPE;
+    if (!al16(dy) || !al16(xhat) || !al16(gamma)) return ICKA_E_ALIGN;
+    EmbBwdArgs a{(const bf16_t*)dy, ids, nullptr, (const bf16_t*)xhat, rstd, gamma, dword, dpos, dtype, partials,
+                 B * S, S, H, vocab, 1, padding_idx, make_drop(p_drop, seed), src, (bf16_t*)dprompt, S_in, P, pos_offset};
+    hipStream_t st = (hipStream_t)stream;
+    switch (pick_nch(H)) {
+        case 1: hipLaunchKernelGGL((embed_bwd_pos_kernel<1>), dim3(S), dim3(512), 8 * H * sizeof(float), st, a); break;
+        case 2: hipLaunchKernelGGL((embed_bwd_pos_kernel<2>), dim3(S), dim3(512), 8 * H * sizeof(float), st, a); break;
+        case 3: hipLaunchKernelGGL((embed_bwd_pos_kernel<3>), dim3(S), dim3(512), 8 * H * sizeof(float), st, a); break;
+        default: hipLaunchKernelGGL((embed_bwd_pos_kernel<4>), dim3(S), dim3(512), 8 * H * sizeof(float), st, a); break;
+    }
+    ICKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, S, H, dgamma, dbeta,
+                       dtype, (float*)nullptr, accumulate);   // slot 2 = token-type row 0 (every row is type 0)
     ICKA_CHECK_LAUNCH();
     return 0;
 }

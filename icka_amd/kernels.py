@@ -294,6 +294,59 @@ def embed_bwd(dy, ids, token_type, xhat, rstd, gamma, dword, dpos, dtype_, dgamm
           "icka_embed_bwd")
 
 
+def embed_prompt_fwd(ids, src, prompt, word, pos, typ, gamma, beta, y, *, y_f32=None, xhat=None, rstd=None,
+                     pos_offset=0, eps=1e-5, p_drop=0.0, seed=0):
+    """Prompt-spliced embeddings + LayerNorm + dropout (icka_hip.h: icka_embed_prompt_fwd).  ids int64 [B,S_in],
+    src int32 [S], prompt bf16 [B,P,H] contiguous, y bf16 [B*S,H]."""
+    lib = _lib.load()
+    _dev(ids, "ids"); _dev(src, "src"); _dev(prompt, "prompt")
+    if ids.dtype != torch.int64 or not ids.is_contiguous() or ids.dim() != 2:
+        raise ValueError("ids must be contiguous int64 [B,S_in]")
+    if src.dtype != torch.int32 or src.dim() != 1 or not src.is_contiguous():
+        raise ValueError("src must be contiguous int32 [S]")
+    B, S_in = ids.shape
+    S, H = src.shape[0], word.shape[1]
+    if prompt.dtype != BF16 or prompt.dim() != 3 or prompt.shape[0] != B or prompt.shape[2] != H or not prompt.is_contiguous():
+        raise ValueError("prompt must be contiguous bf16 [B,P,H]")
+    if pos.shape[0] < S + pos_offset:
+        raise ValueError("position table has %d rows, the spliced sequence needs %d" % (pos.shape[0], S + pos_offset))
+    if tuple(y.shape) != (B * S, H):
+        raise ValueError("y must be [B*S,H]")
+    check(lib.icka_embed_prompt_fwd(ids.data_ptr(), src.data_ptr(), prompt.data_ptr(), word.data_ptr(), pos.data_ptr(),
+                                    typ.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(y_f32),
+                                    _ptr(xhat), _ptr(rstd), B, S_in, S, prompt.shape[1], H, word.shape[0], pos_offset,
+                                    eps, p_drop, seed, _stream()), "icka_embed_prompt_fwd")
+    return y
+
+
+def embed_prompt_bwd(dy, ids, src, xhat, rstd, gamma, dword, dpos, dtype_, dgamma, dbeta, dprompt, partials, *,
+                     pos_offset=0, padding_idx=1, p_drop=0.0, seed=0, accumulate=True):
+    lib = _lib.load()
+    B, S_in = ids.shape
+    S, H = src.shape[0], dword.shape[1]
+    if dprompt.dtype != BF16 or not dprompt.is_contiguous() or dprompt.shape[0] != B or dprompt.shape[2] != H:
+        raise ValueError("dprompt must be contiguous bf16 [B,P,H]")
+    if partials.numel() < S * lib.icka_ln_slab_slots() * H:
+        raise ValueError("partials too small")
+    check(lib.icka_embed_prompt_bwd(dy.data_ptr(), ids.data_ptr(), src.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+                                    gamma.data_ptr(), dword.data_ptr(), dpos.data_ptr(), dtype_.data_ptr(),
+                                    dgamma.data_ptr(), dbeta.data_ptr(), dprompt.data_ptr(), partials.data_ptr(), B,
+                                    S_in, S, dprompt.shape[1], H, dword.shape[0], pos_offset, padding_idx, p_drop, seed,
+                                    int(accumulate), _stream()), "icka_embed_prompt_bwd")
+
+
+def tanh_bwd(dy, y, dx):
+    """dx = dy * (1 - y^2), contiguous bf16."""
+    for n, t in (("dy", dy), ("y", y), ("dx", dx)):
+        _dev(t, n)
+        if t.dtype != BF16 or not t.is_contiguous():
+            raise ValueError("%s must be contiguous bf16" % n)
+    if dy.numel() != y.numel() or dx.numel() != y.numel():
+        raise ValueError("tanh_bwd: size mismatch")
+    check(_lib.load().icka_tanh_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "icka_tanh_bwd")
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------- attention
 def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False):
     """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection).

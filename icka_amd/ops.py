@@ -327,9 +327,8 @@ class LinearFn(torch.autograd.Function):
             dyv = dyb[:, :N]
         else:
             dyv = _c(dy)
-        if ctx.epi == K.EPI_TANH:
-            raise NotImplementedError("backward through the tanh pooler is outside the hot path (pooled output only "
-                                      "feeds the reference's contrastive loss, SURVEY.md section 8a a9)")
+        if ctx.epi == K.EPI_TANH:   # y = tanh(pre): d(pre) = dy * (1 - y^2)
+            dyv = K.tanh_bwd(dyv if dyv.is_contiguous() else dyv.contiguous(), y, torch.empty_like(y))
         fused = lin.bias is not None and N % 128 == 0 and x.shape[1] % 128 == 0 and M % 64 == 0
         K.gemm(K.GEMM_TN, dyv, x, A.g(lin.weight), beta=A.grad_beta(lin.weight),
                colsum_out=A.g(lin.bias) if fused else None,
@@ -521,6 +520,133 @@ class AddLayerNormFn(torch.autograd.Function):
                  accumulate=acc)
         A.flush_final()
         return None, d, d, None, None, None
+
+
+class FanOutFn(torch.autograd.Function):
+    """y1 = y2 = ... = x for a tensor with several consumers; the backward sums the branch gradients with the bf16
+    add kernel instead of leaving the fan-in to autograd's own accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        acc = None
+        for g in grads:
+            if g is None:
+                continue
+            g = _c(g)
+            acc = g if acc is None else K.add_bf16(acc, g, torch.empty_like(g))
+        return acc, None
+
+
+class PromptMappingFn(torch.autograd.Function):
+    """The reference's prompt mapping networks (Cross_Modal_Interaction_Module.py:914-928, calls :995, :998):
+    nn.Sequential(Dropout(p), Linear(in, N1), Tanh(), Dropout(p), Linear(N1, N2)) on [rows, in] bf16.
+    N1 = 756 * prompt_len = 3780 is not a multiple of 8, so the hidden activation lives in a zero-padded
+    [rows, N1p] buffer (N1p = N1 rounded up to 8): dropout / tanh' run on the padded rows, the GEMMs on views."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, lin1, lin2, A: ParamArena, p: float):
+        M, Kin = x.shape
+        N1, N2 = lin1.weight.shape[0], lin2.weight.shape[0]
+        N1p = (N1 + 7) // 8 * 8
+        s1 = A.next_seed() if p > 0 else 0
+        s2 = A.next_seed() if p > 0 else 0
+        xd = x
+        if p > 0:
+            xd = torch.empty_like(x)
+            K.dropout(x, xd, p_drop=p, seed=s1)
+        h = torch.zeros(M, N1p, dtype=BF16, device=x.device)
+        K.gemm(K.GEMM_NT, xd, A.w(lin1.weight), h[:, :N1], bias=lin1.bias, epilogue=K.EPI_TANH)
+        hd = h
+        if p > 0:
+            hd = torch.empty_like(h)
+            K.dropout(h, hd, p_drop=p, seed=s2)
+        y = torch.empty(M, N2, dtype=BF16, device=x.device)
+        K.gemm(K.GEMM_NT, hd[:, :N1], A.w(lin2.weight), y, bias=lin2.bias)
+        ctx.lin1, ctx.lin2, ctx.A, ctx.p, ctx.s1, ctx.s2 = lin1, lin2, A, p, s1, s2
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(xd, h, hd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, h, hd = ctx.saved_tensors
+        lin1, lin2, A, p = ctx.lin1, ctx.lin2, ctx.A, ctx.p
+        dy = _c(dy)
+        M, N2 = dy.shape
+        N1, N1p = lin1.weight.shape[0], h.shape[1]
+        lib = K._lib.load()
+        # second Linear: dW2 = dy^T . hd, db2 = colsum(dy), d(hd) = dy . W2
+        K.gemm(K.GEMM_TN, dy, hd[:, :N1], A.g(lin2.weight), beta=A.grad_beta(lin2.weight))
+        K.colsum(dy, A.g(lin2.bias), A.workspace("colsum", lib.icka_colsum_workspace_floats(N2)),
+                 accumulate=A.grad_beta(lin2.bias) > 0)
+        dh = torch.zeros(M, N1p, dtype=BF16, device=dy.device)
+        K.gemm(K.GEMM_NN, dy, A.w(lin2.weight), dh[:, :N1])
+        if p > 0:
+            K.dropout(dh, dh, p_drop=p, seed=ctx.s2)
+        dpre = K.tanh_bwd(dh, h, torch.empty_like(h))
+        # first Linear
+        K.gemm(K.GEMM_TN, dpre[:, :N1], xd, A.g(lin1.weight), beta=A.grad_beta(lin1.weight))
+        K.colsum(dpre[:, :N1], A.g(lin1.bias), A.workspace("colsum", lib.icka_colsum_workspace_floats(N1)),
+                 accumulate=A.grad_beta(lin1.bias) > 0)
+        dx = None
+        if ctx.need_dx:
+            dx = torch.empty_like(xd)
+            K.gemm(K.GEMM_NN, dpre[:, :N1], A.w(lin1.weight), dx)
+            if p > 0:
+                K.dropout(dx, dx, p_drop=p, seed=ctx.s1)
+        A.flush_final()
+        return None, dx, None, None, None, None
+
+
+class PromptEmbeddingsFn(torch.autograd.Function):
+    """Embeddings of the prompt-accepting encoder stage (icka_hip.h: icka_embed_prompt_fwd): word rows gathered by
+    ``src`` with the prompt vectors spliced in, + position (offset) + type row 0 -> LayerNorm -> dropout."""
+
+    @staticmethod
+    def forward(ctx, anchor, prompt, mod, A: ParamArena, ids, src, d: Dims, pos_offset: int):
+        B = ids.shape[0]
+        S, H = src.shape[0], d.H
+        save = any(ctx.needs_input_grad)
+        y = torch.empty(B * S, H, dtype=BF16, device=ids.device)
+        yf = torch.empty(B * S, H, dtype=F32, device=ids.device)
+        xhat = torch.empty_like(y) if save else None
+        rstd = torch.empty(B * S, dtype=F32, device=ids.device) if save else None
+        seed = A.next_seed() if d.p_hidden > 0 else 0
+        prompt = prompt if prompt.is_contiguous() else prompt.contiguous()
+        K.embed_prompt_fwd(ids, src, prompt, mod.word_embeddings.weight, mod.position_embeddings.weight,
+                           mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias, y, y_f32=yf,
+                           xhat=xhat, rstd=rstd, pos_offset=pos_offset, eps=d.eps, p_drop=d.p_hidden, seed=seed)
+        ctx.mod, ctx.A, ctx.d, ctx.seed, ctx.pos_offset, ctx.pshape = mod, A, d, seed, pos_offset, tuple(prompt.shape)
+        ctx.save_for_backward(ids, src, xhat, rstd)
+        ctx.mark_non_differentiable(yf)
+        ctx.set_materialize_grads(False)
+        return y, yf
+
+    @staticmethod
+    def backward(ctx, dy, _dyf=None):
+        mod, A, d = ctx.mod, ctx.A, ctx.d
+        ids, src, xhat, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        S = src.shape[0]
+        ws = A.workspace("embp", S * K._lib.load().icka_ln_slab_slots() * d.H)
+        tables = (mod.word_embeddings.weight, mod.position_embeddings.weight)
+        if A.grad_beta(tables) == 0.0:
+            A.g(tables[0]).zero_()
+            A.g(tables[1]).zero_()
+        small = (mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
+        acc = A.grad_beta(small) > 0
+        dprompt = torch.empty(ctx.pshape, dtype=BF16, device=dy.device)
+        pad = mod.word_embeddings.padding_idx
+        K.embed_prompt_bwd(dy, ids, src, xhat, rstd, mod.LayerNorm.weight, A.g(tables[0]), A.g(tables[1]),
+                           A.g(small[0]), A.g(small[1]), A.g(small[2]), dprompt, ws, pos_offset=ctx.pos_offset,
+                           padding_idx=-1 if pad is None else pad, p_drop=d.p_hidden, seed=ctx.seed, accumulate=acc)
+        A.flush_final()
+        return None, dprompt, None, None, None, None, None, None
 
 
 class TokenCEFn(torch.autograd.Function):

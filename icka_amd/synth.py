@@ -111,3 +111,39 @@ def synthetic_batch(batch: int, seq_len: int, regions: int, num_labels: int = 13
         "added_attention_mask": added, "visual_embeds_mean": vis_mean, "visual_embeds_att": vis,
         "labels": labels, "lengths": lengths,
     }
+
+
+def synthetic_prompt_batch(batch: int, seq_len: int = 128, vocab_size: int = 30522, roberta_vocab: int = 50265,
+                           prompt_tokens: int = 17, total_len: int = 170, num_labels: int = 13,
+                           seed: int = REFERENCE_SEED, mask_positions=(3, 11), mask_id: Optional[int] = None,
+                           ) -> Dict[str, torch.Tensor]:
+    """Inputs of the reference's current model (Cross_Modal_Interaction_Module.py:941-943) in the conventions of
+    My_cross_attention.py:291-420: the text-encoder view (``ori_*``, ``seq_len`` tokens, as ``synthetic_batch``) and the
+    prompt-encoder view ``input_ids`` = ``prompt_tokens`` prompt-text ids (``<mask>`` at ``mask_positions``) followed by
+    the sentence's ids, zero-padded to ``total_len`` (= max_seq_length + prompt words + 30, :305); ``offsets`` =
+    ``prompt_tokens`` for every sample (:395, asserted equal per batch at :802); CLIP feature [B,1,512]."""
+    b = synthetic_batch(batch, seq_len, 49, num_labels=num_labels, vocab_size=vocab_size, seed=seed, layout="BCHW")
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 1)
+    mask_id = roberta_vocab - 1 if mask_id is None else mask_id
+    prompt = torch.randint(3, roberta_vocab - 1, (prompt_tokens,), generator=g)
+    for p in mask_positions:
+        prompt[p] = mask_id
+    sent = torch.randint(3, roberta_vocab - 1, (batch, seq_len), generator=g) * b["input_mask"] \
+        + (1 - b["input_mask"])                                        # RoBERTa pad id 1 past the length
+    ids = torch.ones(batch, total_len, dtype=torch.long)
+    ids[:, :prompt_tokens] = prompt[None]
+    ids[:, prompt_tokens:prompt_tokens + seq_len] = sent
+    mask = torch.zeros(batch, total_len, dtype=torch.long)
+    mask[:, :prompt_tokens] = 1
+    mask[:, prompt_tokens:prompt_tokens + seq_len] = b["input_mask"]
+    out = {
+        "input_ids": ids, "segment_ids": torch.zeros_like(ids), "input_mask": mask,
+        "ori_input_ids": b["input_ids"], "ori_input_mask": b["input_mask"], "ori_segment_ids": b["segment_ids"],
+        "added_attention_mask": b["added_attention_mask"],
+        "clip_features": torch.empty(batch, 1, 512).normal_(0.0, 1.0, generator=g),
+        "visual_embeds_mean": b["visual_embeds_mean"], "visual_embeds_att": b["visual_embeds_att"],
+        "offsets": torch.full((batch,), prompt_tokens, dtype=torch.long), "output_mask": b["input_mask"],
+        "labels": b["labels"],
+    }
+    return out

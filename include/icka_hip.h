@@ -148,6 +148,26 @@ int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type
                    const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma,
                    float* dbeta, float* partials, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type,
                    int32_t padding_idx, float p_drop, uint64_t seed, int32_t accumulate, void* stream);
+/* Embeddings of the prompt-accepting encoder stage that ends the current reference model
+ * (Cross_Modal_Interaction_Module.py:1010-1012: last_encoder(input_ids=..., prompt_embeddings=prefix_emb, ...); its
+ * package `local_transformers` is absent from the reference tree, so the splice rule is this build's definition, taken
+ * from the reference's own offset arithmetic :1022 and the token dump at My_cross_attention.py:402-404):
+ *   out[b, t] = dropout(LayerNorm(x + pos[t + pos_offset] + type[0])),   t in [0, S)
+ *   x = word[ids[b, src[t]]]            if src[t] >= 0   (ids int64 [B, S_in])
+ *     = prompt[b, -1 - src[t]]          otherwise        (prompt bf16 [B, P, H])
+ * src is int32 [S], shared by the batch (the reference asserts equal offsets per batch, My_cross_attention.py:802). */
+int icka_embed_prompt_fwd(const int64_t* ids, const int32_t* src, const void* prompt, const float* word,
+                          const float* pos, const float* type, const float* gamma, const float* beta, void* y,
+                          float* y_f32, void* xhat, float* rstd, int32_t B, int32_t S_in, int32_t S, int32_t P,
+                          int32_t H, int32_t vocab, int32_t pos_offset, float eps, float p_drop, uint64_t seed,
+                          void* stream);
+/* Backward: table gradients as icka_embed_bwd (dtype = row 0 only), plus dprompt bf16 [B, P, H] (each row written
+ * once).  S <= 1024.  partials: S * icka_ln_slab_slots() * H floats. */
+int icka_embed_prompt_bwd(const void* dy, const int64_t* ids, const int32_t* src, const void* xhat, const float* rstd,
+                          const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta,
+                          void* dprompt, float* partials, int32_t B, int32_t S_in, int32_t S, int32_t P, int32_t H,
+                          int32_t vocab, int32_t pos_offset, int32_t padding_idx, float p_drop, uint64_t seed,
+                          int32_t accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused multi-head attention, head size 64 (bert-base 768/12, bert-large 1024/16).
@@ -240,6 +260,9 @@ int icka_crs_bwd(const float* dcrs, const void* seq, int64_t lds, const void* cr
                  int32_t accumulate, void* stream);
 /* c = a + b (bf16, contiguous n elements; gradient fan-in). */
 int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, void* stream);
+/* dx = dy * (1 - y*y) (bf16, contiguous n elements): backward of the Tanh inside the prompt mapping networks
+ * (Cross_Modal_Interaction_Module.py:914-928: Dropout, Linear, Tanh, Dropout, Linear). */
+int icka_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 /* Token-level cross-entropy over valid tokens (benchmark loss), fused forward + backward:
  * logits f32 [M,C] (ld), labels/mask int64 [M]; loss_sum f32[1] += sum of -log p ; count f32[1] += #valid ;
  * dlogits bf16 [M, ldd] (ldd >= C, pad columns zeroed) = (softmax - onehot) * valid  (see icka_scale_by_ratio). */

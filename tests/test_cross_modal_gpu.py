@@ -1,0 +1,171 @@
+"""GPU: the reference's current (published) model on the HIP kernels (icka_amd.cross_modal) against the fixture produced
+by the reference's own forward and against the CPU oracle's autograd (last row)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _args(g):
+    return dict(input_ids=g["input_ids"], segment_ids=g["segment_ids"], input_mask=g["input_mask"],
+                ori_input_ids=g["ori_input_ids"], ori_input_mask=g["ori_input_mask"],
+                ori_segment_ids=g["ori_segment_ids"], added_attention_mask=g["added_attention_mask"],
+                clip_features=g["clip_features"], visual_embeds_mean=g["visual_embeds_mean"],
+                visual_embeds_att=g["visual_embeds_att"], offsets=g["offsets"], output_mask=g["output_mask"],
+                labels=g["labels"])
+
+
+def test_full_model_against_reference_fixture_and_oracle_gradients():
+    from test_cross_modal_cpu import build_case, oracle_emissions
+    from oracle import crf_oracle as OC
+    fx = np.load(os.path.join(HERE, "golden", "cross_modal_h1024_l1.npz"))
+    model, ocfg, ocfg_r, b = build_case(fx)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    g = {k: v.cuda() for k, v in b.items()}
+    em = model(**_args(g))                                   # mode=None -> emissions
+    ref = torch.from_numpy(fx["emissions"])
+    err = (em.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
+    loss = model(mode="train", **_args(g))
+    loss.backward()
+    pred, dev_loss = model(mode="dev", **_args(g))
+    assert abs(dev_loss.item() - loss.item()) < 1e-4
+    assert model(mode="test", **_args(g)) == pred
+    # ---- CPU oracle: same loss, gradients through every stage
+    oem, _ = oracle_emissions(P, ocfg, ocfg_r, b)
+    mask = b["output_mask"].bool()
+    crfP = [P["crf.start_transitions"], P["crf.end_transitions"], P["crf.transitions"]]
+    rloss = -OC.crf_reduce(OC.crf_llh(oem, b["labels"], mask, *crfP), mask, "token_mean")
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) < 2e-2 * max(1.0, abs(rloss.item()))
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst, worst_key, checked = 0.0, None, 0
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        rel = ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-3 * gmax)).item()
+        checked += 1
+        if rel > worst:
+            worst, worst_key = rel, k
+    assert checked > 100
+    assert worst < 0.15, (worst_key, worst)
+    assert pred == OC.crf_decode(em.float().cpu(), mask, *[p.detach() for p in crfP])
+    print("\n[published model] emissions vs reference fixture max abs err %.3e, loss %.4f (oracle %.4f), worst grad rel "
+          "err %.3e (%s) over %d tensors" % (err, loss.item(), rloss.item(), worst, worst_key, checked))
+
+
+def test_full_model_train_mode_step_and_foreign_encoder_rejected():
+    """Dropout on (0.1 hidden / attention, 0.3 in the mapping networks): finite loss and gradients for every stage;
+    a non-icka last_encoder or embedding is refused (there is no eager fallback)."""
+    from test_cross_modal_cpu import build_case
+    from icka_amd.cross_modal import MTCCMBertForMMTokenClassificationCRF
+    fx = np.load(os.path.join(HERE, "golden", "cross_modal_h1024_l1.npz"))
+    model, _, _, b = build_case(fx)
+    model = model.cuda().train()
+    g = {k: v.cuda() for k, v in b.items()}
+    loss = model(mode="train", **_args(g))
+    loss.backward()
+    assert torch.isfinite(loss).item()
+    for n in ("mapping_network_alignment.1.weight", "mapping_network_vision.4.weight", "vismapping.weight",
+              "cls_layer_Y.1.layer.0.attention.self.query.weight", "last_encoder.embeddings.word_embeddings.weight",
+              "last_encoder.encoder.layer.0.output.dense.weight", "bert.embeddings.word_embeddings.weight",
+              "aux_head.weight", "lstm.weight_hh_l0_reverse", "crf.transitions"):
+        gr = model.get_parameter(n).grad
+        assert gr is not None and torch.isfinite(gr).all().item() and gr.abs().sum().item() > 0, n
+    with pytest.raises(TypeError):
+        MTCCMBertForMMTokenClassificationCRF(model.config, None, torch.nn.Linear(4, 4), num_labels=13)
+    with pytest.raises(ValueError):
+        MTCCMBertForMMTokenClassificationCRF(model.config, None, None, num_labels=13)
+
+
+def test_prompt_embedding_kernels_against_torch():
+    """icka_embed_prompt_fwd / bwd: spliced gather + position offset + LayerNorm, and every gradient (word / position /
+    type tables, gamma, beta, prompt block) against fp32 autograd."""
+    from icka_amd import kernels as K
+    from oracle.cross_modal_oracle import splice_index
+    torch.manual_seed(5)
+    B, S_in, P, H, V = 3, 21, 10, 256, 97
+    ids = torch.randint(0, V, (B, S_in))
+    ids[0, -3:] = 1
+    src = torch.tensor(splice_index(S_in, P), dtype=torch.int32)
+    S = src.shape[0]
+    word = torch.randn(V, H) * 0.5
+    pos = torch.randn(S + 4, H) * 0.5
+    typ = torch.randn(1, H) * 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(H), 0.1 * torch.randn(H)
+    prompt = (torch.randn(B, P, H) * 0.5).bfloat16()
+    dy = torch.randn(B * S, H).bfloat16()
+    # fp32 reference
+    t = [x.clone().requires_grad_(True) for x in (word, pos, typ, gamma, beta, prompt.float())]
+    idx = src.long()
+    x = torch.where((idx >= 0)[None, :, None], torch.nn.functional.embedding(ids, t[0])[:, idx.clamp(min=0)],
+                    t[5][:, (-1 - idx).clamp(min=0)])
+    x = x + t[1][torch.arange(S) + 2][None] + t[2][0]
+    ref = torch.nn.functional.layer_norm(x, (H,), t[3], t[4], 1e-5).reshape(B * S, H)
+    ref.backward(dy.float())
+    dword_ref = t[0].grad.clone()
+    dword_ref[1] = 0          # padding_idx row receives no gradient
+    # kernels
+    c = lambda z: z.cuda()
+    y = torch.empty(B * S, H, dtype=torch.bfloat16, device="cuda")
+    yf = torch.empty(B * S, H, device="cuda")
+    xhat = torch.empty_like(y)
+    rstd = torch.empty(B * S, device="cuda")
+    K.embed_prompt_fwd(c(ids), c(src), c(prompt), c(word), c(pos), c(typ), c(gamma), c(beta), y, y_f32=yf, xhat=xhat,
+                       rstd=rstd, pos_offset=2, eps=1e-5)
+    assert (yf.cpu() - ref.detach()).abs().max().item() < 1e-4
+    dword, dpos, dtyp = torch.zeros(V, H, device="cuda"), torch.zeros(S + 4, H, device="cuda"), torch.zeros(1, H, device="cuda")
+    dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    dprompt = torch.empty(B, P, H, dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(S * 4 * H, device="cuda")
+    K.embed_prompt_bwd(c(dy), c(ids), c(src), xhat, rstd, c(gamma), dword, dpos, dtyp, dg, db, dprompt, ws,
+                       pos_offset=2, padding_idx=1, accumulate=False)
+    for name, got, want in (("word", dword, dword_ref), ("pos", dpos, t[1].grad), ("type", dtyp, t[2].grad),
+                            ("gamma", dg, t[3].grad), ("beta", db, t[4].grad), ("prompt", dprompt.float(), t[5].grad)):
+        rel = ((got.cpu() - want).norm() / (want.norm() + 1e-6)).item()
+        assert rel < 2e-2, (name, rel)
+
+
+def test_prompt_mapping_network_against_torch():
+    """Dropout / Linear(in, 3780) / Tanh / Dropout / Linear(3780, 5H) with the odd 3780 width: forward and all five
+    gradients against fp32 autograd (eval mode), mask consistency between forward and backward in train mode."""
+    from icka_amd import ops
+    from icka_amd.arena import arena_of
+    torch.manual_seed(9)
+    B, Kin, N1, N2 = 6, 256, 3780, 640
+    net = torch.nn.Sequential(torch.nn.Dropout(0.3), torch.nn.Linear(Kin, N1), torch.nn.Tanh(), torch.nn.Dropout(0.3),
+                              torch.nn.Linear(N1, N2))
+    ref = torch.nn.Sequential(torch.nn.Dropout(0.3), torch.nn.Linear(Kin, N1), torch.nn.Tanh(), torch.nn.Dropout(0.3),
+                              torch.nn.Linear(N1, N2))
+    ref.load_state_dict(net.state_dict())
+    ref.eval()
+    x = torch.randn(B, Kin)
+    dy = torch.randn(B, N2) * 0.1
+    xr = x.bfloat16().float().requires_grad_(True)
+    ref(xr).backward(dy.bfloat16().float())
+    net = net.cuda()
+    A = arena_of(net)
+    A.begin_step(); A.sync()
+    xg = x.bfloat16().cuda().requires_grad_(True)
+    y = ops.PromptMappingFn.apply(A.anchor, xg, net[1], net[4], A, 0.0)
+    y.backward(dy.bfloat16().cuda())
+    assert ((y.float().cpu() - ref(xr).detach()).norm() / ref(xr).norm()).item() < 1e-2
+    for name, got, want in (("dx", xg.grad.float().cpu(), xr.grad), ("dW1", net[1].weight.grad.cpu(), ref[1].weight.grad),
+                            ("db1", net[1].bias.grad.cpu(), ref[1].bias.grad), ("dW2", net[4].weight.grad.cpu(), ref[4].weight.grad),
+                            ("db2", net[4].bias.grad.cpu(), ref[4].bias.grad)):
+        rel = ((got - want).norm() / (want.norm() + 1e-6)).item()
+        assert rel < 3e-2, (name, rel)
+    # train mode: with dy = 0 except one output, dx must vanish wherever the input mask dropped x (mask re-generated)
+    net.zero_grad(); A.begin_step()
+    xg2 = torch.ones(B, Kin, dtype=torch.bfloat16, device="cuda", requires_grad=True)
+    y2 = ops.PromptMappingFn.apply(A.anchor, xg2, net[1], net[4], A, 0.3)
+    y2.float().sum().backward()
+    dropped = (xg2.grad == 0).float().mean().item()
+    assert 0.2 < dropped < 0.4, dropped
