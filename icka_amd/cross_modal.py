@@ -111,6 +111,20 @@ class PromptRobertaModel(BertPreTrainedModel):
             raise ValueError("prompt_embeddings must be [B, P, %d]" % H)
         self._arena()
         src = self.splice_index(S_in, P, input_ids.device)
+        S_out = src.shape[0]
+        # Row alignment: the GEMM fast path wants B*S % 128 == 0 (B=32, S=178 -> 5696 rows would fall on the general
+        # kernel for every GEMM of the stack).  Up to 7 masked-out positions are appended (they re-read the last token
+        # id, get additive mask -10000 and are cut off again below), e.g. 178 -> 180.
+        extra = next((e for e in range(8) if (B * (S_out + e)) % 128 == 0), 0)
+        if extra and S_out + extra + self.embeddings.padding_idx + 1 <= self.embeddings.position_embeddings.weight.shape[0]:
+            key = (S_in, P, extra, str(input_ids.device))
+            padded = self._src_cache.get(key)
+            if padded is None:
+                padded = torch.cat([src, torch.full((extra,), S_in - 1, dtype=torch.int32, device=src.device)])
+                self._src_cache[key] = padded
+            src = padded
+        else:
+            extra = 0
         S = src.shape[0]
         # spliced 0/1 mask: token entries from attention_mask, prompt entries from input_mask (index plumbing only)
         am = torch.ones(B, S_in, dtype=torch.int64, device=input_ids.device) if attention_mask is None \
@@ -118,13 +132,15 @@ class PromptRobertaModel(BertPreTrainedModel):
         pm = torch.ones(B, P, dtype=torch.int64, device=input_ids.device) if input_mask is None else input_mask.long()
         idx = src.long()
         spliced = torch.where((idx >= 0).unsqueeze(0), am[:, idx.clamp(min=0)], pm[:, (-1 - idx).clamp(min=0)])
+        if extra:
+            spliced[:, S_out:] = 0
         add_mask = K.additive_mask(spliced.contiguous(), S, torch.empty(B, S, dtype=F32, device=input_ids.device))
         pe = prompt_embeddings
         if pe.dtype != BF16:
             pe = _CastFn.apply(pe.contiguous(), True)
         x = self.embeddings(input_ids, src, pe)
         out = self.encoder(x, add_mask.view(B, 1, 1, S), output_all_encoded_layers=False)[-1]
-        return (out,)
+        return (out[:, :S_out] if extra else out,)
 
 
 class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):

@@ -502,13 +502,17 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
-    if (g_lstm_persistent && nrt <= 2 && H <= 768 && (H / 16) * 2 <= 256) {
+    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= 256) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         if (!base) return ICKA_E_ARG;
         ps.tickets = base; ps.err = base + 2;
         if (hipMemsetAsync(base, 0, 2 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
-        if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_persistent_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        // KS = resident W_hh fragments per wave (32 hidden units each): 24 up to H = 768, 32 up to H = 1024
+        if (H > 768) {
+            if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_persistent_kernel<1, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+            else hipLaunchKernelGGL((lstm_fwd_persistent_kernel<2, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        } else if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_persistent_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
         else hipLaunchKernelGGL((lstm_fwd_persistent_kernel<2, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
         ICKA_CHECK_LAUNCH();
         return 0;
@@ -534,13 +538,16 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
     a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
-    if (g_lstm_persistent && nrt <= 2 && H <= 768 && (H / 16) * 2 <= 256) {
+    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= 256) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         if (!base) return ICKA_E_ARG;
         ps.tickets = base; ps.err = base + 2;
         if (hipMemsetAsync(base, 0, 2 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
-        if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_persistent_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        if (H > 768) {
+            if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_persistent_kernel<1, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+            else hipLaunchKernelGGL((lstm_bwd_persistent_kernel<2, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
+        } else if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_persistent_kernel<1, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
         else hipLaunchKernelGGL((lstm_bwd_persistent_kernel<2, 24>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
         ICKA_CHECK_LAUNCH();
         return 0;

@@ -566,15 +566,19 @@ class PromptMappingFn(torch.autograd.Function):
             hd = torch.empty_like(h)
             K.dropout(h, hd, p_drop=p, seed=s2)
         y = torch.empty(M, N2, dtype=BF16, device=x.device)
-        K.gemm(K.GEMM_NT, hd[:, :N1], A.w(lin2.weight), y, bias=lin2.bias)
+        # W2 [N2, N1] has 7560-byte rows in the arena (not 16-byte aligned): a zero-padded bf16 copy [N2, N1p] keeps the
+        # operand loads of this GEMM and of d(hidden) = dy . W2 vectorised (one cast launch from the f32 master)
+        w2p = K.cast_pad_f32_to_bf16(lin2.weight.detach(), torch.empty(N2, N1p, dtype=BF16, device=x.device)) \
+            if N1p != N1 else A.w(lin2.weight)
+        K.gemm(K.GEMM_NT, hd, w2p, y, bias=lin2.bias)
         ctx.lin1, ctx.lin2, ctx.A, ctx.p, ctx.s1, ctx.s2 = lin1, lin2, A, p, s1, s2
         ctx.need_dx = x.requires_grad
-        ctx.save_for_backward(xd, h, hd)
+        ctx.save_for_backward(xd, h, hd, w2p)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xd, h, hd = ctx.saved_tensors
+        xd, h, hd, w2p = ctx.saved_tensors
         lin1, lin2, A, p = ctx.lin1, ctx.lin2, ctx.A, ctx.p
         dy = _c(dy)
         M, N2 = dy.shape
@@ -584,8 +588,8 @@ class PromptMappingFn(torch.autograd.Function):
         K.gemm(K.GEMM_TN, dy, hd[:, :N1], A.g(lin2.weight), beta=A.grad_beta(lin2.weight))
         K.colsum(dy, A.g(lin2.bias), A.workspace("colsum", lib.icka_colsum_workspace_floats(N2)),
                  accumulate=A.grad_beta(lin2.bias) > 0)
-        dh = torch.zeros(M, N1p, dtype=BF16, device=dy.device)
-        K.gemm(K.GEMM_NN, dy, A.w(lin2.weight), dh[:, :N1])
+        dh = torch.empty(M, N1p, dtype=BF16, device=dy.device)
+        K.gemm(K.GEMM_NN, dy, w2p, dh)            # pad columns: dy . 0 = 0
         if p > 0:
             K.dropout(dh, dh, p_drop=p, seed=ctx.s2)
         dpre = K.tanh_bwd(dh, h, torch.empty_like(h))

@@ -169,3 +169,53 @@ def test_prompt_mapping_network_against_torch():
     y2.float().sum().backward()
     dropped = (xg2.grad == 0).float().mean().item()
     assert 0.2 < dropped < 0.4, dropped
+
+
+def test_prompt_encoder_row_padding_matches_oracle():
+    """B=16, 18 ids + 10 prompts -> 26 positions, padded to 32 inside (B*S % 128 == 0) and cut back: output and the
+    prompt / table gradients equal the un-padded CPU oracle; ragged attention masks."""
+    from icka_amd import synth
+    from icka_amd.config import BertConfig
+    from icka_amd.cross_modal import PromptRobertaModel
+    from oracle import cross_modal_oracle as XO
+    from oracle import mner_oracle as O
+    torch.manual_seed(3)
+    B, S_in, P, H, V = 16, 18, 10, 128, 90
+    cfg = BertConfig(V, hidden_size=H, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=40, type_vocab_size=1, layer_norm_eps=1e-5)
+    m = PromptRobertaModel(cfg)
+    synth.fill_module_(m)
+    Pm = {"last_encoder." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ocfg = O.OracleConfig(vocab_size=V, hidden_size=H, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=40, type_vocab_size=1, layer_norm_eps=1e-5)
+    ids = torch.randint(2, V, (B, S_in))
+    lens = torch.randint(13, S_in + 1, (B,))
+    am = (torch.arange(S_in)[None] < lens[:, None]).long()
+    ids = ids * am + (1 - am)
+    prompt = torch.randn(B, P, H) * 0.5
+    pm = torch.ones(B, P, dtype=torch.long)
+    w = torch.randn(B, S_in - 2 + P, H) * am.new_ones(B, S_in - 2 + P, 1)
+    pr = prompt.bfloat16().float().requires_grad_(True)
+    ref = XO.prompt_roberta(Pm, "last_encoder", ocfg, ids, am, pr, pm)
+    (ref * w).sum().backward()
+    m = m.cuda().eval()
+    pg = prompt.bfloat16().cuda().requires_grad_(True)
+    out = m(input_ids=ids.cuda(), token_type_ids=None, attention_mask=am.cuda(), prompt_embeddings=pg,
+            input_mask=pm.cuda(), offset=5)[0]
+    assert tuple(out.shape) == (B, S_in - 2 + P, H)
+    valid = torch.tensor(XO.splice_index(S_in, P))
+    vmask = torch.where(valid >= 0, am[:, valid.clamp(min=0)], torch.ones(B, valid.shape[0], dtype=torch.long)).bool()
+    err = ((out.float().cpu() - ref.detach()).abs() * vmask[..., None]).max().item()
+    assert err < 6e-2, err
+    (out.float() * (w * vmask[..., None]).cuda()).sum().backward()
+    # oracle gradient with the same (valid-only) weighting
+    for v in Pm.values():
+        v.grad = None
+    pr.grad = None
+    (XO.prompt_roberta(Pm, "last_encoder", ocfg, ids, am, pr, pm) * w * vmask[..., None]).sum().backward()
+    rel = ((pg.grad.float().cpu() - pr.grad).norm() / pr.grad.norm()).item()
+    assert rel < 0.1, rel
+    for k in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+              "encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight"):
+        a, b_ = m.get_parameter(k).grad.float().cpu(), Pm["last_encoder." + k].grad
+        assert ((a - b_).norm() / (b_.norm() + 1e-6)).item() < 0.1, k

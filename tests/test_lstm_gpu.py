@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("persistent", [1, 0])
-@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64)])
+@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64), (32, 24, 1024), (7, 12, 1024)])
 def test_bilstm_forward_backward_against_aten(B, S, H, persistent, request):
     from icka_amd import _lib
     from icka_amd.lstm import BiLSTM
