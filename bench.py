@@ -80,9 +80,22 @@ def build_model(args, dev):
     cfg = BertConfig(30522, hidden_size=args.hidden, num_hidden_layers=args.layers,
                      num_attention_heads=args.hidden // 64, intermediate_size=4 * args.hidden)
     model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=args.cross_layers, num_labels=args.labels,
-                                                 regions=args.regions)
+                                                 regions=args.regions, cross_attention_fp8=args.fp8_cross)
     synth.fill_module_(model)
     return model.to(dev).train(), cfg
+
+
+def workload_name(args) -> str:
+    """BASELINE.json config names: c2/c3 bert-base S128 R36 B32 (the default), c4 bert-large S256 R50, c5 = c2 at B64 with
+    fp8 cross-attention; anything else is 'custom'."""
+    base = (args.hidden, args.layers, args.seq, args.regions)
+    if base == (768, 12, 128, 36) and args.batch == 32 and not args.fp8_cross:
+        return "c2"
+    if base == (768, 12, 128, 36) and args.batch == 64 and args.fp8_cross:
+        return "c5"
+    if base == (1024, 24, 256, 50):
+        return "c4"
+    return "custom"
 
 
 def cpu_baseline(args):
@@ -129,6 +142,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--cross-layers", type=int, default=1)
     ap.add_argument("--labels", type=int, default=13)
+    ap.add_argument("--fp8-cross", action="store_true", help="BASELINE config c5: fp8 QK^T / PV in the cross-attention")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -297,12 +311,13 @@ def main():
         flops, ms, launches, abytes = K.profile_gemm(False, reps=nprof)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(tpath):   # PMC passes cannot run inside this process: taken from the committed rocprofv3 runs
+        # PMC passes cannot run inside this process: taken from the committed rocprofv3 runs (measured on c2 only)
+        if os.path.exists(tpath) and workload_name(args) == "c2":
             tj = json.load(open(tpath))
             traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_ws_kernel|gemm_ws2_kernel|gemm_ws_group_kernel<NT|NN|TN> (128x128x64 bf16 MFMA, all GEMM launches of a step)",
+            roof = {"bound": "mfma", "kernel": "gemm_ws_kernel|gemm_ws2_kernel|gemm_big_group_kernel<NT|NN|TN> (128x128 / 128x96 / 256x128 tiles, bf16 MFMA, all GEMM launches of a step)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(abytes / launches),
@@ -324,10 +339,11 @@ def main():
             "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "c2: bert-base(H%d,L%d,h%d,I%d)+%dx2048 regions, seq_len %d, per-GPU batch %d, "
-                                   "%d cross layer(s), gated head, %d labels, train mode p=0.1, token-CE loss"
-                                   % (args.hidden, args.layers, args.hidden // 64, 4 * args.hidden, args.regions,
-                                      args.seq, args.batch, args.cross_layers, args.labels),
+            "config": {"workload": "%s: bert(H%d,L%d,h%d,I%d)+%dx2048 regions, seq_len %d, per-GPU batch %d, "
+                                   "%d cross layer(s)%s, gated head, %d labels, train mode p=0.1, token-CE loss"
+                                   % (workload_name(args), args.hidden, args.layers, args.hidden // 64, 4 * args.hidden,
+                                      args.regions, args.seq, args.batch, args.cross_layers,
+                                      " with fp8 QK^T/PV" if args.fp8_cross else "", args.labels),
                        "global_batch": args.batch * world, "seq_len": args.seq, "regions": args.regions,
                        "parallelism": "dp%d" % world, "flops_per_sample_fwd_bwd": fl_sample, "launch": mode},
             "loss": round(final_loss, 5),

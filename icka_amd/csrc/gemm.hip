@@ -1348,13 +1348,10 @@ __global__ __launch_bounds__(512) void slab_reduce_kernel(const SlabRed r) {
     slab_reduce_block(r, smem, blockIdx.x);
 }
 
-__device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
+__device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, const int m0, const int n0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
-    int m0, n0;
-    tile_origin(bid, nb, g.M / 256, g.N / BN, m0, n0);
-    m0 *= 2;   // tile_origin counts rows in units of BM = 128
     const int nk = g.K / BK;
 
     if (wave >= 4) {
@@ -1535,11 +1532,23 @@ __global__ __launch_bounds__(512) void gemm_big_group_kernel(const BigGroupArgs 
         big_colsum_block(g, smem, cb - ga.cs_start[pi]);
         return;
     }
+    // Block -> tile across the WHOLE group (blocks b and b+8 share an XCD and its private 4 MiB L2): XCD x takes the
+    // contiguous run [x*T/8, (x+1)*T/8) of the problems' concatenated tile lists, each list ordered along its shorter
+    // side.  A problem then lives on ~T_p/27 XCDs instead of all 8, each of which has to fetch the operand panels its
+    // tiles touch: rocprofv3 FETCH_SIZE was 340 MB per launch against ~100 MB of operands with per-problem striping.
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qn = tiles >> 3, rn = tiles & 7;
+    const int gt = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < MAX_GROUP; ++i) pi += bid >= ga.start[i] ? 1 : 0;
+    for (int i = 1; i < MAX_GROUP; ++i) pi += gt >= ga.start[i] ? 1 : 0;
     const GemmArgs g = ga.p[pi];
-    gemm_big_tn_body(g, smem, bid - ga.start[pi], ga.start[pi + 1] - ga.start[pi]);
+    const int local = gt - ga.start[pi];
+    const int nbm = g.M / 256, nbn = g.N / BN;
+    int tm, tn;
+    if (nbn > nbm) { tm = local % nbm; tn = local / nbm; }
+    else { tm = local / nbn; tn = local % nbn; }
+    gemm_big_tn_body(g, smem, tm * 256, tn * BN);
 }
 
 int g_big = 1;   // icka_gemm_set_big_tiles: 256x128 tiles for eligible grouped TN launches
