@@ -12,9 +12,11 @@ BF16, F32 = torch.bfloat16, torch.float32
 lib = _lib.load()
 bn = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 lib.icka_gemm_set_tile_n(bn)
+if len(sys.argv) > 2:   # LDS ring depth (14: ring 4 with paired staging)
+    assert lib.icka_gemm_set_ring(int(sys.argv[2])) == 0
 torch.manual_seed(0)
 for op, name in ((K.GEMM_TN, "TN"), (K.GEMM_NN, "NN"), (K.GEMM_NT, "NT")):
-    for Kd in (64, 128, 192, 768):
+    for Kd in (64, 128, 192, 256, 320, 384, 448, 768):
         for M, N in ((256, 384), (256, 768), (128, 384)):
             for cs_on in ((False, True) if op == K.GEMM_TN else (False,)):
                 if op == K.GEMM_TN:
