@@ -1161,7 +1161,10 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
         // blockIdx.y and accumulate f32 partial tiles atomically (C is scaled by beta / zeroed first)
         const int nk = (g.K + BK - 1) / BK;
         int ks = 1;
-        if (g.c_f32 && g.epi == ICKA_EPI_NONE && nb < 64 && nk >= 16) {
+        // (M <= 256 only: weight-gradient shapes.  Forward outputs such as the [tokens, labels] emissions stay on one
+        //  block per tile so that two identical calls give bitwise identical logits -- atomic split-K order flipped
+        //  Viterbi near-ties between a 'dev' and a 'test' pass of the same batch.)
+        if (g.c_f32 && g.epi == ICKA_EPI_NONE && nb < 64 && nk >= 16 && g.M <= 256) {
             ks = 256 / nb;
             if (ks > nk / 4) ks = nk / 4;
             if (ks < 1) ks = 1;
