@@ -18,18 +18,16 @@ stack (RoBERTa's layer is the BERT layer):
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Sequence
 
 import torch
 import torch.nn as nn
 
 from . import kernels as K
 from . import ops
-from .arena import arena_of
 from .config import check_config
 from .modeling import (BF16, F32, BertCrossEncoder, BertEncoder, BertLayerNorm, BertModel, BertPreTrainedModel,
-                       BertSelfEncoder, _CastFn, _IckaModule, _dims, _hidden2d, _mner_trunk, _twin, _with_twin,
-                       cls_layer_both)
+                       BertSelfEncoder, _CastFn, _IckaModule, _dims, _mner_trunk, _with_twin, cls_layer_both)
 
 
 class PromptRobertaEmbeddings(_IckaModule):
