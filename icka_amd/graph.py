@@ -36,7 +36,9 @@ class GraphedStep(object):
         self.arena = model._icka_arena
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
-        with torch.cuda.graph(self.graph):
+        # thread_local: only this thread's calls are checked against the capture -- with a process group alive, RCCL's
+        # watchdog / heartbeat threads make runtime calls of their own that must not invalidate it
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             K.bump_dropout_nonce(self.nonce)
             self.loss = step_fn()
 
