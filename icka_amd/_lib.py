@@ -50,6 +50,7 @@ PROTOTYPES = {
     "icka_gemm_grouped_ex": (c_i32, [C.POINTER(GemmDesc), c_i32, C.POINTER(SlabReduction), c_i32, c_vp]),
     "icka_gemm_set_ring": (c_i32, [c_i32]),
     "icka_gemm_set_tile_n": (c_i32, [c_i32]),
+    "icka_gemm_set_wide_tiles": (c_i32, [c_i32]),
     "icka_gemm_set_direct_epilogue": (c_i32, [c_i32]),
     "icka_gemm_set_big_tiles": (c_i32, [c_i32]),
     "icka_gemm_set_ablation": (c_i32, [c_i32]),

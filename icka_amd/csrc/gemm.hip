@@ -402,6 +402,8 @@ __device__ __forceinline__ void dma_issue(const bf16_t* (&ptr)[4], int64_t strid
 
 // f32 C tile in LDS: [128 rows][32 chunks of 4 floats], chunk index XORed with row&31
 __device__ __forceinline__ uint32_t off_c(int row, int ch) { return row * 512 + ((ch ^ (row & 31)) << 4); }
+// same for a 192-column f32 tile (48 chunks of 16 B per row; the XOR stays inside each group of 16 chunks)
+__device__ __forceinline__ uint32_t off_cw(int row, int ch) { return row * 768 + ((ch ^ (row & 15)) << 4); }
 
 // Output stores of the fast-path epilogues are NON-TEMPORAL: an FFN launch writes 25-50 MB, which as ordinary stores
 // pushed the operand panels out of the XCD's 4 MiB L2 (rocprofv3: L2 hit rate 0.57-0.79, 3-6x the algorithmic bytes
@@ -459,7 +461,7 @@ __device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, i
 
 // Second half of the LDS-staged epilogue: thread t finishes 8 consecutive columns (c8 = t & 15) of rows
 // (t >> 4) + RSTEP*i; 16 lanes cover a whole 128-column row -> 16-byte row-contiguous global accesses.
-template <int RSTEP, int NC8 = 16>
+template <int RSTEP, int NC8 = 16, bool WIDE = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
     // NC8 = 8-column groups per tile row: 16 (128-wide tile) or 12 (96-wide: 12 lanes per row, 384 of 512 threads)
     if (NC8 != 16 && tid >= RSTEP * NC8) return;
@@ -479,12 +481,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
     }
-#pragma unroll
+    // (the 12-wave kernel runs at a 168-register cap with accumulators of the other pass alive: keep its row loop rolled)
+#pragma unroll(WIDE ? 1 : 128 / RSTEP)
     for (int i = 0; i < 128 / RSTEP; ++i) {
         const int row = rb + RSTEP * i;
-        const int m = m0 + row;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8 + 1));
+        // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
+        const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + (WIDE ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + (WIDE ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
         float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
                       hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
         float a[8];
@@ -1086,6 +1090,7 @@ int g_abl = 0;
 unsigned long long* g_stamp = nullptr;
 int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
 int g_direct = 1;  // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
+int g_w3 = 1;    // 256x192 tiles for wide / short-K outputs (icka_gemm_set_wide_tiles)
 int g_bn = 0;    // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced (icka_gemm_set_tile_n)
 int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
 
@@ -1095,6 +1100,120 @@ __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) 
     const int64_t r = i / N;
     float* p = C + r * ldc + (i - r * N);
     *p = beta == 0.f ? 0.f : *p * beta;
+}
+
+
+// =====================================================================================================================
+// 256 x 192 output tiles, 12 waves (8 compute waves of 64 x 96 + 4 loader waves), for the wide-output / short-K GEMMs of
+// the step (qkv: 4096 x 2304, ffn-up and d(ffn-down): 4096 x 3072, K = 768): 192 / 256 tiles = ONE round of the 256 CUs
+// instead of 2.25 / 3 rounds of 128 x 128 tiles, and 0.75x the operand bytes per FLOP through L2 -> LDS (the in-step
+// limiter).  Two compute waves per SIMD cover each other's LDS latency (fragments are read per
+// 32-deep step right before their MFMAs, as in the two-blocks-per-CU kernel); LDS ring of 2 stages of
+// [A rows 0..127 | A rows 128..255 | B 0..95 | B 96..191] (4 x 16 KiB images in the usual swizzled layouts); outputs go
+// straight from the accumulators through the general 4-column epilogue.  A is k-contiguous (NT and NN).
+constexpr int W3_A = 2 * TILE_BYTES, W3_B = 2 * TILE_BYTES;   // one k-tile of A (2 x 128 rows) / of B (2 x 96 columns)
+constexpr int W3_NA = 3, W3_NB = 2;                           // ring depths: 3 x 32 KiB + 2 x 32 KiB = 160 KiB = the whole LDS
+template <bool B_KM>
+__global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    const int nbn = g.N / 192, nb = gridDim.x;
+    // blocks b and b+8 share an XCD: each XCD takes a contiguous row-major run of tiles (nb % 8 == 0, host-checked)
+    const int sw = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+    const int m0 = (sw / nbn) * 256, n0 = (sw % nbn) * 192;
+    const int nk = g.K / BK;
+    if (wave >= 8) {
+        // ------------------------------------------------------------------------------------------- loader waves
+        // The activation operand A (cold, the expensive one: tools/gemm_cold.py) runs TWO k-tiles ahead in a ring of 3,
+        // the weight operand B one k-tile ahead in a ring of 2.  Issue order per iteration: B(kt+1), then A(kt+2); LDS-DMA
+        // returns in order, so "A(kt), B(kt) landed" = at most the 8 instructions of A(kt+1) still in flight.
+        const int lw = wave - 8;
+        const bf16_t* pa0[4];
+        const bf16_t* pa1[4];
+        const bf16_t* pb0[4];
+        const bf16_t* pb1[4];
+        dma_init<false>(pa0, g.A, g.lda, m0, lw, lane);
+        dma_init<false>(pa1, g.A, g.lda, m0 + 128, lw, lane);
+        dma_init<B_KM, 96>(pb0, g.B, g.ldb, n0, lw, lane);
+        dma_init<B_KM, 96>(pb1, g.B, g.ldb, n0 + 96, lw, lane);
+        const int64_t sa = BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+        constexpr int NJB = B_KM ? 4 : 3;
+        const uint32_t ldsB = lds0 + W3_NA * W3_A;
+#define ICKA_W3_A(SLOT)                                                          \
+    do {                                                                         \
+        dma_issue(pa0, sa, lds0 + (SLOT) * W3_A + lw * 1024);                    \
+        dma_issue(pa1, sa, lds0 + (SLOT) * W3_A + TILE_BYTES + lw * 1024);       \
+    } while (0)
+#define ICKA_W3_B(SLOT)                                                          \
+    do {                                                                         \
+        dma_issue<NJB>(pb0, sb, ldsB + (SLOT) * W3_B + lw * 1024);               \
+        dma_issue<NJB>(pb1, sb, ldsB + (SLOT) * W3_B + TILE_BYTES + lw * 1024);  \
+    } while (0)
+        ICKA_W3_A(0);
+        ICKA_W3_B(0);
+        if (nk > 1) ICKA_W3_A(1);
+        int sa3 = 2;   // A slot of tile kt+2
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();   // A(kt+1) may still be in flight
+            __builtin_amdgcn_s_barrier();        // tile kt published; every compute wave is done with tile kt-1
+            if (kt + 1 < nk) ICKA_W3_B((kt + 1) & 1);
+            if (kt + 2 < nk) ICKA_W3_A(sa3);
+            sa3 = sa3 == 2 ? 0 : sa3 + 1;
+        }
+#undef ICKA_W3_A
+#undef ICKA_W3_B
+    }
+    // ---------------------------------------------------------------------------------------------- compute waves
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 96;
+    f32x4 acc[4][6];
+    if (wave < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* sA = smem + (kt % W3_NA) * W3_A + (wr >> 7) * TILE_BYTES;
+            const char* sB = smem + W3_NA * W3_A + (kt & 1) * W3_B + (wave & 1) * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[6];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t] = read_frag<false>(sA, (wr & 127) + 16 * t, ks, lane);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) fb[t] = read_frag<B_KM>(sB, 16 * t, ks, lane);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+            }
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
+    }
+    // ---- epilogue through LDS in two passes of 128 x 192 (96 KiB f32): in pass p EVERY compute wave deposits the 32-row
+    //      half p of its 64 x 96 accumulator tile (so only 48 accumulator registers stay alive under the row loop: with
+    //      whole wave tiles per pass the other pass's 96 spilled to scratch at the 168-register cap of 3 waves / SIMD),
+    //      then all 12 waves finish 8-column groups of rows with 16-byte row-contiguous accesses
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();   // operand ring dead (pass 0) / previous C tile consumed (pass 1)
+        if (wave < 8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = (wave >> 1) * 32 + 16 * h + (lane & 15);
+#pragma unroll
+                for (int ni = 0; ni < 6; ++ni)
+                    *reinterpret_cast<f32x4*>(smem + off_cw(row, (wc >> 2) + 4 * ni + (lane >> 4))) =
+                        acc[2 * pass + h][ni] * g.alpha;
+            }
+        }
+        __syncthreads();
+        epilogue_rows<32, 24, true>(g, smem, m0 + 32 * pass, n0, tid);
+    }
 }
 
 template <bool A_KM, bool B_KM>
@@ -1122,6 +1241,16 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
 #endif
+                // 256x192 tiles (12-wave kernel) where they cover the CUs in ONE round: wide outputs with a short reduction
+                if constexpr (!A_KM) {
+                    const int nb3 = (g.M / 256) * (g.N / 192);
+                    if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
+                        nb3 >= 128 && nb3 <= 256 && g.ksplit == 1) {
+                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM>), dim3(nb3), dim3(768), 0, st, g);
+                        ICKA_CHECK_LAUNCH();
+                        return 0;
+                    }
+                }
                 // Tile width: 128x96 tiles when they quantise better onto the 256 CUs (N = 768: 256 tiles instead of 192).
                 if (g.n96ok && g_bn != 128) {
                     // measured (profiles/README.md): a 128x96 tile costs ~0.9-1.0 of a 128x128 one (the k-loop is bound
@@ -1204,6 +1333,11 @@ extern "C" int icka_gemm_set_ablation(int mode) {
 
 extern "C" int icka_gemm_set_direct_epilogue(int on) {
     g_direct = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int icka_gemm_set_wide_tiles(int on) {
+    g_w3 = on ? 1 : 0;
     return 0;
 }
 

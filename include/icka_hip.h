@@ -88,6 +88,9 @@ int icka_gemm_set_ring(int nbuf);
  * tiles (the narrower tile when it quantises better onto the 256 CUs: N = 768 gives 256 tiles instead of 192),
  * 128 / 96 = forced where applicable (96 needs N % 96 == 0 on top of the fast-path alignment). */
 int icka_gemm_set_tile_n(int bn);
+/* 256x192 output tiles (12-wave kernel) for wide outputs with a short reduction whose tile grid covers the 256 CUs in one
+ * round (M % 256 == 0, N % 192 == 0, K <= 1024, 128..256 tiles): on by default; 0 switches back to 128x128 tiles. */
+int icka_gemm_set_wide_tiles(int on);
 /* 1 (default): f32 outputs without activation / fan-in operand / accumulate are stored straight from the MFMA
  * accumulators; 0: every epilogue goes through the LDS C tile (16-byte row-contiguous stores). */
 int icka_gemm_set_direct_epilogue(int on);

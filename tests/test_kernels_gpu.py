@@ -127,6 +127,43 @@ def test_gemm_epilogues_and_dual_k():
     assert rel_err(o, 0.5 * (A.float() @ B.float().t()) + 1.0) < 1e-2
 
 
+@pytest.mark.parametrize("wide", [1, 0])
+@pytest.mark.parametrize("op", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(4096, 2304, 768), (4096, 3072, 768), (2048, 3072, 64), (4096, 1536, 1024), (4096, 3072, 192)])
+def test_gemm_wide_tiles(M, N, K, op, wide, request):
+    """256x192-tile kernel (qkv / ffn-up / d-ffn-down shapes: 128..256 tiles of one round) against fp32 matmul, with
+    every epilogue those GEMMs use: bias, GELU (two outputs), GELU' (aux), fan-in add, f32 and bf16 outputs, odd and even
+    k-tile counts; wide=0 runs the same calls on the 128x128 path."""
+    k = _k()
+    lib = k._lib.load()
+    assert lib.icka_gemm_set_wide_tiles(wide) == 0
+    request.addfinalizer(lambda: lib.icka_gemm_set_wide_tiles(1))
+    A = rnd(M, K, seed=1, scale=0.5)
+    B = rnd(N, K, seed=2, scale=0.5) if op == "NT" else rnd(K, N, seed=2, scale=0.5)
+    kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
+    bias = rnd(N, seed=3, dtype=F32)
+    ref = A.float() @ (B.float().t() if op == "NT" else B.float())
+    o = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(kop, A, B, o)
+    assert rel_err(o, ref) < 1e-2
+    of = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(kop, A, B, of, bias=bias)
+    assert rel_err(of, ref + bias) < 1e-4
+    z = torch.empty_like(o)
+    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    assert rel_err(z, ref + bias) < 1e-2 and rel_err(o, torch.nn.functional.gelu(ref + bias)) < 1e-2
+    aux = rnd(M, N, seed=4)
+    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(o, ref * x.grad) < 1e-2
+    k.gemm(kop, A, B, o, epilogue=k.EPI_ADD, aux=aux)
+    assert rel_err(o, ref + aux.float()) < 1e-2
+    ov = torch.empty(M, N + 64, dtype=BF16, device="cuda")[:, :N]      # strided output view
+    k.gemm(kop, A, B, ov, alpha=0.5)
+    assert rel_err(ov, 0.5 * ref) < 1e-2
+
+
 @pytest.mark.parametrize("tile_n", [96, 128])
 @pytest.mark.parametrize("M,N,K", [(128, 384, 64), (4096, 768, 768), (512, 2304, 768), (256, 768, 3072)])
 def test_gemm_tile_widths(M, N, K, tile_n, request):
