@@ -482,7 +482,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
         for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
     }
     // (the 12-wave kernel runs at a 168-register cap with accumulators of the other pass alive: keep its row loop rolled)
-#pragma unroll(WIDE ? 1 : 128 / RSTEP)
+    constexpr int UNR = WIDE ? 1 : 128 / RSTEP;
+#pragma unroll UNR
     for (int i = 0; i < 128 / RSTEP; ++i) {
         const int row = rb + RSTEP * i;
         // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
@@ -1244,8 +1245,10 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 // 256x192 tiles (12-wave kernel) where they cover the CUs in ONE round: wide outputs with a short reduction
                 if constexpr (!A_KM) {
                     const int nb3 = (g.M / 256) * (g.N / 192);
+                    // ... or in whole rounds: at least 3/4 of the last round of 256 must be filled
+                    const int rounds3 = (nb3 + 255) / 256;
                     if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
-                        nb3 >= 128 && nb3 <= 256 && g.ksplit == 1) {
+                        nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
                         hipLaunchKernelGGL((gemm_w3_kernel<B_KM>), dim3(nb3), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
