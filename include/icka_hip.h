@@ -94,8 +94,10 @@ int icka_gemm_set_wide_tiles(int on);
 /* 1 (default): f32 outputs without activation / fan-in operand / accumulate are stored straight from the MFMA
  * accumulators; 0: every epilogue goes through the LDS C tile (16-byte row-contiguous stores). */
 int icka_gemm_set_direct_epilogue(int on);
-/* 1 (default): grouped TN launches whose problems are plain f32 outputs with M % 256 == 0 (the weight gradients of a
- * layer, overwrite or beta-accumulate) use 256x128 output tiles and compute their fused column sums in extra blocks of the same grid; 0: 128x128. */
+/* Grouped TN launches whose problems are plain f32 outputs with M % 256 == 0 (the weight gradients of a layer,
+ * overwrite or beta-accumulate) use 256x128 output tiles and compute their fused column sums in extra blocks of the
+ * same grid.  2 (default): 12-wave blocks (8 compute waves of 64x64 + 4 loader waves); 1: 8-wave blocks (4 compute
+ * waves of 128x64); 0: 128x128 tiles. */
 int icka_gemm_set_big_tiles(int on);
 /* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
 int icka_gemm_set_ablation(int mode);

@@ -231,7 +231,7 @@ def test_gemm_grouped_matches_individual_launches():
     assert rel_err(single, keep[1][0].float().sum(0)) < 1e-4 and rel_err(o2, keep[1][0].float().t() @ keep[1][1].float()) < 1e-4
 
 
-@pytest.mark.parametrize("big", [1, 0])
+@pytest.mark.parametrize("big", [1, 2, 0])
 def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
     """The four weight-gradient GEMMs of a BERT layer as one grouped launch, overwrite mode (beta = 0) with fused bias
     gradients: 256x128-tile kernel with column-sum blocks in the same grid (big=1) vs the 128x128 group kernel."""
@@ -239,7 +239,7 @@ def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
     from icka_amd import _lib
     lib = _lib.load()
     assert lib.icka_gemm_set_big_tiles(big) == 0
-    request.addfinalizer(lambda: lib.icka_gemm_set_big_tiles(1))
+    request.addfinalizer(lambda: lib.icka_gemm_set_big_tiles(2))
     T, H, I = 1024, 768, 3072
     shapes = [(3 * H, H), (H, H), (I, H), (H, I)]
     descs, outs, refs, css, keep = [], [], [], [], []
