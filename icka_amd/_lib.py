@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
-GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+GEMM_NT, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -39,6 +39,19 @@ class SlabReduction(C.Structure):
     """Mirror of ``icka_slab_reduction`` (include/icka_hip.h)."""
     _fields_ = [("partials", c_vp), ("slab_stride", c_i64), ("nslab", c_i32), ("H", c_i32), ("nslots", c_i32),
                 ("accumulate", c_i32), ("out", c_vp * 4)]
+
+
+class XGemmDesc(C.Structure):
+    """Mirror of ``icka_xgemm_desc`` (include/icka_hip.h): batched f32 GEMM of the fp32-exact mode."""
+    _fields_ = [
+        ("op", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("A", c_vp), ("lda", c_i64), ("a_bs0", c_i64), ("a_bs1", c_i64),
+        ("B", c_vp), ("ldb", c_i64), ("b_bs0", c_i64), ("b_bs1", c_i64),
+        ("C", c_vp), ("ldc", c_i64), ("c_bs0", c_i64), ("c_bs1", c_i64),
+        ("nb0", c_i32), ("nb1", c_i32),
+        ("bias", c_vp),
+        ("alpha", c_f32), ("beta", c_f32),
+    ]
 
 
 # name -> (restype, argtypes); must list every function declared in include/icka_hip.h
@@ -124,6 +137,28 @@ PROTOTYPES = {
     "icka_set_dropout_nonce": (c_i32, [c_vp]),
     "icka_bump_dropout_nonce": (c_i32, [c_vp, c_vp]),
     "icka_dropout_mask": (c_i32, [c_vp, c_i64, c_f32, c_u64, c_vp]),
+    # ---- fp32 "exact" mode (csrc/exact.hip)
+    "icka_x_gemm": (c_i32, [C.POINTER(XGemmDesc), c_vp]),
+    "icka_x_ln_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64,
+                              c_vp]),
+    "icka_x_ln_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_u64, c_vp]),
+    "icka_x_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32,
+                                 c_vp]),
+    "icka_x_embed_scatter": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_softmax_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_x_softmax_bwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_x_act_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "icka_x_act_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "icka_x_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_vp]),
+    "icka_x_add": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "icka_x_concat2": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp]),
+    "icka_x_regions_to_tokens": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_sample_gate_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_sample_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                       c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "icka_x_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 
 _lib: Optional[C.CDLL] = None

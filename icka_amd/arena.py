@@ -2,8 +2,10 @@
 
 MI355X-first memory layout (288 GB HBM3E per GPU): instead of ~200 small parameter tensors we keep
   * ``flat``    fp32 master copy  -- the nn.Parameters are *views* into it (state_dict keys/shapes unchanged),
-  * ``shadow``  bf16 copy of the same layout -- what the MFMA GEMMs read; refreshed by ONE cast launch when any
-                parameter's version counter moved (optimizer step, load_state_dict),
+  * ``shadow``  bf16 copy of the same layout -- what the MFMA GEMMs read; refreshed by ONE cast launch at the start
+                of every outermost forward (``shadow_policy = "always"``, the default: optimizers that update through
+                ``p.data`` -- the reference's BertAdam, my_bert/optimization.py:153 -- leave no trace in the version
+                counters), or only when a change was seen (``"tracked"``, see ``sync``),
   * ``gflat``   fp32 gradients      -- ``p.grad`` are views into it; backward kernels write straight into it
                 (GEMM beta = 0/1), so data-parallel all-reduce runs over a few large contiguous slices.
 Parameters are laid out in registration (= execution) order, each slot aligned to 8 elements (16 B in bf16), so the
@@ -64,7 +66,10 @@ class ParamArena(object):
                 view.copy_(s.param.data)
                 s.param.data = view
         self._synced = None
-        self._touched: List[Slot] = []
+        # "always": re-cast the bf16 shadow at every outermost forward (safe with ANY way of updating parameters);
+        # "tracked": re-cast only when a parameter version counter moved, an optimizer step ran (global post-step
+        # hook) or mark_dirty() was called -- the caller promises not to write parameters through ``.data``
+        self.shadow_policy = "always"
         self._ws: Dict[Tuple[str, int], torch.Tensor] = {}
         # autograd anchor: a leaf that requires grad, passed to every Function so that backward runs even when
         # no *tensor input* requires grad (parameters are read from the arena, not passed through autograd)
@@ -138,14 +143,15 @@ class ParamArena(object):
         return sl[0], rows
 
     # ------------------------------------------------------------------------------------------ bf16 shadow
-    def sync(self) -> None:
-        """Refresh the bf16 shadow if any parameter changed since the last refresh (one cast launch)."""
+    def sync(self, force: bool = False) -> None:
+        """Refresh the bf16 shadow (one cast launch).  Policy "always": every call casts.  Policy "tracked": only
+        when a version counter moved / an optimizer stepped / mark_dirty() was called since the last refresh."""
         if self.shadow is None:
             raise RuntimeError("ParamArena.sync: bf16 shadows need a ROCm device (no CPU path)")
-        v = 0
+        v = _OPT_STEPS[0]
         for s in self.order:
             v += s.param._version
-        if v != self._synced:
+        if force or self.shadow_policy == "always" or v != self._synced:
             from . import kernels
             kernels.cast_f32_to_bf16(self.flat, self.shadow)
             self._synced = v
@@ -155,32 +161,33 @@ class ParamArena(object):
 
     # ------------------------------------------------------------------------------------------ gradients
     def begin_step(self) -> None:
-        """Called at the start of a forward pass: if the user dropped the gradients (optimizer.zero_grad(), whose
-        default sets p.grad = None) the next backward overwrites instead of accumulating."""
-        if self._touched and self._touched[0].param.grad is None:
-            for s in self._touched:
-                s.live = False
-            self._touched = []
+        """Kept for callers of the round-1 API; the overwrite-vs-accumulate decision is taken per slot at backward
+        time (grad_beta), so nothing has to happen at the start of a forward."""
+
+    def _is_live(self, s: Slot) -> bool:
+        """A slot accumulates only if it was written in this accumulation cycle AND the user still holds that
+        gradient: ``zero_grad()`` (p.grad = None) or a foreign ``p.grad`` tensor at ANY point before this backward
+        -- including between forward and backward -- starts a fresh cycle."""
+        g = s.param.grad
+        return s.live and g is not None and g.data_ptr() == self.gflat.data_ptr() + 4 * s.off
 
     def grad_beta(self, ps) -> float:
         """beta for a gradient write into the slot(s): 0.0 on the first write of an accumulation cycle, else 1.0.
-        Also (re)attaches p.grad to the arena view."""
+        Also (re)attaches p.grad to the arena view.  In a fused group with mixed state (one of q/k/v frozen or
+        cleared by hand) the fresh slots are zeroed and the group accumulates."""
         if isinstance(ps, nn.Parameter):
             ps = (ps,)
-        live = None
-        for p in ps:
-            s = self.slots[id(p)]
-            if live is None:
-                live = s.live
-            elif live != s.live:
-                raise RuntimeError("fused parameter group %s has mixed gradient state" % s.name)
-            if not s.live:
+        sl = [self.slots[id(p)] for p in ps]
+        live = [self._is_live(s) for s in sl]
+        mixed = any(live) and not all(live)
+        for s, lv in zip(sl, live):
+            if not lv:
+                if mixed:
+                    self.gflat[s.off:s.off + s.numel].zero_()
                 s.live = True
-                self._touched.append(s)
+                s.param.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
             self._pending_final.append(s)
-            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * s.off:
-                p.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
-        return 1.0 if live else 0.0
+        return 1.0 if live[0] or mixed else 0.0
 
     def flush_final(self) -> None:
         """End of a block's backward: every gradient slot written since the last flush is final for this step."""
@@ -192,7 +199,14 @@ class ParamArena(object):
         self.gflat.zero_()
         for s in self.order:
             s.live = False
-        self._touched = []
+
+    def attach_grads(self, slots=None) -> None:
+        """(Re)attach ``p.grad`` views for slots whose gradient was produced without Python running (hipGraph replay)."""
+        for s in (self.order if slots is None else slots):
+            g = s.param.grad
+            if g is None or g.data_ptr() != self.gflat.data_ptr() + 4 * s.off:
+                s.param.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
+            s.live = True
 
     # ------------------------------------------------------------------------------------------ workspace
     def workspace(self, tag: str, numel: int, dtype=torch.float32) -> torch.Tensor:
@@ -220,6 +234,25 @@ class ParamArena(object):
         return out
 
 
+# number of optimizer steps seen by the global post-step hook: part of the "tracked" shadow fingerprint
+_OPT_STEPS = [0]
+
+
+def _install_optimizer_hook() -> None:
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:   # pragma: no cover
+        return
+
+    def _bump(optimizer, args, kwargs):
+        _OPT_STEPS[0] += 1
+
+    register_optimizer_step_post_hook(_bump)
+
+
+_install_optimizer_hook()
+
+
 def _collect(module: nn.Module, prefix: str):
     """Parameters in arena order: registration order, except that a module may impose the order of its whole
     sub-tree through ``icka_param_order()`` (attention blocks put query/key/value weights, then their biases,
@@ -235,6 +268,30 @@ def _collect(module: nn.Module, prefix: str):
     for cname, child in module._modules.items():
         if child is not None:
             yield from _collect(child, prefix + cname + ".")
+
+
+_FWD_DEPTH = [0]   # nesting depth of ArenaModule forwards (one Python thread per process)
+
+
+class ArenaModule(nn.Module):
+    """Base of every icka module that owns parameters read by kernels.  ``_arena()`` returns the (shared) ParamArena
+    and, in the OUTERMOST icka forward of a call tree only, refreshes the bf16 shadow (ParamArena.sync)."""
+
+    def __call__(self, *args, **kwargs):
+        _FWD_DEPTH[0] += 1
+        try:
+            return super().__call__(*args, **kwargs)
+        finally:
+            _FWD_DEPTH[0] -= 1
+
+    def _arena(self) -> ParamArena:
+        A = arena_of(self)
+        if A.device.type != "cuda":
+            raise RuntimeError("%s: parameters are on %s; move the module to a ROCm device (icka_amd has no CPU "
+                               "path)" % (type(self).__name__, A.device))
+        if _FWD_DEPTH[0] <= 1 or A._synced is None:
+            A.sync()
+        return A
 
 
 def arena_of(module: nn.Module) -> ParamArena:

@@ -68,11 +68,17 @@ def check_config(config) -> None:
     if config.hidden_size % config.num_attention_heads != 0:
         raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
                          % (config.hidden_size, config.num_attention_heads))
-    if config.hidden_size // config.num_attention_heads != 64:
-        raise ValueError("icka_amd attention kernels are built for head size 64 (bert-base 768/12, bert-large "
-                         "1024/16); got %d" % (config.hidden_size // config.num_attention_heads))
     act = getattr(config, "hidden_act", "gelu")
     if act != "gelu":
         raise ValueError("only the erf 'gelu' activation of the reference's BERT is implemented, got %r" % (act,))
     if config.hidden_size % 8 or config.intermediate_size % 8:
         raise ValueError("hidden_size and intermediate_size must be multiples of 8")
+
+
+def check_head_size_bf16(config) -> None:
+    """The bf16 MFMA attention kernels are built for head size 64 (bert-base 768/12, bert-large 1024/16): checked when
+    a bf16-mode forward runs.  The fp32-exact mode (icka_amd.set_precision(model, "fp32")) takes any head size."""
+    if config.hidden_size // config.num_attention_heads != 64:
+        raise ValueError("icka_amd bf16 attention kernels are built for head size 64 (bert-base 768/12, bert-large "
+                         "1024/16); got %d -- use set_precision(model, 'fp32') for other geometries"
+                         % (config.hidden_size // config.num_attention_heads))

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .arena import ParamArena, arena_of
+from .arena import ArenaModule, ParamArena, arena_of
 
 F32 = torch.float32
 
@@ -46,7 +46,7 @@ class _CrfFn(torch.autograd.Function):
         return None, de, None, None, None, None
 
 
-class CRF(nn.Module):
+class CRF(ArenaModule):
     def __init__(self, num_tags: int, batch_first: bool = False) -> None:
         if num_tags <= 0:
             raise ValueError("invalid number of tags: %d" % num_tags)
@@ -92,14 +92,6 @@ class CRF(nn.Module):
         e = emissions.to(F32).contiguous()
         t = tags.to(torch.int64).contiguous() if tags is not None else None
         return e, t, mask
-
-    def _arena(self) -> ParamArena:
-        A = arena_of(self)
-        if A.device.type != "cuda":
-            raise RuntimeError("CRF parameters are on %s; move the module to a ROCm device" % A.device)
-        A.begin_step()
-        A.sync()
-        return A
 
     def forward(self, emissions: torch.Tensor, tags: torch.Tensor, mask: Optional[torch.Tensor] = None,
                 reduction: str = "sum") -> torch.Tensor:

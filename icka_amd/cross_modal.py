@@ -275,12 +275,6 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
             return self.crf.decode(emissions, mask=output_mask)
         return emissions
 
-    def zero_grad(self, set_to_none: bool = True):
-        super().zero_grad(set_to_none=set_to_none)
-        A = getattr(self, "_icka_arena", None)
-        if A is not None:
-            A.begin_step()
-
 
 def _scalar_gate(owner, A, cross2d: torch.Tensor, tok2d: torch.Tensor, B: int, S: int) -> torch.Tensor:
     """:1029-1036 on 2-D [B*S,H] bf16 operands (modeling.scalar_gate_fusion without the arena bookkeeping)."""

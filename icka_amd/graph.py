@@ -4,9 +4,18 @@ A forward+backward step of the hot path is ~850 short kernel launches; issued ea
 host time each and the GPU starves once the kernels are fast.  The step is static (fixed shapes, no host sync, all
 scratch from the caching allocator, parameters/gradients in the ParamArena), so it is captured once and replayed.
 Dropout stays random across replays through the device-side nonce (icka_bump_dropout_nonce is the first node of the
-graph).  Gradients are written with beta = 0 (the capture happens right after zero_grad), so every replay leaves
-this step's gradients in ``p.grad``; the optimizer runs outside the graph and ``ParamArena.sync`` refreshes the bf16
-shadows before the next replay.
+graph).
+
+Contract
+  * Gradients are captured with beta = 0 (the capture happens right after zero_grad): every replay OVERWRITES the
+    gradient arena with this step's gradients -- a GraphedStep does not accumulate across calls.  After each replay
+    ``p.grad`` is re-attached to the arena views for every parameter that received a gradient at capture, so the
+    reference's loop (``model.zero_grad()`` / ``optimizer.zero_grad()`` after every step, My_cross_attention.py:843,
+    set_to_none or not) keeps working with ``optimizer.step()`` seeing this step's gradients.
+  * The optimizer runs outside the graph.  With the default shadow policy ("always") the bf16 re-cast of the
+    parameters is the first kernel inside the captured forward; with "tracked" it runs before the replay when a change
+    was seen.
+  * ``close()`` (also run by ``__del__``) unregisters the dropout nonce, whose device memory this object owns.
 """
 from __future__ import annotations
 
@@ -41,8 +50,26 @@ class GraphedStep(object):
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             K.bump_dropout_nonce(self.nonce)
             self.loss = step_fn()
+        self._grad_slots = [s for s in self.arena.order if s.live]
 
     def __call__(self) -> torch.Tensor:
-        self.arena.sync()                       # parameters may have changed since the last replay (optimizer step)
+        if self.graph is None:
+            raise RuntimeError("GraphedStep is closed")
+        if self.arena.shadow_policy != "always":   # "always": the cast is a node of the captured forward
+            self.arena.sync()
         self.graph.replay()
+        self.arena.attach_grads(self._grad_slots)   # replay runs no Python: p.grad may have been dropped by zero_grad
         return self.loss
+
+    def close(self) -> None:
+        """Release the graph and unregister the dropout nonce (the kernels keep a raw pointer to it)."""
+        if getattr(self, "nonce", None) is not None:
+            try:
+                K.clear_dropout_nonce_if(self.nonce)
+            except Exception:      # interpreter shutdown: the library may already be gone
+                pass
+            self.nonce = None
+        self.graph = None
+
+    def __del__(self):
+        self.close()

@@ -588,7 +588,18 @@ def set_dropout_nonce(words: Optional[torch.Tensor]) -> None:
     """Register (or clear) the 2 x int32 device tensor whose value every dropout kernel folds into its seed."""
     if words is not None and (not words.is_cuda or words.numel() < 2 or words.element_size() != 4):
         raise TypeError("nonce must be a device tensor of two 32-bit words")
+    global _NONCE_PTR
     check(_lib.load().icka_set_dropout_nonce(_ptr(words)), "icka_set_dropout_nonce")
+    _NONCE_PTR = _ptr(words)
+
+
+_NONCE_PTR = None
+
+
+def clear_dropout_nonce_if(words: torch.Tensor) -> None:
+    """Unregister ``words`` if (and only if) it is the currently registered nonce (its owner is going away)."""
+    if _NONCE_PTR is not None and words is not None and _NONCE_PTR == words.data_ptr():
+        set_dropout_nonce(None)
 
 
 def bump_dropout_nonce(words: torch.Tensor) -> None:

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .arena import ParamArena, arena_of
+from .arena import ArenaModule, ParamArena, arena_of
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -74,7 +74,7 @@ class _LstmFn(torch.autograd.Function):
         return None, dx, None, None, None, None
 
 
-class BiLSTM(nn.Module):
+class BiLSTM(ArenaModule):
     """nn.LSTM(input_size, hidden_size, num_layers=1, batch_first=True, bidirectional=True) on MI355X."""
 
     def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, bias: bool = True,
@@ -103,14 +103,6 @@ class BiLSTM(nn.Module):
         # both directions of each tensor back to back: [8H, in] / [8H, H] fused operands for the GEMMs and the kernel
         names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
         return [(n + s, getattr(self, n + s)) for n in names for s in ("", "_reverse")]
-
-    def _arena(self) -> ParamArena:
-        A = arena_of(self)
-        if A.device.type != "cuda":
-            raise RuntimeError("BiLSTM parameters are on %s; move the module to a ROCm device" % A.device)
-        A.begin_step()
-        A.sync()
-        return A
 
     def forward(self, x: torch.Tensor, hx=None):
         if hx is not None:

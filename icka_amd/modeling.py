@@ -18,10 +18,11 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from . import exact as X
 from . import kernels as K
 from . import ops
-from .arena import ParamArena, arena_of
-from .config import BertConfig, check_config
+from .arena import ArenaModule, ParamArena, arena_of
+from .config import BertConfig, check_config, check_head_size_bf16
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -44,10 +45,18 @@ class _CastFn(torch.autograd.Function):
         return K.cast_f32_to_bf16(dy, torch.empty_like(dy, dtype=BF16)), None
 
 
-def _hidden2d(x: torch.Tensor, name: str = "hidden_states") -> torch.Tensor:
-    """[B,S,H] (bf16 or f32, ROCm) -> contiguous bf16 [B*S, H]."""
+def _hidden2d(x: torch.Tensor, name: str = "hidden_states", exact: bool = False) -> torch.Tensor:
+    """[B,S,H] (bf16 or f32, ROCm) -> contiguous bf16 [B*S, H]  (f32 [B*S, H] in the fp32-exact mode)."""
     if not x.is_cuda:
         raise TypeError("%s must be on a ROCm device: icka_amd has no CPU path" % name)
+    if exact:
+        if x.dtype == BF16:
+            x = _CastFn.apply(x, False)
+        elif x.dtype != F32:
+            raise TypeError("%s must be bf16 or f32, got %s" % (name, x.dtype))
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return x.view(-1, x.shape[-1])
     if x.dtype == F32:
         x = _CastFn.apply(x, True)
     elif x.dtype != BF16:
@@ -83,23 +92,35 @@ def _add_mask2d(mask: torch.Tensor, B: int, T: int) -> torch.Tensor:
     return mask.reshape(B, T).contiguous()
 
 
-def _dims(config, B, S, R, train: bool) -> ops.Dims:
+PRECISIONS = ("bf16", "fp32")
+
+
+def set_precision(module: nn.Module, precision: str) -> nn.Module:
+    """Select the arithmetic of every icka block under ``module``:
+    "bf16" (default): bf16 MFMA operands, f32 accumulation / statistics / residual stream -- the product path;
+    "fp32": f32 storage and f32-input MFMA arithmetic (icka_amd/exact.py) for the 1e-3 parity bar of BASELINE.json."""
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
+    for m in module.modules():
+        m.icka_precision = precision
+    return module
+
+
+def _is_exact(module: nn.Module) -> bool:
+    return getattr(module, "icka_precision", "bf16") == "fp32"
+
+
+def _dims(config, B, S, R, train: bool, exact: bool = False) -> ops.Dims:
+    if not exact:
+        check_head_size_bf16(config)
     return ops.Dims(B, S, R, config.hidden_size, config.intermediate_size, config.num_attention_heads,
                     float(getattr(config, "layer_norm_eps", 1e-12)), float(config.hidden_dropout_prob),
                     float(config.attention_probs_dropout_prob), train)
 
 
-class _IckaModule(nn.Module):
-    """Shared plumbing: lazily (re)build the ParamArena over the outermost module and refresh bf16 shadows."""
-
-    def _arena(self) -> ParamArena:
-        A = arena_of(self)
-        if A.device.type != "cuda":
-            raise RuntimeError("%s: parameters are on %s; move the module to a ROCm device (icka_amd has no CPU "
-                               "path)" % (type(self).__name__, A.device))
-        A.begin_step()
-        A.sync()
-        return A
+class _IckaModule(ArenaModule):
+    """Shared plumbing (arena.ArenaModule): lazily (re)build the ParamArena over the outermost module; the outermost
+    forward of a call tree refreshes the bf16 shadows."""
 
     def _anchor(self, A: ParamArena) -> torch.Tensor:
         return A.anchor
@@ -118,6 +139,9 @@ class BertLayerNorm(_IckaModule):
     def forward(self, x):
         A = self._arena()
         shape = x.shape
+        if _is_exact(self):
+            return X.LayerNormFn.apply(A.anchor, _hidden2d(x, "x", True), None, self, A,
+                                       float(self.variance_epsilon)).view(shape)
         return _LayerNormFn.apply(A.anchor, _hidden2d(x, "x"), self, A).view(shape)
 
 
@@ -168,6 +192,9 @@ class BertEmbeddings(_IckaModule):
         A = self._arena()
         ids = input_ids.contiguous()
         tt = None if token_type_ids is None else token_type_ids.contiguous()
+        if _is_exact(self):
+            d = _dims(self.config, B, S, 0, self.training, True)
+            return X.EmbeddingsFn.apply(A.anchor, self, A, ids, tt, d).view(B, S, -1)
         d = _dims(self.config, B, S, 0, self.training)
         y, yf = ops.EmbeddingsFn.apply(A.anchor, self, A, ids, tt, d)
         return _with_twin(y, yf, (B, S, -1))
@@ -256,6 +283,10 @@ class BertLayer(_IckaModule):
     def forward(self, hidden_states, attention_mask):
         B, S, H = hidden_states.shape
         A = self._arena()
+        if _is_exact(self):
+            d = _dims(self.config, B, S, 0, self.training, True)
+            return X.BertLayerFn.apply(A.anchor, _hidden2d(hidden_states, exact=True), self, A,
+                                       _add_mask2d(attention_mask, B, S), d).view(B, S, H)
         x = _hidden2d(hidden_states)
         d = _dims(self.config, B, S, 0, self.training)
         y, yf = ops.BertLayerFn.apply(A.anchor, x, _twin(hidden_states), self, A, _add_mask2d(attention_mask, B, S), d)
@@ -306,6 +337,11 @@ class BertCrossAttentionLayer(_IckaModule):
         B, S, H = s1_hidden_states.shape
         R = s2_hidden_states.shape[1]
         A = self._arena()
+        if _is_exact(self):
+            d = _dims(self.config, B, S, R, self.training, True)
+            return X.CrossLayerFn.apply(A.anchor, _hidden2d(s1_hidden_states, "s1_hidden_states", True),
+                                        _hidden2d(s2_hidden_states, "s2_hidden_states", True), self, A,
+                                        _add_mask2d(s2_attention_mask, B, R), d).view(B, S, H)
         s1 = _hidden2d(s1_hidden_states, "s1_hidden_states")
         s2 = _hidden2d(s2_hidden_states, "s2_hidden_states")
         d = _dims(self.config, B, S, R, self.training)
@@ -344,6 +380,9 @@ class BertPooler(_IckaModule):
     def forward(self, hidden_states):
         A = self._arena()
         B, S, H = hidden_states.shape
+        if _is_exact(self):
+            first = _hidden2d(hidden_states, exact=True).view(B, S, H)[:, 0]
+            return X.LinearFn.apply(A.anchor, first, self.dense, A, True)
         x = _hidden2d(hidden_states)
         first = x.view(B, S, H)[:, 0]            # strided [B,H] view, row stride S*H: read in place by the GEMM
         return ops.LinearFn.apply(A.anchor, first, self.dense, A, False, K.EPI_TANH)
@@ -360,6 +399,11 @@ class cls_layer_both(_IckaModule):
 
     def forward(self, lang_feat, img_feat):
         A = self._arena()
+        if _is_exact(self):
+            x = _hidden2d(lang_feat, "lang_feat", True)
+            r = _hidden2d(img_feat, "img_feat", True)
+            feat = X.LayerNormFn.apply(A.anchor, x, r, self.proj_norm, A, float(self.proj_norm.eps))
+            return X.LinearFn.apply(A.anchor, feat, self.proj, A, False)
         x = lang_feat if lang_feat.dtype == BF16 else _CastFn.apply(lang_feat, True)
         r = img_feat if img_feat.dtype == BF16 else _CastFn.apply(img_feat, True)
         feat = ops.AddLayerNormFn.apply(A.anchor, x, r, self.proj_norm, A, float(self.proj_norm.eps))
@@ -372,8 +416,16 @@ def scalar_gate_fusion(owner: nn.Module, cross_output_layer: torch.Tensor, token
     returns g*token_embedding + (1-g)*cross_output_layer  ([B,S,H] bf16).  ``token_embedding`` comes from the
     out-of-scope RoBERTa stage and is an input here."""
     A = arena_of(owner)
-    A.begin_step(); A.sync()
+    A.sync()
     B, S, H = cross_output_layer.shape
+    if _is_exact(owner):
+        cross = _hidden2d(cross_output_layer, "cross_output_layer", True)
+        tok = _hidden2d(token_embedding, "token_embedding", True)
+        feat = X.LayerNormFn.apply(A.anchor, cross.view(B, S, H)[:, 0], tok.view(B, S, H)[:, 0], owner.cls_layer.proj_norm,
+                                   A, float(owner.cls_layer.proj_norm.eps))
+        related = X.LinearFn.apply(A.anchor, feat, owner.cls_layer.proj, A, False)
+        logit = X.LinearFn.apply(A.anchor, related, owner.aux_head, A, False)
+        return X.SampleGateFn.apply(tok, cross, logit.view(B), 0, B, S).view(B, S, H)
     cross = _hidden2d(cross_output_layer, "cross_output_layer")
     tok = _hidden2d(token_embedding, "token_embedding")
     c0 = cross.view(B, S, H)[:, 0]          # strided [B,H] views (row stride S*H), read in place
@@ -498,6 +550,9 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     # ---- text encoder (cl_modeling.py:1341-1344)
     sequence_output, _ = self.bert(input_ids, token_type_ids=segment_ids, attention_mask=input_mask,
                                    output_all_encoded_layers=False)
+    exact = _is_exact(self)
+    if exact:
+        return _mner_trunk_exact(self, A, sequence_output.view(B * S, H), added_attention_mask, visual_embeds_att, B, S)
     seq = sequence_output.view(B * S, H)
     seqf = _twin(sequence_output)
     if self.training and cfg.hidden_dropout_prob > 0:
@@ -505,13 +560,7 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
         seqf = None
     # ---- region tokens + projection (:1348-1350)
     v = visual_embeds_att
-    if not v.is_cuda:
-        raise TypeError("visual_embeds_att must be on a ROCm device")
-    if v.dim() == 4 or (v.dim() == 3 and v.shape[1] == 2048 and v.shape[2] != 2048):
-        R = v.shape[2] * v.shape[3] if v.dim() == 4 else v.shape[2]
-        layout = 1
-    else:
-        R, layout = v.shape[1], 0
+    R, layout = _region_layout(v)
     tokens = torch.empty(B * R, 2048, dtype=BF16, device=dev)
     K.regions_to_tokens(v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v, tokens, B, R,
                         2048, layout)
@@ -525,6 +574,33 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     for layer in self.txt2img_attention.layer:
         cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
     return A, seq, seqf, cross, crossf
+
+
+def _region_layout(v: torch.Tensor):
+    """(R, layout): layout 1 = the reference's channel-major [B,2048,7,7] / [B,2048,R] (:956), 0 = tokens [B,R,2048]."""
+    if not v.is_cuda:
+        raise TypeError("visual_embeds_att must be on a ROCm device")
+    if v.dim() == 4 or (v.dim() == 3 and v.shape[1] == 2048 and v.shape[2] != 2048):
+        return (v.shape[2] * v.shape[3] if v.dim() == 4 else v.shape[2]), 1
+    return v.shape[1], 0
+
+
+def _mner_trunk_exact(self, A, seq, added_attention_mask, v, B, S):
+    """fp32-exact form of the trunk after the text encoder (same reference lines as _mner_trunk)."""
+    cfg = self.config
+    dev = seq.device
+    if self.training and cfg.hidden_dropout_prob > 0:
+        seq = X.DropoutFn.apply(seq, A, float(cfg.hidden_dropout_prob))
+    R, layout = _region_layout(v)
+    tokens = X.regions_to_tokens(v if v.dtype == F32 else v.float(), B, R, layout)
+    vis = X.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False)
+    img_mask = K.additive_mask(added_attention_mask if added_attention_mask.dtype == torch.int64
+                               else added_attention_mask.long(), R, torch.empty(B, R, dtype=F32, device=dev))
+    d = _dims(cfg, B, S, R, self.training, True)
+    cross = seq
+    for layer in self.txt2img_attention.layer:
+        cross = X.CrossLayerFn.apply(A.anchor, cross, vis, layer, A, img_mask, d)
+    return A, seq, None, cross, None
 
 
 class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
@@ -584,9 +660,15 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
             if self.crs_classifier.weight.shape[1] != 2 * H * S:
                 raise ValueError("gate_cl: sequence length %d does not match crs_classifier (built for %d)"
                                  % (S, self.crs_classifier.weight.shape[1] // (2 * H)))
-            crs = ops.CrsFn.apply(A.anchor, seq, cross, self.crs_classifier, A, B, S)
-            cross = ops.SampleGateFn.apply(cross, None, crs, 1, B, S)
+            if _is_exact(self):
+                crs = X.CrsFn.apply(A.anchor, seq, cross, self.crs_classifier, A, B, S)
+                cross = X.SampleGateFn.apply(cross, None, crs, 1, B, S)
+            else:
+                crs = ops.CrsFn.apply(A.anchor, seq, cross, self.crs_classifier, A, B, S)
+                cross = ops.SampleGateFn.apply(cross, None, crs, 1, B, S)
         # ---- gate + classifier (:1363-1371)
+        if _is_exact(self):
+            return X.GatedHeadFn.apply(A.anchor, seq, cross, self, A).view(B, S, self.num_labels)
         logits = ops.GatedHeadFn.apply(A.anchor, seq, cross, self, A)
         return logits.view(B, S, self.num_labels)
 
@@ -599,13 +681,7 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
             return logits
         if self.crf is not None:
             return -self.crf(logits, labels, mask=input_mask.byte(), reduction="mean")
-        return token_ce_loss(logits, labels, input_mask)
-
-    def zero_grad(self, set_to_none: bool = True):
-        super().zero_grad(set_to_none=set_to_none)
-        A = getattr(self, "_icka_arena", None)
-        if A is not None:
-            A.begin_step()   # grads dropped -> the next backward overwrites the arena slots instead of accumulating
+        return token_ce_loss(logits, labels, input_mask, exact=_is_exact(self))
 
 
 class MTCCMBertForMMTokenClassificationCRF_gate_1(BertPreTrainedModel):
@@ -663,17 +739,14 @@ class MTCCMBertForMMTokenClassificationCRF_gate_1(BertPreTrainedModel):
             return self.crf.decode(emissions, mask=output_mask)
         return emissions
 
-    def zero_grad(self, set_to_none: bool = True):
-        super().zero_grad(set_to_none=set_to_none)
-        A = getattr(self, "_icka_arena", None)
-        if A is not None:
-            A.begin_step()
 
-
-def token_ce_loss(logits: torch.Tensor, labels: torch.Tensor, input_mask: torch.Tensor) -> torch.Tensor:
-    """Token-level cross-entropy, mean over tokens with input_mask != 0 (fused forward + logit gradient)."""
+def token_ce_loss(logits: torch.Tensor, labels: torch.Tensor, input_mask: torch.Tensor, exact: bool = False) -> torch.Tensor:
+    """Token-level cross-entropy, mean over tokens with input_mask != 0 (fused forward + logit gradient; ``exact``:
+    f32 logit gradient instead of the bf16 one the bf16 classifier backward consumes)."""
     C = logits.shape[-1]
     lg = logits.reshape(-1, C)
     if lg.dtype != F32:
         raise TypeError("logits must be f32")
+    if exact:
+        return X.TokenCEFn.apply(lg.contiguous(), labels.reshape(-1).contiguous(), input_mask.reshape(-1).contiguous())
     return ops.TokenCEFn.apply(lg, labels.contiguous(), input_mask.contiguous())

@@ -78,6 +78,16 @@ class ResNet(nn.Module):
                 m.bias.data.zero_()
         self._folded = None
         self._folded_key = None
+        # load_state_dict always invalidates the folded weights (version counters also move, but be explicit)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refold())
+
+    def refold(self) -> None:
+        """Drop the folded conv+BatchNorm operands; the next forward re-folds.  The encoder is frozen in the reference
+        (resnet/resnet_utils.py:13-53 under no_grad), so the fold is cached: it is re-done when a parameter / buffer
+        version counter moved, after load_state_dict, after any optimizer step in the process, or after refold() --
+        call refold() yourself after writing parameters through ``.data`` (invisible to version counters)."""
+        self._folded = None
+        self._folded_key = None
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None
@@ -114,7 +124,8 @@ class ResNet(nn.Module):
         return out.to(BF16).contiguous(), b.contiguous()
 
     def _prepare(self):
-        key = (sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
+        from .arena import _OPT_STEPS
+        key = (sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()) + _OPT_STEPS[0],
                next(self.parameters()).device)
         if self.training:
             raise RuntimeError("icka_amd ResNet runs eval-mode BatchNorm only (call .eval(); the reference keeps the "

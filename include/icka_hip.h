@@ -354,6 +354,80 @@ int icka_bump_dropout_nonce(uint32_t* device_words, void* stream);
 /* Debug/test helper: materialise the dropout keep-multiplier (0 or 1/(1-p)) for element indices [0,n) as f32. */
 int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t seed, void* stream);
 
+/* ===============================================================================================================
+ * fp32 "exact" mode (icka_amd.set_precision(model, "fp32")): the same path in f32 storage and f32 arithmetic, for
+ * BASELINE.json's "within 1e-3 fp32" bar -- the reference is fp32 end to end (SURVEY.md section 0;
+ * Cross_Modal_Interaction_Module.py:950).  Every contraction runs on the f32-input matrix instruction
+ * v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain); attention materialises its scores as the reference does
+ * (:488-502).  All pointers are f32 device pointers unless stated.  Used only when selected; never a fallback.
+ *
+ * Batched GEMM  C[b0,b1] = alpha * op(A[b0,b1]) . op(B[b0,b1]) (+ bias[n]) (+ beta * C[b0,b1]),  nb0*nb1 <= 65535:
+ *   NT: A[M,K] B[N,K]    NN: A[M,K] B[K,N]    TN: A[K,M] B[K,N]    TT: A[K,M] B[N,K]
+ * any M, N, K >= 1, any leading dimension; X[b0,b1] = X + b0*x_bs0 + b1*x_bs1 (elements).  Replaces nn.Linear /
+ * torch.matmul (:479-481, :488, :502, :533, :549, :562, :958; cl_modeling.py:1363, :1371) and their autograd. */
+enum { ICKA_GEMM_TT = 3 };
+typedef struct icka_xgemm_desc {
+    int32_t op, M, N, K;
+    const float* A; int64_t lda, a_bs0, a_bs1;
+    const float* B; int64_t ldb, b_bs0, b_bs1;
+    float* C; int64_t ldc, c_bs0, c_bs1;
+    int32_t nb0, nb1;
+    const float* bias;      /* f32 [N] or NULL */
+    float alpha, beta;
+} icka_xgemm_desc;
+int icka_x_gemm(const icka_xgemm_desc* d, void* stream);
+/* y = LayerNorm(dropout(x) + residual) * gamma + beta  (BertSelfOutput :561-565, BertOutput :532-536, BertLayerNorm
+ * :518-522; x is the dense output WITH its bias).  xhat [M,H] / rstd [M] saved for backward (nullable). */
+int icka_x_ln_fwd(const float* x, int64_t ldx, const float* residual, int64_t ldr, const float* gamma,
+                  const float* beta, float* y, float* xhat, float* rstd, int32_t M, int32_t H, float eps,
+                  float p_drop, uint64_t seed, void* stream);
+/* dpre [M,H] = gradient of the LayerNorm input (= of the residual); ddense (nullable) = dpre * dropout mask. */
+int icka_x_ln_bwd(const float* dy, int64_t lddy, const float* xhat, const float* rstd, const float* gamma,
+                  float* dpre, float* ddense, int32_t M, int32_t H, float p_drop, uint64_t seed, void* stream);
+/* out[c] (+)= sum_r a[r,c] * (b ? b[r,c] : 1)   (bias and LayerNorm parameter gradients; fixed summation order) */
+int icka_x_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int32_t M, int32_t N,
+                  int32_t accumulate, void* stream);
+/* BertEmbeddings.forward :398-410 up to the LayerNorm (dropout: icka_x_dropout); scatter = backward into the tables
+ * from the LayerNorm-input gradient (f32 atomics, padding_idx row of the word table skipped). */
+int icka_x_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                     const float* typ, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
+                     int32_t B, int32_t S, int32_t H, float eps, void* stream);
+int icka_x_embed_scatter(const float* dpre, const int64_t* ids, const int64_t* token_type, float* dword, float* dpos,
+                         float* dtyp, int32_t B, int32_t S, int32_t H, int32_t padding_idx, void* stream);
+/* In place P[B,heads,Sq,Skv] = softmax(P*scale + add_mask[b,j]) (:489-494); Pd = dropout(P) (:500) when p_drop > 0.
+ * Backward, in place on dS (which holds dPd on entry): dS = P * (dPd*mask - sum_j dPd*mask*P) * scale. */
+int icka_x_softmax_fwd(float* P, float* Pd, const float* add_mask, int32_t B, int32_t heads, int32_t Sq, int32_t Skv,
+                       float scale, float p_drop, uint64_t seed, void* stream);
+int icka_x_softmax_bwd(const float* P, float* dS, int32_t B, int32_t heads, int32_t Sq, int32_t Skv, float scale,
+                       float p_drop, uint64_t seed, void* stream);
+/* Elementwise activations.  mode 0: y = gelu(x) (erf form, :31-37); 1: y = tanh(x) (BertPooler :675-681);
+ * 2: y2 = sigmoid(x), y = y2 * aux (cl_modeling.py:1363-1367).
+ * Backward: mode 0: dx = dy * gelu'(saved = x); 1: dx = dy * (1 - saved^2), saved = y; 2 (saved = gate, aux = cross):
+ * dx = dy * aux * g(1-g) (gradient of the gate pre-activation), dx2 = dy * g (gradient of cross through the product). */
+int icka_x_act_fwd(const float* x, const float* aux, float* y, float* y2, int64_t n, int32_t mode, void* stream);
+int icka_x_act_bwd(const float* dy, const float* saved, const float* aux, float* dx, float* dx2, int64_t n,
+                   int32_t mode, void* stream);
+/* y = x * keep(i) / (1-p), the same counter-hash mask as the bf16 kernels (forward and backward are the same call) */
+int icka_x_dropout(const float* x, float* y, int64_t n, float p_drop, uint64_t seed, void* stream);
+int icka_x_add(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int32_t M,
+               int32_t N, void* stream);
+/* out [M, Ha+Hb] = [a | b]  (torch.cat((seq, cross), dim=-1), cl_modeling.py:1363-1370) */
+int icka_x_concat2(const float* a, int64_t lda, int32_t Ha, const float* b, int64_t ldb, int32_t Hb, float* out,
+                   int32_t M, void* stream);
+/* f32 twin of icka_regions_to_tokens */
+int icka_x_regions_to_tokens(const float* src, float* dst, int32_t B, int32_t R, int32_t C, int32_t layout,
+                             void* stream);
+/* f32 twins of icka_sample_gate_fwd / _bwd (dgate is OVERWRITTEN: one block per sample, fixed order) */
+int icka_x_sample_gate_fwd(const float* a, int64_t lda, const float* c, int64_t ldc, const float* gate, int32_t mode,
+                           float* out, int64_t ldo, int32_t B, int32_t S, int32_t H, void* stream);
+int icka_x_sample_gate_bwd(const float* dout, int64_t lddo, const float* a, int64_t lda, const float* c, int64_t ldc,
+                           const float* gate, int32_t mode, float* da, int64_t ldda, float* dc, int64_t lddc,
+                           float* dgate, int32_t B, int32_t S, int32_t H, void* stream);
+/* f32 twins of icka_token_ce / icka_scale_by_ratio (dlogits f32 [M,C] contiguous, unscaled) */
+int icka_x_token_ce(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* loss_sum,
+                    float* count, float* dlogits, int32_t M, int32_t C, void* stream);
+int icka_x_scale_by_ratio(const float* x, float* y, const float* num, const float* den, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
