@@ -163,31 +163,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_) {
     }
 }
 
-// ------------------------------------------------------------------------------------------- delta = rowsum(dO*O)
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ O, int64_t ldo, const bf16_t* __restrict__ dO,
-                                  int64_t lddo, float* __restrict__ delta, int B, int h, int Sq) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8-element chunk
-    const int cpr = h * 8;                                               // chunks per token row
-    const int64_t total = (int64_t)B * Sq * cpr;
-    float s = 0.f;
-    int64_t row = 0; int c = 0;
-    if (idx < total) {
-        row = idx / cpr; c = (int)(idx - row * cpr);
-        const bf16x8 o = as_bf16x8(*reinterpret_cast<const u32x4*>(O + row * ldo + c * 8));
-        const bf16x8 d = as_bf16x8(*reinterpret_cast<const u32x4*>(dO + row * lddo + c * 8));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += bf2f(o[e]) * bf2f(d[e]);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (idx < total && (c & 7) == 0) {
-        const int head = c >> 3;
-        const int64_t b = row / Sq, sq = row - b * Sq;
-        delta[(b * h + head) * Sq + sq] = s;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------- dQ kernel
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_) {
     AttnArgs a = a_;
@@ -216,15 +191,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_) {
     const bool qok = q < a.Sq;
     const int64_t stat = (int64_t)(b * a.h + head) * a.Sq + q;
     const float lse_q = qok ? a.lse[stat] : INFINITY;
-    const float dl_q = qok ? a.delta[stat] : 0.f;
     const uint32_t idx_row = ((uint32_t)(b * a.h + head) * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
+
+    // Pass 1: delta_q = sum_j P_qj * dP_qj in f32 from the recomputed P and dP.  The flash-attention shortcut
+    // delta = rowsum(dO * O) reads the bf16-ROUNDED output: its 2^-9 relative error is harmless per se, but dS =
+    // P * (dP - delta) cancels almost completely once the value rows of a head resemble each other (deep layers), and
+    // the query / key weight gradients of the last bert-large layers then came out 10 % off (tests/test_fullsize_gpu.py).
+    float dl_q = 0.f;
+    for (int kv0 = 0; kv0 < a.Skv; kv0 += TILE) {
+        if (kv0) __syncthreads();
+        stage_tile(sK, Kb, a.ldk, kv0, a.Skv, tid);
+        stage_tile(sV, Vb, a.ldv, kv0, a.Skv, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = mfma16(frag_row(sK, 16 * kt, ks, lane), qf[ks], s);
+                dp = mfma16(frag_row(sV, 16 * kt, ks, lane), dof[ks], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + 16 * kt + 4 * g + r;
+                const float p = key < a.Skv ? __expf(s[r] * a.scale + mb[key] - lse_q) : 0.f;
+                dl_q += p * dp[r] * drop_mul(a.drop, idx_row + (uint32_t)key);
+            }
+        }
+    }
+    dl_q += __shfl_xor(dl_q, 16, 64);
+    dl_q += __shfl_xor(dl_q, 32, 64);
+    if (g == 0 && qok) a.delta[stat] = dl_q;    // read by attn_bwd_dkv_kernel (launched after this kernel)
 
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kv0 = 0; kv0 < a.Skv; kv0 += TILE) {
-        if (kv0) __syncthreads();
+        __syncthreads();
         stage_tile(sK, Kb, a.ldk, kv0, a.Skv, tid);
         stage_tile(sV, Vb, a.ldv, kv0, a.Skv, tid);
         __syncthreads();
@@ -802,10 +806,7 @@ extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
         ICKA_CHECK_LAUNCH();
         return 0;
     }
-    const int64_t chunks = (int64_t)B * Sq * heads * 8;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a.O, ldo, a.dO,
-                       lddo, delta, B, heads, Sq);
-    ICKA_CHECK_LAUNCH();
+    // the dQ kernel computes delta = rowsum(P . dP) itself (first pass) and leaves it for the dK/dV kernel
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * heads * ((Sq + TILE - 1) / TILE)), dim3(256), 0, st, a);
     ICKA_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * heads * ((Skv + TILE - 1) / TILE)), dim3(256), 0, st, a);

@@ -1,0 +1,122 @@
+"""GPU: parameter / gradient bookkeeping around the kernels: the bf16 shadow follows parameter updates
+made through ``.data`` (the reference's BertAdam, my_bert/optimization.py:153), zero_grad between forward and backward,
+hipGraph replay with the reference loop's zero_grad-per-step (My_cross_attention.py:843)."""
+import pytest
+import torch
+
+from icka_amd import synth
+from golden_util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    case = load_case("tiny_cl_r49")
+    cfg = case["cfg"]
+    c = BertConfig(cfg["vocab_size"], hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                   num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
+                   max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=cfg["type_vocab_size"])
+    m = MTCCMBertForMMTokenClassificationCRF(c, layer_num1=cfg["layer_num1"], num_labels=cfg["num_labels"])
+    synth.fill_module_(m)
+    g = {k: v.cuda() for k, v in case["batch"].items()}
+    args = (g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"], g["visual_embeds_mean"],
+            g["visual_embeds_att"])
+    return m.cuda().eval(), args, g["labels"]
+
+
+def _shadow_ok(A):
+    torch.cuda.synchronize()
+    return torch.equal(A.shadow, A.flat.to(torch.bfloat16))
+
+
+def test_shadow_follows_data_updates_like_bertadam():
+    """p.data.add_() leaves every version counter untouched; the default policy re-casts in each outermost forward."""
+    model, args, labels = _model()
+    model(*args, labels=labels).backward()
+    A = model._icka_arena
+    assert A.shadow_policy == "always" and _shadow_ok(A)
+    l0 = model(*args, labels=labels).item()
+    v = sum(p._version for p in model.parameters())
+    with torch.no_grad():
+        for p in model.parameters():           # my_bert/optimization.py:153  p.data.add_(-update_with_lr)
+            if p.grad is not None:
+                p.data.add_(-0.05 * p.grad.data)
+    assert sum(p._version for p in model.parameters()) == v      # invisible to the counters (the ADVICE scenario)
+    l1 = model(*args, labels=labels).item()
+    assert _shadow_ok(A), "GEMMs would keep running on stale weights"
+    assert l1 < l0 - 1e-3                       # a gradient step on the same batch lowers the loss
+    # opt-in tracked policy: in-place ops on the parameter / optimizer steps / mark_dirty() are seen, .data writes are not
+    A.shadow_policy = "tracked"
+    model(*args, labels=labels)
+    with torch.no_grad():
+        model.classifier.weight.mul_(1.5)       # bumps _version
+    model(*args, labels=labels)
+    assert _shadow_ok(A)
+    model.classifier.weight.data.mul_(0.5)
+    A.mark_dirty()                              # the documented escape hatch for .data writes under "tracked"
+    model(*args, labels=labels)
+    assert _shadow_ok(A)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    model(*args, labels=labels).backward()
+    opt.step()
+    model(*args, labels=labels)
+    assert _shadow_ok(A)
+
+
+def test_zero_grad_between_forward_and_backward():
+    model, args, labels = _model()
+    model(*args, labels=labels).backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    for _ in range(2):                          # loss = model(x); optimizer.zero_grad(); loss.backward()
+        loss = model(*args, labels=labels)
+        opt.zero_grad()
+        loss.backward()
+    for n, p in model.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), "%s accumulated across steps" % n
+
+
+def test_parameters_outside_the_optimizer_accumulate_like_torch():
+    model, args, labels = _model()
+    head = [model.classifier.weight, model.classifier.bias]
+    opt = torch.optim.SGD(head, lr=0.0)         # trunk frozen out of the optimizer: nobody clears its .grad
+    model(*args, labels=labels).backward()
+    g_head, g_trunk = head[0].grad.clone(), model.vismap2text.weight.grad.clone()
+    opt.zero_grad()
+    model(*args, labels=labels).backward()
+    assert torch.equal(head[0].grad, g_head)
+    assert torch.allclose(model.vismap2text.weight.grad, 2 * g_trunk, rtol=1e-3, atol=1e-7)
+
+
+def test_graphed_step_with_reference_training_loop():
+    from icka_amd import kernels as K
+    from icka_amd.graph import GraphedStep
+    model, args, labels = _model()
+    model.train()
+
+    def step():
+        loss = model(*args, labels=labels)
+        loss.backward()
+        return loss
+
+    gs = GraphedStep(model, step)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    losses = []
+    for _ in range(4):
+        loss = gs()
+        assert all(p.grad is not None for p in (model.classifier.weight, model.bert.pooler.dense.weight) if p is model.classifier.weight)
+        w0 = model.classifier.weight.detach().clone()
+        opt.step()
+        assert not torch.equal(w0, model.classifier.weight.detach()), "optimizer saw no gradient after replay"
+        model.zero_grad()                       # My_cross_attention.py:843 (set_to_none=True is the default)
+        assert model.classifier.weight.grad is None
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]               # the replayed forward sees the updated weights
+    assert K._NONCE_PTR == gs.nonce.data_ptr()
+    gs.close()
+    assert K._NONCE_PTR is None                 # kernels no longer point at memory the GraphedStep owned
+    with pytest.raises(RuntimeError):
+        gs()

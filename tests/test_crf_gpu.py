@@ -4,6 +4,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+HEAD_CRF_GRAD_BAR = 0.1   # 2x the value measured on MI355X (printed by the test)
+
 F32 = torch.float32
 
 
@@ -112,11 +114,15 @@ def test_model_with_native_crf_loss_and_decode():
     rloss.backward()
     assert abs(loss.item() - rloss.item()) < 2e-2 * max(1.0, abs(rloss.item()))
     gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst, wk = 0.0, ""
     for k, p in model.named_parameters():
         if P[k].grad is None:
             continue
         rel = ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item()
-        assert rel < 0.1, (k, rel)
+        if rel > worst:
+            worst, wk = rel, k
+    print("\n[gated head + CRF] loss %.4f (oracle %.4f), worst gradient rel-L2 %.3e at %s" % (loss.item(), rloss.item(), worst, wk))
+    assert worst < HEAD_CRF_GRAD_BAR, (wk, worst)
     pred = model(*args)
     assert isinstance(pred, list) and [len(p) for p in pred] == b["input_mask"].sum(1).tolist()
     ref_pred = OC.crf_decode(model.logits(*args[:4], args[5]).float().cpu(), b["input_mask"].bool(),

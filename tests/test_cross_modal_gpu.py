@@ -8,6 +8,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# gradient bars = 2x the values measured on MI355X (printed by the tests)
+PUBLISHED_GRAD_BAR = 0.15
+PROMPT_GRAD_BARS = (0.1, 0.1)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -55,10 +59,10 @@ def test_full_model_against_reference_fixture_and_oracle_gradients():
         if rel > worst:
             worst, worst_key = rel, k
     assert checked > 100
-    assert worst < 0.15, (worst_key, worst)
     assert pred == OC.crf_decode(em.float().cpu(), mask, *[p.detach() for p in crfP])
     print("\n[published model] emissions vs reference fixture max abs err %.3e, loss %.4f (oracle %.4f), worst grad rel "
           "err %.3e (%s) over %d tensors" % (err, loss.item(), rloss.item(), worst, worst_key, checked))
+    assert worst < PUBLISHED_GRAD_BAR, (worst_key, worst)
 
 
 def test_full_model_train_mode_step_and_foreign_encoder_rejected():
@@ -214,8 +218,14 @@ def test_prompt_encoder_row_padding_matches_oracle():
     pr.grad = None
     (XO.prompt_roberta(Pm, "last_encoder", ocfg, ids, am, pr, pm) * w * vmask[..., None]).sum().backward()
     rel = ((pg.grad.float().cpu() - pr.grad).norm() / pr.grad.norm()).item()
-    assert rel < 0.1, rel
+    wk, wv = "", 0.0
     for k in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
               "encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight"):
         a, b_ = m.get_parameter(k).grad.float().cpu(), Pm["last_encoder." + k].grad
-        assert ((a - b_).norm() / (b_.norm() + 1e-6)).item() < 0.1, k
+        e = ((a - b_).norm() / (b_.norm() + 1e-6)).item()
+        if e > wv:
+            wk, wv = k, e
+    print("\n[prompt encoder] output max abs err %.3e; prompt-gradient rel-L2 %.3e; worst parameter gradient %.3e at %s"
+          % (err, rel, wv, wk))
+    assert rel < PROMPT_GRAD_BARS[0], rel
+    assert wv < PROMPT_GRAD_BARS[1], (wk, wv)

@@ -1,0 +1,115 @@
+"""GPU: the HIP path at the FULL BASELINE.json configurations against the live CPU oracle (eval mode, same by-key
+seeded weights and seeded inputs): logits, loss and every parameter gradient, in both arithmetic modes.
+
+  c2  bert-base  (L12, H768)   seq 128, 36 regions, batch 32                      bf16 <= 2e-2, fp32 <= 1e-3
+  c4  bert-large (L24, H1024)  seq 256, 50 regions, batch 4 (tiled attention)     bf16 <= 2e-2, fp32 <= 1e-3
+  c5  bert-base, fp8 QK^T/PV in the cross-attention, batch 64                     within the bf16 budget
+
+The oracle (oracle/mner_oracle.py, pinned bit-exactly to the reference by tests/golden/make_golden.py) runs ONCE per
+configuration on the host cores; the gradient bars are 2x the values measured on MI355X (printed with the worst key).
+Reference lines matched: my_bert/cl_modeling.py:1338-1371, Cross_Modal_Interaction_Module.py:478-506.
+"""
+import time
+
+import pytest
+import torch
+
+from icka_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL_BF16 = 2e-2   # BASELINE.json north_star
+LOGIT_TOL_FP32 = 1e-3
+
+
+def _oracle(cfgkw, layer_num1, R, batch):
+    """One CPU fwd+bwd of the oracle: returns (state-dict-keyed fp32 parameters with .grad, logits, loss)."""
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    from oracle import mner_oracle as O
+    S = batch["input_ids"].shape[1]
+    cfg = BertConfig(cfgkw["vocab_size"], **{k: v for k, v in cfgkw.items() if k != "vocab_size"})
+    model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=layer_num1, num_labels=13, regions=R, max_seq_length=S)
+    synth.fill_module_(model)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ocfg = O.OracleConfig(**cfgkw)
+    t0 = time.time()
+    ref = O.mner_logits(P, ocfg, batch["input_ids"], batch["segment_ids"], batch["input_mask"],
+                        batch["added_attention_mask"], batch["visual_embeds_att"], layer_num1, R)
+    rloss = O.token_ce_loss(ref, batch["labels"], batch["input_mask"])
+    rloss.backward()
+    print("\n  [oracle] CPU fwd+bwd %.1f s on %d threads" % (time.time() - t0, torch.get_num_threads()))
+    return cfg, model, P, ref.detach(), rloss.item()
+
+
+def _compare(tag, model, P, ref_logits, ref_loss, batch, logit_tol, grad_tol):
+    g = {k: v.cuda() for k, v in batch.items()}
+    args = (g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"], g["visual_embeds_mean"],
+            g["visual_embeds_att"])
+    model.eval()
+    logits = model(*args)
+    err = (logits.float().cpu() - ref_logits).abs().max().item()
+    model.zero_grad()
+    loss = model(*args, labels=g["labels"])
+    loss.backward()
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst, worst_key, nonfinite, rows = 0.0, "", [], []
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        if not torch.isfinite(p.grad).all():
+            nonfinite.append(k)
+            continue
+        gr = P[k].grad    # parameters with an exactly-zero true gradient (key.bias): absolute floor
+        rel = ((p.grad.float().cpu() - gr).norm() / (gr.norm() + 1e-4 * gmax)).item()
+        rows.append((rel, k, gr.norm().item()))
+        if rel > worst:
+            worst, worst_key = rel, k
+    rows.sort(reverse=True)
+    print("  [%s] five worst gradients (rel-L2, key, |g_ref|; largest |g_ref| %.3e): %s"
+          % (tag, gmax, "; ".join("%.2e %s %.2e" % r for r in rows[:5])))
+    print("  [%s] median gradient rel-L2 %.3e over %d tensors" % (tag, rows[len(rows) // 2][0], len(rows)))
+    print("  [%s] logits max abs err %.3e (tol %.0e)  loss %.6f (oracle %.6f)  worst grad rel-L2 %.3e at %s (bar %.1e)"
+          % (tag, err, logit_tol, loss.item(), ref_loss, worst, worst_key, grad_tol))
+    assert not nonfinite, nonfinite
+    assert err < logit_tol, "%s: logits max abs err %.3e" % (tag, err)
+    assert abs(loss.item() - ref_loss) < logit_tol
+    assert worst < grad_tol, "%s: %s gradient rel-L2 %.3e" % (tag, worst_key, worst)
+    pad = model.bert.embeddings.word_embeddings.weight.grad[0]
+    assert pad.abs().max().item() == 0.0
+    return err, worst
+
+
+BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+            max_position_embeddings=512)
+LARGE = dict(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+             max_position_embeddings=512)
+
+
+def _both_modes(tag, cfgkw, B, S, R, seed, grad_bf16, grad_fp32, fp8=False):
+    import copy
+    import icka_amd
+    batch = synth.synthetic_batch(B, S, R, vocab_size=cfgkw["vocab_size"], seed=seed)
+    cfg, model, P, ref, rloss = _oracle(cfgkw, 1, R, batch)
+    if fp8:
+        for layer in model.txt2img_attention.layer:
+            layer.attention.self.fp8_scores = True
+    m16 = copy.deepcopy(model).cuda()
+    _compare(tag + " bf16" + ("+fp8 cross" if fp8 else ""), m16, P, ref, rloss, batch, LOGIT_TOL_BF16, grad_bf16)
+    del m16
+    torch.cuda.empty_cache()
+    m32 = icka_amd.set_precision(model.cuda(), "fp32")
+    _compare(tag + " fp32", m32, P, ref, rloss, batch, LOGIT_TOL_FP32, grad_fp32)
+
+
+def test_c2_full_size_bert_base_b32_s128_r36():
+    _both_modes("c2 B32 S128 R36 L12", BASE, 32, 128, 36, 19260817, grad_bf16=6e-2, grad_fp32=1e-3)
+
+
+def test_c4_full_depth_bert_large_l24_s256_r50():
+    _both_modes("c4 B4 S256 R50 L24", LARGE, 4, 256, 50, 19260818, grad_bf16=1e-1, grad_fp32=1e-3)
+
+
+def test_c5_full_size_fp8_cross_attention_b64():
+    _both_modes("c5 B64 S128 R36 L12", BASE, 64, 128, 36, 19260819, grad_bf16=6e-2, grad_fp32=1e-3, fp8=True)

@@ -5,6 +5,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+TAGGER_GRAD_BAR = 0.1   # 2x the value measured on MI355X (printed by the test)
+
 
 @pytest.mark.parametrize("persistent", [1, 0])
 @pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64), (32, 24, 1024), (7, 12, 1024)])
@@ -108,8 +110,8 @@ def test_gate_1_tagger_end_to_end_against_oracle_composition():
         if P[k].grad is None:
             continue
         worst = max(worst, ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item())
-    assert worst < 0.1, worst
     ref_pred = OC.crf_decode(em.float().cpu(), mask, *[p.detach() for p in crfP])
     assert pred == ref_pred
     print("\n[_gate_1 tagger] emissions max abs err %.3e, loss %.4f (oracle %.4f), worst grad rel err %.3e"
           % (err, loss.item(), rloss.item(), worst))
+    assert worst < TAGGER_GRAD_BAR, worst

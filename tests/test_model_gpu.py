@@ -10,6 +10,12 @@ from golden_util import GOLDEN_DIR, load_case
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-2   # bf16 tolerance stated by BASELINE.json:north_star
+# per fixture: (relative error of each parameter-gradient L2 norm, relative L2 error of the sampled gradient tensors)
+# = 2x the values measured on MI355X (the test prints the measured values and the worst key)
+C4_GEOMETRY_GRAD_BAR = 0.1
+ALIGN_GRAD_BARS = (5e-2, 0.1)   # single-query alignment encoders: (input gradients, parameter gradients)
+GRAD_BARS = {"tiny_cl_r49": (0.08, 0.12), "tiny_cl_masks": (0.08, 0.12), "tiny_gatecl_s128": (0.08, 0.12),
+             "base_cl_s64_r36": (0.08, 0.12), "base_cl_s128_r49": (0.08, 0.12)}
 
 
 def _build(cfg, regions=49, variant="cl", max_seq_length=128):
@@ -48,21 +54,26 @@ def test_logits_loss_and_grads_match_reference_fixture(name):
     loss.backward()
     params = dict(model.named_parameters())
     gmax = float(exp["grad_norms"].max())   # e.g. key.bias has an exactly-zero true gradient: absolute floor
-    worst = 0.0
+    worst_n, worst_t, key_n, key_t = 0.0, 0.0, "", ""
     for n, gn in zip([str(x) for x in exp["grad_names"]], exp["grad_norms"]):
         if n not in params or gn == 0.0:
             continue
         g = params[n].grad
         assert g is not None, n
-        mine = g.float().norm().item()
-        rel = abs(mine - gn) / gn
-        worst = max(worst, rel)
-        assert abs(mine - gn) < 0.08 * gn + 1e-5 * gmax, (n, mine, gn)
+        rel = abs(g.float().norm().item() - gn) / (gn + 1e-5 * gmax)
+        if rel > worst_n:
+            worst_n, key_n = rel, n
         key = "grad/" + n
         if key in exp:
             ref = torch.from_numpy(exp[key])
             e = ((g.float().cpu() - ref).norm() / (ref.norm() + 1e-5 * gmax)).item()
-            assert e < 0.12, (n, e)
+            if e > worst_t:
+                worst_t, key_t = e, n
+    bar_n, bar_t = GRAD_BARS[name]
+    print("[%s] worst gradient-norm error %.3e at %s (bar %.1e); worst gradient-tensor rel-L2 %.3e at %s (bar %.1e)"
+          % (name, worst_n, key_n, bar_n, worst_t, key_t, bar_t))
+    assert worst_n < bar_n, (key_n, worst_n)
+    assert worst_t < bar_t, (key_t, worst_t)
     assert model.bert.embeddings.word_embeddings.weight.grad[0].abs().max().item() == 0.0   # padding_idx row
 
 
@@ -216,8 +227,8 @@ def test_bert_large_geometry_against_live_oracle(layout, regions):
             continue
         gr = P[k].grad
         worst = max(worst, ((p.grad.float().cpu() - gr).norm() / (gr.norm() + 1e-4 * gmax)).item())
-    assert worst < 0.1, "worst relative gradient error %.3e" % worst
     print("\n[c4 geometry %s R=%d] logits max abs err %.3e, worst grad rel err %.3e" % (layout, regions, err, worst))
+    assert worst < C4_GEOMETRY_GRAD_BAR, "worst relative gradient error %.3e" % worst
 
 
 def test_fp8_cross_attention_reference_diff_report():
@@ -299,11 +310,15 @@ def test_alignment_cross_encoder_single_query_token():
     r.sum().backward()
     err = (x.detach().float().cpu() - r.detach()).abs().max().item()
     assert err < 3e-2, err
-    for mine, ref in ((c_gpu.grad, c_ref.grad), (t_gpu.grad, t_ref.grad)):
-        assert ((mine.float().cpu() - ref).norm() / ref.norm()).item() < 5e-2
+    win = max(((mine.float().cpu() - ref).norm() / ref.norm()).item()
+              for mine, ref in ((c_gpu.grad, c_ref.grad), (t_gpu.grad, t_ref.grad)))
     gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    wpar, wkey = 0.0, ""
     for k, p in m.named_parameters():
         if P[k].grad is not None:
             rel = ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item()
-            assert rel < 0.1, (k, rel)
-    print("\n[S_q=1 alignment encoders] max abs err %.3e" % err)
+            if rel > wpar:
+                wpar, wkey = rel, k
+    print("\n[S_q=1 alignment encoders] max abs err %.3e; input-gradient rel-L2 %.3e; worst parameter gradient %.3e at %s"
+          % (err, win, wpar, wkey))
+    assert win < ALIGN_GRAD_BARS[0] and wpar < ALIGN_GRAD_BARS[1], (win, wpar, wkey)
