@@ -94,8 +94,7 @@ def test_parameters_outside_the_optimizer_accumulate_like_torch():
 def test_graphed_step_with_reference_training_loop():
     from icka_amd import kernels as K
     from icka_amd.graph import GraphedStep
-    model, args, labels = _model()
-    model.train()
+    model, args, labels = _model()     # eval mode: the loss sequence below is deterministic
 
     def step():
         loss = model(*args, labels=labels)
@@ -107,7 +106,7 @@ def test_graphed_step_with_reference_training_loop():
     losses = []
     for _ in range(4):
         loss = gs()
-        assert all(p.grad is not None for p in (model.classifier.weight, model.bert.pooler.dense.weight) if p is model.classifier.weight)
+        assert model.classifier.weight.grad is not None and model.vismap2text.weight.grad is not None
         w0 = model.classifier.weight.detach().clone()
         opt.step()
         assert not torch.equal(w0, model.classifier.weight.detach()), "optimizer saw no gradient after replay"

@@ -4,7 +4,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-HEAD_CRF_GRAD_BAR = 0.1   # 2x the value measured on MI355X (printed by the test)
+HEAD_CRF_GRAD_BAR = 1.3e-2   # 2x the 6.1e-3 measured on MI355X (printed by the test)
 
 F32 = torch.float32
 

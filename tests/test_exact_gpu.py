@@ -10,7 +10,7 @@ from golden_util import GOLDEN_DIR, load_case
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3    # "within 1e-3 fp32" (BASELINE.json north_star)
-GRAD_TOL = 1e-3    # relative L2 per parameter; measured values are printed (expected ~1e-5)
+GRAD_TOL = 2.5e-4  # relative L2 per parameter: 2x the worst measured (1.1e-4, bert-base fixtures; tiny ones 2e-5)
 
 
 def _rel(a, b):

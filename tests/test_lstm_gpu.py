@@ -5,7 +5,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TAGGER_GRAD_BAR = 0.1   # 2x the value measured on MI355X (printed by the test)
+TAGGER_GRAD_BAR = 1.6e-2   # 2x the 7.8e-3 measured on MI355X (printed by the test)
 
 
 @pytest.mark.parametrize("persistent", [1, 0])

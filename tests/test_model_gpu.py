@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 2e-2   # bf16 tolerance stated by BASELINE.json:north_star
 # per fixture: (relative error of each parameter-gradient L2 norm, relative L2 error of the sampled gradient tensors)
 # = 2x the values measured on MI355X (the test prints the measured values and the worst key)
-C4_GEOMETRY_GRAD_BAR = 0.1
-ALIGN_GRAD_BARS = (5e-2, 0.1)   # single-query alignment encoders: (input gradients, parameter gradients)
-GRAD_BARS = {"tiny_cl_r49": (0.08, 0.12), "tiny_cl_masks": (0.08, 0.12), "tiny_gatecl_s128": (0.08, 0.12),
-             "base_cl_s64_r36": (0.08, 0.12), "base_cl_s128_r49": (0.08, 0.12)}
+C4_GEOMETRY_GRAD_BAR = 1.6e-2   # measured 7.8e-3 (3.0e-2 before the tiled-attention delta fix)
+ALIGN_GRAD_BARS = (1.2e-2, 2.3e-2)   # measured 5.9e-3 / 1.15e-2   # single-query alignment encoders: (input gradients, parameter gradients)
+# measured: tiny_* 5.4e-3 .. 8.5e-3 (norms and tensors); base_* norms <= 1.3e-2 (the base fixtures hold norms only)
+GRAD_BARS = {"tiny_cl_r49": (1.7e-2, 1.7e-2), "tiny_cl_masks": (1.6e-2, 1.6e-2), "tiny_gatecl_s128": (1.1e-2, 1.6e-2),
+             "base_cl_s64_r36": (2.6e-2, 2.6e-2), "base_cl_s128_r49": (2.6e-2, 2.6e-2)}
 
 
 def _build(cfg, regions=49, variant="cl", max_seq_length=128):
@@ -60,13 +61,13 @@ def test_logits_loss_and_grads_match_reference_fixture(name):
             continue
         g = params[n].grad
         assert g is not None, n
-        rel = abs(g.float().norm().item() - gn) / (gn + 1e-5 * gmax)
+        rel = abs(g.float().norm().item() - gn) / (gn + 1e-4 * gmax)
         if rel > worst_n:
             worst_n, key_n = rel, n
         key = "grad/" + n
         if key in exp:
             ref = torch.from_numpy(exp[key])
-            e = ((g.float().cpu() - ref).norm() / (ref.norm() + 1e-5 * gmax)).item()
+            e = ((g.float().cpu() - ref).norm() / (ref.norm() + 1e-4 * gmax)).item()
             if e > worst_t:
                 worst_t, key_t = e, n
     bar_n, bar_t = GRAD_BARS[name]
