@@ -85,6 +85,14 @@ def build_model(args, dev):
     return model.to(dev).train(), cfg
 
 
+# BASELINE.json configs[1], [3], [4] (configs[2] = c2 on 8 GPUs: --gpus 8); per-GPU batch 32 unless the config names one
+PRESETS = {
+    "c2": dict(hidden=768, layers=12, seq=128, regions=36, batch=32, fp8_cross=False),
+    "c4": dict(hidden=1024, layers=24, seq=256, regions=50, batch=32, fp8_cross=False),
+    "c5": dict(hidden=768, layers=12, seq=128, regions=36, batch=64, fp8_cross=True),
+}
+
+
 def workload_name(args) -> str:
     """BASELINE.json config names: c2/c3 bert-base S128 R36 B32 (the default), c4 bert-large S256 R50, c5 = c2 at B64 with
     fp8 cross-attention; anything else is 'custom'."""
@@ -98,13 +106,29 @@ def workload_name(args) -> str:
     return "custom"
 
 
-def cpu_baseline(args):
-    """Oracle (CPU restatement of the reference path), fwd+bwd, train mode, on a bounded sample of the workload."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, fl_sample):
+    """Oracle (CPU restatement of the reference path), fwd+bwd, train mode, on a bounded sample of the workload: the
+    workload's OWN per-GPU batch when one iteration is at most ~2.5e12 FLOP (c2's batch 32: ~3-5 s per iteration on 16
+    threads), else the largest power-of-two batch under that bound (c4, c5) -- stated in ``sample``."""
     from icka_amd import synth
     from oracle import mner_oracle as O
     cores = usable_cores()
     torch.set_num_threads(cores)
-    log("cpu baseline on %d threads (os.cpu_count()=%s)" % (cores, os.cpu_count()))
+    log("cpu baseline on %d threads (os.cpu_count()=%s, %s)" % (cores, os.cpu_count(), cpu_model()))
+    if args.cpu_batch <= 0:
+        args.cpu_batch = args.batch
+        while args.cpu_batch > 1 and args.cpu_batch * fl_sample > 2.5e12:
+            args.cpu_batch //= 2
     ocfg = O.OracleConfig(vocab_size=30522, hidden_size=args.hidden, num_hidden_layers=args.layers,
                           num_attention_heads=args.hidden // 64, intermediate_size=4 * args.hidden)
     shapes = O.hot_path_keys(ocfg, args.cross_layers, args.labels)
@@ -125,37 +149,47 @@ def cpu_baseline(args):
             times.append(dt)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(bs / med, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle (PyTorch CPU eager fp32, train mode) fwd+bwd, batch %d x seq %d x %d regions, 1 warm-up + "
-                      "median of %d iterations, %d threads" % (bs, args.seq, args.regions, args.cpu_iters, cores)}
+    return {"value": round(bs / med, 3), "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": "oracle (PyTorch CPU eager fp32, train mode) fwd+bwd, batch %d%s x seq %d x %d regions, 1 warm-up + "
+                      "median of %d iterations, %d threads"
+                      % (bs, " (= the workload's per-GPU batch)" if bs == args.batch else " (workload batch %d)" % args.batch,
+                         args.seq, args.regions, args.cpu_iters, cores)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--seq", type=int, default=128)
-    ap.add_argument("--regions", type=int, default=36)
-    ap.add_argument("--hidden", type=int, default=768)
-    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None,
+                    help="BASELINE.json configuration preset (default: c2, the configuration the metric is quoted on); "
+                         "explicit shape flags override the preset")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
+    ap.add_argument("--seq", type=int, default=None)
+    ap.add_argument("--regions", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--cross-layers", type=int, default=1)
     ap.add_argument("--labels", type=int, default=13)
-    ap.add_argument("--fp8-cross", action="store_true", help="BASELINE config c5: fp8 QK^T / PV in the cross-attention")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--fp8-cross", action="store_true", default=None,
+                    help="BASELINE config c5: fp8 QK^T / PV in the cross-attention")
+    ap.add_argument("--cpu-batch", type=int, default=0, help="0 = the workload's batch, bounded (see cpu_baseline)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=32.0,
-                    help="gradient all-reduce bucket size: ~one BERT layer (28 MB fp32) per bucket keeps the un-overlapped tail "
-                         "(layer 0 + the 94 MB word-embedding table, final only at the very end of backward) short")
-    ap.add_argument("--comm-bf16", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=100.0,
+                    help="minimum gradient bucket size in MB of fp32 gradients (the embedding tables are always a bucket of "
+                         "their own): every bucket is a fork/join of the captured graph, see DESIGN.md section 6")
+    ap.add_argument("--comm-f32", action="store_true", help="fp32 gradient buckets on the wire (default at N > 1: bf16)")
+    ap.add_argument("--comm-bf16", action="store_true", help="force bf16 buckets (already the default at N > 1)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time fwd+bwd+AdamW (reported separately)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (tests the "
                                                               "RCCL path on a single GPU)")
     args = ap.parse_args()
+    for k, v in PRESETS[args.config or "c2"].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -207,7 +241,8 @@ def main():
     arena = model._icka_arena
     if use_dist:
         from icka_amd.dp import GradReducer
-        reducer = GradReducer(arena, bucket_mb=args.bucket_mb, comm_bf16=args.comm_bf16)
+        reducer = GradReducer(arena, bucket_mb=args.bucket_mb,
+                              comm_dtype="f32" if args.comm_f32 else ("bf16" if (args.comm_bf16 or args.force_dist) else None))
         reducer.broadcast_parameters(0)
         arena.reducer = reducer
     opt = torch.optim.AdamW(model.parameters(), lr=3e-5) if args.with_optimizer else None
@@ -325,7 +360,10 @@ def main():
             traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_ws_kernel|gemm_ws2_kernel|gemm_big_group_kernel<NT|NN|TN> (128x128 / 128x96 / 256x128 tiles, bf16 MFMA, all GEMM launches of a step)",
+            roof = {"bound": "mfma",
+                    "kernel": "all GEMM launches of a step: gemm_ws_kernel / gemm_ws2_kernel (128x128, 128x96 tiles), "
+                              "gemm_w3_kernel (256x192), gemm_big_group_kernel (grouped weight gradients, 256x128), "
+                              "gemm_kernel (ragged shapes); NT / NN / TN, bf16 MFMA 16x16x32",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(abytes / launches),
@@ -337,7 +375,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+        cpu = cpu_baseline(args, fl_sample)
 
     if use_dist:
         dist.barrier()

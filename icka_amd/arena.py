@@ -23,11 +23,12 @@ ALIGN = 8
 
 
 class Slot(object):
-    __slots__ = ("name", "off", "numel", "shape", "param", "live")
+    __slots__ = ("name", "off", "numel", "shape", "param", "live", "is_table")
 
-    def __init__(self, name, off, numel, shape, param):
+    def __init__(self, name, off, numel, shape, param, is_table=False):
         self.name, self.off, self.numel, self.shape, self.param = name, off, numel, tuple(shape), param
         self.live = False   # gflat slot holds a valid (accumulating) gradient for the current cycle
+        self.is_table = is_table   # nn.Embedding table: gathered from the f32 master, never a GEMM operand -> no shadow
 
 
 class ParamArena(object):
@@ -50,8 +51,9 @@ class ParamArena(object):
         off = 0
         self.slots: Dict[int, Slot] = {}
         self.order: List[Slot] = []
+        tables = {id(m.weight) for m in root.modules() if isinstance(m, nn.Embedding)}
         for name, p in named:
-            s = Slot(name, off, p.numel(), p.shape, p)
+            s = Slot(name, off, p.numel(), p.shape, p, id(p) in tables)
             self.slots[id(p)] = s
             self.order.append(s)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
@@ -65,6 +67,17 @@ class ParamArena(object):
                 view = self.flat[s.off:s.off + s.numel].view(s.shape)
                 view.copy_(s.param.data)
                 s.param.data = view
+        # element ranges of ``flat`` that get a bf16 shadow: everything but the embedding tables (20 % of the bert-base
+        # path's parameters: the per-forward re-cast skips them); neighbouring ranges are merged across small gaps
+        self._cast_ranges: List[Tuple[int, int]] = []
+        for s in self.order:
+            if s.is_table:
+                continue
+            lo, hi = s.off, s.off + (s.numel + ALIGN - 1) // ALIGN * ALIGN
+            if self._cast_ranges and lo - self._cast_ranges[-1][1] < (1 << 16):
+                self._cast_ranges[-1] = (self._cast_ranges[-1][0], hi)
+            else:
+                self._cast_ranges.append((lo, hi))
         self._synced = None
         # "always": re-cast the bf16 shadow at every outermost forward (safe with ANY way of updating parameters);
         # "tracked": re-cast only when a parameter version counter moved, an optimizer step ran (global post-step
@@ -110,6 +123,8 @@ class ParamArena(object):
     def w(self, p: nn.Parameter) -> torch.Tensor:
         """bf16 shadow view of a parameter."""
         s = self.slots[id(p)]
+        if s.is_table:
+            raise RuntimeError("%s is an embedding table: it has no bf16 shadow (kernels gather the f32 master)" % s.name)
         return self.shadow[s.off:s.off + s.numel].view(s.shape)
 
     def w_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
@@ -153,7 +168,8 @@ class ParamArena(object):
             v += s.param._version
         if force or self.shadow_policy == "always" or v != self._synced:
             from . import kernels
-            kernels.cast_f32_to_bf16(self.flat, self.shadow)
+            for lo, hi in self._cast_ranges:
+                kernels.cast_f32_to_bf16(self.flat[lo:hi], self.shadow[lo:hi])
             self._synced = v
 
     def mark_dirty(self) -> None:
@@ -220,11 +236,18 @@ class ParamArena(object):
     # ------------------------------------------------------------------------------------------ DP buckets
     def buckets(self, bucket_elems: int) -> List[Tuple[int, int]]:
         """Contiguous [start, end) element ranges of gflat, from the END of the arena towards the start (the order
-        in which backward produces gradients), each at least ``bucket_elems`` long (last one takes the rest)."""
+        in which backward produces gradients), each at least ``bucket_elems`` long (last one takes the rest).  A run
+        of embedding tables starts a bucket of its own: their gradient is final only at the very end of backward and
+        must not hold back the reduction of the encoder layers that share its tail of the arena."""
         out = []
         end = self.total
         cur = end
+        prev_table = None
         for s in reversed(self.order):
+            if prev_table is False and s.is_table and end > cur:
+                out.append((cur, end))
+                end = cur
+            prev_table = s.is_table
             cur = s.off
             if end - cur >= bucket_elems:
                 out.append((cur, end))

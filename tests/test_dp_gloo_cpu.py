@@ -97,6 +97,49 @@ def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path):
         assert res["calibrated"]
 
 
+def _twice_worker(rank, world, port, tmp):
+    """A slot that receives TWO gradient writes per step (a module applied twice per forward): its bucket must not be
+    reduced after the first write (the late write would race with the reduction and never be averaged)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from icka_amd.dp import GradReducer
+    model = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 64))
+    arena = ParamArena(model)
+    red = GradReducer(arena, bucket_mb=64 * 65 * 4 / (1 << 20))     # one Linear per bucket
+    assert len(red.buckets) == 3
+    arena.reducer = red
+    launched_early = []
+    orig = red._launch
+    red._launch = lambda idx: (launched_early.append((idx, dict(red._seen))), orig(idx))[1]
+    shared = model[2]                                   # written twice per step, the other two once
+    for step in range(3):
+        for p in model.parameters():
+            p.grad = None
+        for layer, times in ((shared, 2), (model[1], 1), (model[0], 1)):
+            for t in range(times):
+                for p in (layer.weight, layer.bias):
+                    beta = arena.grad_beta(p)
+                    arena.g(p).mul_(beta).add_(float(rank + 1))
+                arena.flush_final()                     # end of one "block backward"
+        red.finish()
+        assert torch.allclose(arena.g(shared.weight), torch.full_like(shared.weight, 2 * 1.5)), step
+        assert torch.allclose(arena.g(model[0].weight), torch.full_like(model[0].weight, 1.5)), step
+    # after calibration the shared bucket (index 0 = end of the arena) was launched only once BOTH writes were in
+    sid = id(arena.slots[id(shared.weight)])
+    early = [seen for idx, seen in launched_early if idx == 0 and seen]
+    assert early and all(seen.get(sid) == 2 for seen in early), early
+    torch.save({"ok": True}, os.path.join(tmp, "t%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_slot_written_twice_is_reduced_after_its_last_write(tmp_path):
+    port = _free_port()
+    mp.spawn(_twice_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(os.path.join(str(tmp_path), "t%d.pt" % r))["ok"]
+
+
 def test_bucket_partition_covers_arena_in_reverse_order():
     model = MTCCMBertForMMTokenClassificationCRF(BertConfig(512, **CFG), layer_num1=1, num_labels=13)
     arena = ParamArena(model)
@@ -104,7 +147,12 @@ def test_bucket_partition_covers_arena_in_reverse_order():
     assert b[0][1] == arena.total and b[-1][0] == 0
     for (s0, e0), (s1, e1) in zip(b[:-1], b[1:]):
         assert e1 == s0 and e0 > s0
-    assert all(e - s >= 50_000 for s, e in b[:-1])
+    assert all(e - s >= 50_000 for s, e in b[:-2])
+    # the embedding tables (gradient final only at the very end of backward) are a bucket of their own
+    tables = [s for s in arena.order if s.is_table]
+    assert [s.name.split(".")[-2] for s in tables] == ["word_embeddings", "position_embeddings", "token_type_embeddings"]
+    assert b[-1] == (0, tables[-1].off + (tables[-1].numel + 7) // 8 * 8)
+    assert arena._cast_ranges == [(b[-1][1], arena.total)]      # and they are the only part without a bf16 shadow
     # fused QKV operands are physically adjacent
     sa = model.bert.encoder.layer[0].attention.self
     first, rows = arena._adjacent((sa.query.weight, sa.key.weight, sa.value.weight))
