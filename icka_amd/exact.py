@@ -211,9 +211,8 @@ def _linear_bwd_params(A: ParamArena, dy, x, ws, bs) -> None:
         colsum(dy, A.g_cat(bt), accumulate=A.grad_beta(bt) > 0)
 
 
-def _attn_fwd(A: ParamArena, att, x, kv_src, add_mask, d, Skv: int, save: bool):
-    """BertAttention / BertCrossAttention (:451-454, :633-636).  Returns (y, saved)."""
-    sa, so = att.self, att.output
+def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d, Skv: int, save: bool):
+    """BertSelfAttention / BertCoAttention (:478-506, :590-624).  Returns (ctx [M,H], saved)."""
     M, H = x.shape
     B, h, S = d.B, d.heads, d.S
     dh = H // h
@@ -232,33 +231,21 @@ def _attn_fwd(A: ParamArena, att, x, kv_src, add_mask, d, Skv: int, save: bool):
              P, Skv, (h * S * Skv, S * Skv), B, h)
     seed_a = A.next_seed() if d.p_attn > 0 else 0
     Pd = torch.empty_like(P) if d.p_attn > 0 else None
-    scale = 1.0 / math.sqrt(dh)
-    softmax_fwd(P, Pd, add_mask, B, h, S, Skv, scale, d.p_attn, seed_a)                            # (:489-500)
+    softmax_fwd(P, Pd, add_mask, B, h, S, Skv, 1.0 / math.sqrt(dh), d.p_attn, seed_a)             # (:489-500)
     Pu = P if Pd is None else Pd
     ctx = _new(x, M, H)
     gemm_raw(GEMM_NN, S, dh, Skv, Pu, Skv, (h * S * Skv, S * Skv), v, v.stride(0), (Skv * v.stride(0), dh),
              ctx, H, (S * H, dh), B, h)                                                           # (:502-505)
-    ao = gemm(GEMM_NT, ctx, _fw(A, so.dense.weight), _new(x, M, H), bias=so.dense.bias)
-    seed_h = A.next_seed() if d.p_hidden > 0 else 0
-    y, xhat, rstd = ln_fwd(ao, x, so.LayerNorm.weight, so.LayerNorm.bias, eps=d.eps, p_drop=d.p_hidden, seed=seed_h,
-                           save=save)                                                             # (:561-565)
-    saved = (qkv, kvb, P, Pd, ctx, xhat, rstd, seed_a, seed_h) if save else None
-    return y, saved
+    return ctx, ((qkv, kvb, P, Pd, seed_a) if save else None)
 
 
-def _attn_bwd(A: ParamArena, att, x, kv_src, d, Skv: int, saved, dy, need_dkv_src: bool):
-    """Returns (dx, dkv_src)."""
-    sa, so = att.self, att.output
-    qkv, kvb, P, Pd, ctx, xhat, rstd, seed_a, seed_h = saved
+def _attn_core_bwd(A: ParamArena, sa, x, kv_src, d, Skv: int, saved, dctx, dres, need_dkv_src: bool):
+    """Returns (dx, dkv_src); ``dres`` (optional, overwritten) receives the result: dx = dres + dqkv . W."""
+    qkv, kvb, P, Pd, seed_a = saved
     M, H = x.shape
     B, h, S = d.B, d.heads, d.S
     dh = H // h
     scale = 1.0 / math.sqrt(dh)
-    colsum(dy, A.g(so.LayerNorm.weight), b=xhat, accumulate=A.grad_beta(so.LayerNorm.weight) > 0)
-    colsum(dy, A.g(so.LayerNorm.bias), accumulate=A.grad_beta(so.LayerNorm.bias) > 0)
-    dres, dao = ln_bwd(dy, xhat, rstd, so.LayerNorm.weight, p_drop=d.p_hidden, seed=seed_h)
-    _linear_bwd_params(A, dao, ctx, so.dense.weight, so.dense.bias)
-    dctx = gemm(GEMM_NN, dao, _fw(A, so.dense.weight), _new(x, M, H))
     if kv_src is None:
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
         dqkv = _new(x, M, 3 * H)
@@ -280,41 +267,71 @@ def _attn_bwd(A: ParamArena, att, x, kv_src, d, Skv: int, saved, dy, need_dkv_sr
              (S * dq.stride(0), dh), B, h)
     gemm_raw(GEMM_TN, Skv, dh, S, dS, Skv, pb, q, q.stride(0), (S * q.stride(0), dh), dk, dk.stride(0),
              (Skv * dk.stride(0), dh), B, h)
+    out = dres if dres is not None else _new(x, M, H)
+    beta = 1.0 if dres is not None else 0.0
     if kv_src is None:
         wq = (sa.query.weight, sa.key.weight, sa.value.weight)
         _linear_bwd_params(A, dqkv, x, wq, (sa.query.bias, sa.key.bias, sa.value.bias))
-        dx = gemm(GEMM_NN, dqkv, _fw(A, wq), dres, beta=1.0)           # + gradient of the residual
-        return dx, None
+        return gemm(GEMM_NN, dqkv, _fw(A, wq), out, beta=beta), None           # + gradient of the residual
     _linear_bwd_params(A, dq, x, sa.query.weight, sa.query.bias)
     wkv = (sa.key.weight, sa.value.weight)
     _linear_bwd_params(A, dkv, kv_src, wkv, (sa.key.bias, sa.value.bias))
-    dx = gemm(GEMM_NN, dq, _fw(A, sa.query.weight), dres, beta=1.0)
+    dx = gemm(GEMM_NN, dq, _fw(A, sa.query.weight), out, beta=beta)
     dsrc = gemm(GEMM_NN, dkv, _fw(A, wkv), _new(x, kv_src.shape[0], H)) if need_dkv_src else None
     return dx, dsrc
 
 
+def _dense_norm_fwd(A: ParamArena, mod, h, res, d, save: bool):
+    """BertSelfOutput / BertOutput (:561-565, :532-536): LayerNorm(dropout(dense(h)) + res)."""
+    o = gemm(GEMM_NT, h, _fw(A, mod.dense.weight), _new(h, h.shape[0], mod.dense.weight.shape[0]), bias=mod.dense.bias)
+    seed_h = A.next_seed() if d.p_hidden > 0 else 0
+    y, xhat, rstd = ln_fwd(o, res, mod.LayerNorm.weight, mod.LayerNorm.bias, eps=d.eps, p_drop=d.p_hidden, seed=seed_h,
+                           save=save)
+    return y, ((xhat, rstd, seed_h) if save else None)
+
+
+def _dense_norm_bwd(A: ParamArena, mod, h, d, saved, dy):
+    """Returns (do, dres): gradients of the dense output (dropout mask applied) and of the residual input."""
+    xhat, rstd, seed_h = saved
+    ln = mod.LayerNorm
+    colsum(dy, A.g(ln.weight), b=xhat, accumulate=A.grad_beta(ln.weight) > 0)
+    colsum(dy, A.g(ln.bias), accumulate=A.grad_beta(ln.bias) > 0)
+    dres, do = ln_bwd(dy, xhat, rstd, ln.weight, p_drop=d.p_hidden, seed=seed_h)
+    _linear_bwd_params(A, do, h, mod.dense.weight, mod.dense.bias)
+    return do, dres
+
+
+def _attn_fwd(A: ParamArena, att, x, kv_src, add_mask, d, Skv: int, save: bool):
+    """BertAttention / BertCrossAttention (:451-454, :633-636).  Returns (y, saved)."""
+    ctx, s_core = _attn_core_fwd(A, att.self, x, kv_src, add_mask, d, Skv, save)
+    y, s_out = _dense_norm_fwd(A, att.output, ctx, x, d, save)
+    return y, ((ctx, s_core, s_out) if save else None)
+
+
+def _attn_bwd(A: ParamArena, att, x, kv_src, d, Skv: int, saved, dy, need_dkv_src: bool):
+    """Returns (dx, dkv_src)."""
+    ctx, s_core, s_out = saved
+    dao, dres = _dense_norm_bwd(A, att.output, ctx, d, s_out, dy)
+    # without dropout ln_bwd hands back ONE buffer as both gradients: accumulating dx into it below is safe, every
+    # reader of dao (weight gradient, dctx) is stream-ordered before that GEMM
+    dctx = gemm(GEMM_NN, dao, _fw(A, att.output.dense.weight), _new(x, x.shape[0], x.shape[1]))
+    return _attn_core_bwd(A, att.self, x, kv_src, d, Skv, s_core, dctx, dres, need_dkv_src)
+
+
 def _ffn_fwd(A: ParamArena, layer, x, d, save: bool):
     """BertIntermediate + BertOutput (:548-551, :532-536)."""
-    inter, out = layer.intermediate, layer.output
-    M, H = x.shape
-    I = inter.dense.weight.shape[0]
-    z = gemm(GEMM_NT, x, _fw(A, inter.dense.weight), _new(x, M, I), bias=inter.dense.bias)
+    inter = layer.intermediate
+    z = gemm(GEMM_NT, x, _fw(A, inter.dense.weight), _new(x, x.shape[0], inter.dense.weight.shape[0]), bias=inter.dense.bias)
     g = act_fwd(z, ACT_GELU)
-    fo = gemm(GEMM_NT, g, _fw(A, out.dense.weight), _new(x, M, H), bias=out.dense.bias)
-    seed_h = A.next_seed() if d.p_hidden > 0 else 0
-    y, xhat, rstd = ln_fwd(fo, x, out.LayerNorm.weight, out.LayerNorm.bias, eps=d.eps, p_drop=d.p_hidden, seed=seed_h,
-                           save=save)
-    return y, ((z, g, xhat, rstd, seed_h) if save else None)
+    y, s_out = _dense_norm_fwd(A, layer.output, g, x, d, save)
+    return y, ((z, g, s_out) if save else None)
 
 
 def _ffn_bwd(A: ParamArena, layer, x, d, saved, dy):
-    inter, out = layer.intermediate, layer.output
-    z, g, xhat, rstd, seed_h = saved
-    colsum(dy, A.g(out.LayerNorm.weight), b=xhat, accumulate=A.grad_beta(out.LayerNorm.weight) > 0)
-    colsum(dy, A.g(out.LayerNorm.bias), accumulate=A.grad_beta(out.LayerNorm.bias) > 0)
-    dres, dfo = ln_bwd(dy, xhat, rstd, out.LayerNorm.weight, p_drop=d.p_hidden, seed=seed_h)
-    _linear_bwd_params(A, dfo, g, out.dense.weight, out.dense.bias)
-    dg = gemm(GEMM_NN, dfo, _fw(A, out.dense.weight), torch.empty_like(z))
+    inter = layer.intermediate
+    z, g, s_out = saved
+    dfo, dres = _dense_norm_bwd(A, layer.output, g, d, s_out, dy)
+    dg = gemm(GEMM_NN, dfo, _fw(A, layer.output.dense.weight), torch.empty_like(z))
     dz = act_bwd(dg, z, ACT_GELU)
     _linear_bwd_params(A, dz, x, inter.dense.weight, inter.dense.bias)
     return gemm(GEMM_NN, dz, _fw(A, inter.dense.weight), dres, beta=1.0)
@@ -356,9 +373,10 @@ class EmbeddingsFn(torch.autograd.Function):
         colsum(dy, A.g(ln.bias), accumulate=A.grad_beta(ln.bias) > 0)
         dpre, _ = ln_bwd(dy, xhat, rstd, ln.weight)
         tables = (mod.word_embeddings.weight, mod.position_embeddings.weight, mod.token_type_embeddings.weight)
+        from . import kernels as K
         for t in tables:     # atomically accumulated: a fresh gradient starts from zero
             if A.grad_beta(t) == 0.0:
-                A.g(t).zero_()
+                K.zero_(A.g(t).view(-1))
         B, S = ids.shape
         pad = mod.word_embeddings.padding_idx
         check(_lib.load().icka_x_embed_scatter(dpre.data_ptr(), ids.data_ptr(), None if tt is None else tt.data_ptr(),
@@ -414,6 +432,71 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.s_att = ctx.s_ffn = None
         A.flush_final()
         return None, ds1, ds2, None, None, None, None
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """BertSelfAttention.forward / BertCoAttention.forward called on their own (:478-506, :590-624)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, kv_src, sa, A: ParamArena, add_mask, d, Skv: int):
+        save = any(ctx.needs_input_grad)
+        c, saved = _attn_core_fwd(A, sa, x, kv_src, add_mask, d, Skv, save)
+        ctx.sa, ctx.A, ctx.d, ctx.Skv, ctx.saved = sa, A, d, Skv, saved
+        ctx.need_kv = kv_src is not None and kv_src.requires_grad
+        ctx.save_for_backward(x, kv_src)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        x, kv_src = ctx.saved_tensors
+        dx, dsrc = _attn_core_bwd(ctx.A, ctx.sa, x, kv_src, ctx.d, ctx.Skv, ctx.saved, _cf(dc), None, ctx.need_kv)
+        ctx.saved = None
+        ctx.A.flush_final()
+        return None, dx, dsrc, None, None, None, None, None
+
+
+class DenseResidualNormFn(torch.autograd.Function):
+    """BertSelfOutput.forward / BertOutput.forward (hidden_states, input_tensor) (:561-565, :532-536)."""
+
+    @staticmethod
+    def forward(ctx, anchor, h, res, mod, A: ParamArena, d):
+        save = any(ctx.needs_input_grad)
+        y, saved = _dense_norm_fwd(A, mod, h, res, d, save)
+        ctx.mod, ctx.A, ctx.d, ctx.saved = mod, A, d, saved
+        ctx.save_for_backward(h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        mod, A = ctx.mod, ctx.A
+        do, dres = _dense_norm_bwd(A, mod, h, ctx.d, ctx.saved, _cf(dy))
+        dh = gemm(GEMM_NN, do, _fw(A, mod.dense.weight), torch.empty_like(h))
+        ctx.saved = None
+        A.flush_final()
+        return None, dh, dres, None, None, None
+
+
+class IntermediateFn(torch.autograd.Function):
+    """BertIntermediate.forward (:548-551): gelu(dense(hidden_states))."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, inter, A: ParamArena):
+        z = gemm(GEMM_NT, x, _fw(A, inter.dense.weight), _new(x, x.shape[0], inter.dense.weight.shape[0]),
+                 bias=inter.dense.bias)
+        ctx.inter, ctx.A = inter, A
+        ctx.save_for_backward(x, z)
+        return act_fwd(z, ACT_GELU)
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, z = ctx.saved_tensors
+        inter, A = ctx.inter, ctx.A
+        dz = act_bwd(dg, z, ACT_GELU)
+        _linear_bwd_params(A, dz, x, inter.dense.weight, inter.dense.bias)
+        dx = gemm(GEMM_NN, dz, _fw(A, inter.dense.weight), torch.empty_like(x))
+        A.flush_final()
+        return None, dx, None, None
 
 
 class LinearFn(torch.autograd.Function):

@@ -347,6 +347,16 @@ def tanh_bwd(dy, y, dx):
     return dx
 
 
+def dgelu(dg, z, dz):
+    """dz = dg * gelu'(z), contiguous bf16."""
+    for n, t in (("dg", dg), ("z", z), ("dz", dz)):
+        _dev(t, n)
+        if t.dtype != BF16 or not t.is_contiguous() or t.numel() != z.numel():
+            raise ValueError("%s must be contiguous bf16 with %d elements" % (n, z.numel()))
+    check(_lib.load().icka_dgelu_bf16(dg.data_ptr(), z.data_ptr(), dz.data_ptr(), z.numel(), _stream()), "icka_dgelu_bf16")
+    return dz
+
+
 # ------------------------------------------------------------------------------------------------- attention
 def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False):
     """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection).
@@ -569,6 +579,23 @@ def token_ce(logits, labels, mask, loss_sum, count, dlogits):
     check(_lib.load().icka_token_ce(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
                                     loss_sum.data_ptr(), count.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
                                     M, Cn, _stream()), "icka_token_ce")
+
+
+def token_ce_fused(logits, labels, mask, stats, dlogits):
+    """One-launch token CE: stats f32[3] <- (loss sum, #valid, mean loss); dlogits bf16 [M, ldd>=C] unscaled."""
+    M, Cn = logits.shape
+    check(_lib.load().icka_token_ce_fused(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
+                                          stats.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), M, Cn, _stream()),
+          "icka_token_ce_fused")
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """Clear a contiguous f32 device tensor with the library's fill kernel."""
+    _dev(t, "t")
+    if t.dtype != F32 or not t.is_contiguous():
+        raise TypeError("zero_: contiguous f32 tensor")
+    check(_lib.load().icka_zero_f32(t.data_ptr(), t.numel(), _stream()), "icka_zero_f32")
+    return t
 
 
 def scale_by_ratio(x, y, num=None, den=None):

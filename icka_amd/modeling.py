@@ -200,14 +200,17 @@ class BertEmbeddings(_IckaModule):
         return _with_twin(y, yf, (B, S, -1))
 
 
-class BertSelfAttention(nn.Module):
-    """Parameter container with the reference's names (:456-506); computed inside BertLayer's fused kernels."""
+class BertSelfAttention(_IckaModule):
+    """forward(hidden_states, attention_mask) -> context_layer [B,S,H] (:456-506).  Inside BertLayer the same kernels
+    run with the block's gradient fan-ins fused; called on its own (as BertAttention.forward does, :451-454) the
+    projections + fused attention run as one autograd node."""
 
     def __init__(self, config):
         super().__init__()
         if config.hidden_size % config.num_attention_heads != 0:
             raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
                              % (config.hidden_size, config.num_attention_heads))
+        self.config = config
         self.num_attention_heads = config.num_attention_heads
         self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
         self.all_head_size = self.num_attention_heads * self.attention_head_size
@@ -222,48 +225,105 @@ class BertSelfAttention(nn.Module):
                 ("value.weight", self.value.weight), ("query.bias", self.query.bias),
                 ("key.bias", self.key.bias), ("value.bias", self.value.bias)]
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("BertSelfAttention/BertCoAttention run fused inside BertLayer / "
-                                  "BertCrossAttentionLayer (icka_attn_* kernels); call the enclosing layer")
+    def _context(self, q_states, kv_states, attention_mask):
+        B, S, H = q_states.shape
+        A = self._arena()
+        ex = _is_exact(self)
+        x = _hidden2d(q_states, "hidden_states", ex)
+        kv = None if kv_states is None else _hidden2d(kv_states, "s2_hidden_states", ex)
+        T = S if kv_states is None else kv_states.shape[1]
+        d = _dims(self.config, B, S, T if kv_states is not None else 0, self.training, ex)
+        mask = _add_mask2d(attention_mask, B, T)
+        fn = X.AttnCoreFn if ex else ops.AttnCoreFn
+        return fn.apply(A.anchor, x, kv, self, A, mask, d, T).view(B, S, H)
+
+    def forward(self, hidden_states, attention_mask):
+        return self._context(hidden_states, None, attention_mask)
 
 
 class BertCoAttention(BertSelfAttention):
-    """Q from s1, K/V from s2 (:568-624).  ``fp8_scores = True`` (BASELINE config c5, not a reference feature) computes
-    QK^T and PV of this co-attention on the fp8 matrix cores; requires s1/s2 lengths <= 128."""
+    """forward(s1_hidden_states, s2_hidden_states, s2_attention_mask): Q from s1, K/V from s2 (:568-624).
+    ``fp8_scores = True`` (BASELINE config c5, not a reference feature) computes QK^T and PV of this co-attention on the
+    fp8 matrix cores; requires s1/s2 lengths <= 128."""
     fp8_scores = False
 
+    def forward(self, s1_hidden_states, s2_hidden_states, s2_attention_mask):
+        return self._context(s1_hidden_states, s2_hidden_states, s2_attention_mask)
 
-class BertSelfOutput(nn.Module):
+
+class _DenseResidualNorm(_IckaModule):
+    """LayerNorm(dropout(dense(hidden_states)) + input_tensor): BertSelfOutput (:554-565) and BertOutput (:525-536)."""
+
+    def forward(self, hidden_states, input_tensor):
+        shape = input_tensor.shape
+        A = self._arena()
+        ex = _is_exact(self)
+        h = _hidden2d(hidden_states, "hidden_states", ex)
+        res = _hidden2d(input_tensor, "input_tensor", ex)
+        B = h.shape[0]
+        d = _dims(self.config, B, 1, 0, self.training, True)     # no attention here: head size is irrelevant
+        if ex:
+            return X.DenseResidualNormFn.apply(A.anchor, h, res, self, A, d).view(shape)
+        y, yf = ops.DenseResidualNormFn.apply(A.anchor, h, res, _twin(input_tensor), self, A, d)
+        return _with_twin(y, yf, shape)
+
+
+class BertSelfOutput(_DenseResidualNorm):
     def __init__(self, config):
         super().__init__()
+        self.config = config
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
         self.LayerNorm = BertLayerNorm(config.hidden_size, eps=getattr(config, "layer_norm_eps", 1e-12))
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
 
-class BertAttention(nn.Module):
+class BertAttention(_IckaModule):
+    """forward(input_tensor, attention_mask) = output(self(input_tensor, attention_mask), input_tensor) (:445-454)."""
+
     def __init__(self, config):
         super().__init__()
         self.self = BertSelfAttention(config)
         self.output = BertSelfOutput(config)
 
+    def forward(self, input_tensor, attention_mask):
+        self_output = self.self(input_tensor, attention_mask)
+        return self.output(self_output, input_tensor)
 
-class BertCrossAttention(nn.Module):
+
+class BertCrossAttention(_IckaModule):
+    """forward(s1_input_tensor, s2_input_tensor, s2_attention_mask) (:627-636)."""
+
     def __init__(self, config):
         super().__init__()
         self.self = BertCoAttention(config)
         self.output = BertSelfOutput(config)
 
+    def forward(self, s1_input_tensor, s2_input_tensor, s2_attention_mask):
+        s1_cross_output = self.self(s1_input_tensor, s2_input_tensor, s2_attention_mask)
+        return self.output(s1_cross_output, s1_input_tensor)
 
-class BertIntermediate(nn.Module):
+
+class BertIntermediate(_IckaModule):
+    """forward(hidden_states) = gelu(dense(hidden_states)) (:539-551)."""
+
     def __init__(self, config):
         super().__init__()
+        self.config = config
         self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
 
+    def forward(self, hidden_states):
+        shape = hidden_states.shape
+        A = self._arena()
+        ex = _is_exact(self)
+        x = _hidden2d(hidden_states, "hidden_states", ex)
+        fn = X.IntermediateFn if ex else ops.IntermediateFn
+        return fn.apply(A.anchor, x, self, A).view(*shape[:-1], -1)
 
-class BertOutput(nn.Module):
+
+class BertOutput(_DenseResidualNorm):
     def __init__(self, config):
         super().__init__()
+        self.config = config
         self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
         self.LayerNorm = BertLayerNorm(config.hidden_size, eps=getattr(config, "layer_norm_eps", 1e-12))
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
@@ -569,7 +629,13 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     img_mask = K.additive_mask(added_attention_mask if added_attention_mask.dtype == torch.int64
                                else added_attention_mask.long(), R, torch.empty(B, R, dtype=F32, device=dev))
     # ---- cross encoder (:1359-1361)
-    cross, crossf = seq, seqf
+    # the text stream feeds both the cross encoder and the head: its two gradients are summed by our bf16 add kernel
+    # (FanOutFn) instead of autograd's own accumulation
+    if torch.is_grad_enabled() and seq.requires_grad:
+        cross, seq = ops.FanOutFn.apply(seq, 2)
+    else:
+        cross = seq
+    crossf = seqf
     d = _dims(cfg, B, S, R, self.training)
     for layer in self.txt2img_attention.layer:
         cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
@@ -664,7 +730,12 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
                 crs = X.CrsFn.apply(A.anchor, seq, cross, self.crs_classifier, A, B, S)
                 cross = X.SampleGateFn.apply(cross, None, crs, 1, B, S)
             else:
-                crs = ops.CrsFn.apply(A.anchor, seq, cross, self.crs_classifier, A, B, S)
+                if torch.is_grad_enabled() and seq.requires_grad:
+                    seq, seq_c = ops.FanOutFn.apply(seq, 2)
+                    cross, cross_c = ops.FanOutFn.apply(cross, 2)
+                else:
+                    seq_c, cross_c = seq, cross
+                crs = ops.CrsFn.apply(A.anchor, seq_c, cross_c, self.crs_classifier, A, B, S)
                 cross = ops.SampleGateFn.apply(cross, None, crs, 1, B, S)
         # ---- gate + classifier (:1363-1371)
         if _is_exact(self):

@@ -82,14 +82,15 @@ def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres
 
 
 # =============================================================================================== sub-blocks
-def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool):
-    """BertAttention / BertCrossAttention: projections -> fused attention -> out-proj -> bias+dropout+residual+LN.
-    ``att`` is the reference-named module (``.self.{query,key,value}``, ``.output.{dense,LayerNorm}``).
-    x is the bf16 MFMA operand; xres its f32 twin used as the residual (None -> x).  Returns (y bf16, y f32, saved)."""
-    sa, so = att.self, att.output
+# Each reference sub-module is one forward / backward pair of launch sequences; the layer Functions (BertLayerFn,
+# CrossLayerFn) chain them with the gradient fan-ins fused into GEMM epilogues, the sub-module Functions further down
+# (AttnCoreFn, DenseResidualNormFn, IntermediateFn) expose the same pairs one by one for callers that compose
+# BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput themselves (as BertAttention.forward :451-454 does).
+def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, save: bool):
+    """BertSelfAttention / BertCoAttention (:478-506, :590-624): fused projection GEMM -> fused attention kernel.
+    Returns (ctx bf16 [M,H], saved)."""
     M, H = x.shape
-    self_attn = kv_src is None
-    if self_attn:
+    if kv_src is None:
         qkv = _empty(x, M, 3 * H)
         K.gemm(K.GEMM_NT, x, A.w_cat((sa.query.weight, sa.key.weight, sa.value.weight)), qkv,
                bias=A.f_cat((sa.query.bias, sa.key.bias, sa.value.bias)))
@@ -106,35 +107,17 @@ def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv:
     lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
     seed_a = A.next_seed() if d.p_attn > 0 else 0
     # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
-    fp8 = (not self_attn) and bool(getattr(sa, "fp8_scores", False))
+    fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
     K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8)
-    ao = _empty(x, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra bf16 rounding)
-    K.gemm(K.GEMM_NT, ctx, A.w(so.dense.weight), ao)
-    y = _empty(x, M, H)
-    yf = _empty(x, M, H, dtype=F32)
-    xhat = _empty(x, M, H) if save else None
-    rstd = _empty(x, M, dtype=F32) if save else None
-    seed_h = A.next_seed() if d.p_hidden > 0 else 0
-    K.ln_fwd(ao, so.dense.bias, x if xres is None else xres, so.LayerNorm.weight, so.LayerNorm.bias, y, y_f32=yf,
-             xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed_h)
-    saved = (qkv, kvbuf, ctx, lse, xhat, rstd, seed_a, seed_h) if save else None
-    return y, yf, saved
+    return ctx, ((qkv, kvbuf, lse, seed_a) if save else None)
 
 
-def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, saved, dy, dy2, need_dkv_src: bool):
-    """Returns (dx, dkv_src).  dy2 is an optional second gradient of the block output (fused into the LN backward)."""
-    sa, so = att.self, att.output
-    qkv, kvbuf, ctx, lse, xhat, rstd, seed_a, seed_h = saved
+def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, saved, ctx, dctx, dres, need_dkv_src: bool):
+    """Returns (dx, dkv_src); ``dres`` (optional) is added to dx in the last GEMM's epilogue (residual fan-in)."""
+    qkv, kvbuf, lse, seed_a = saved
     M, H = x.shape
-    dres = _empty(x, M, H)
-    dao = _empty(x, M, H)
-    _ln_bwd_deferred(A, "ln_attn", so.LayerNorm, dy, xhat, rstd, dy2=dy2, dres=dres, dx=dao, p_drop=d.p_hidden,
-                     seed=seed_h)
-    # the dense bias gradient (column sums of dao) rides on the weight-gradient GEMM
-    _wgrad(A, dao, ctx, A.g(so.dense.weight), A.grad_beta(so.dense.weight), bias=so.dense.bias)
-    dctx = _empty(x, M, H)
-    K.gemm(K.GEMM_NN, dao, A.w(so.dense.weight), dctx)
     delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
+    epi = dict(epilogue=K.EPI_ADD, aux=dres) if dres is not None else {}
     if kv_src is None:
         dqkv = _empty(x, M, 3 * H)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
@@ -144,7 +127,7 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
         bg = (sa.query.bias, sa.key.bias, sa.value.bias)
         _wgrad(A, dqkv, x, A.g_cat(wg), A.grad_beta(wg), bias=bg)
         dx = _empty(x, M, H)
-        K.gemm(K.GEMM_NN, dqkv, A.w_cat(wg), dx, epilogue=K.EPI_ADD, aux=dres)
+        K.gemm(K.GEMM_NN, dqkv, A.w_cat(wg), dx, **epi)
         return dx, None
     dq = _empty(x, M, H)
     dkv = _empty(x, kv_src.shape[0], 2 * H)
@@ -155,7 +138,7 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     bg = (sa.key.bias, sa.value.bias)
     _wgrad(A, dkv, kv_src, A.g_cat(wg), A.grad_beta(wg), bias=bg)
     dx = _empty(x, M, H)
-    K.gemm(K.GEMM_NN, dq, A.w(sa.query.weight), dx, epilogue=K.EPI_ADD, aux=dres)
+    K.gemm(K.GEMM_NN, dq, A.w(sa.query.weight), dx, **epi)
     dsrc = None
     if need_dkv_src:
         dsrc = _empty(x, kv_src.shape[0], H)
@@ -163,43 +146,90 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     return dx, dsrc
 
 
-def _ffn_block_fwd(A: ParamArena, layer, x, xres, d: Dims, save: bool):
-    """BertIntermediate + BertOutput.  Returns (y bf16, y f32, saved)."""
-    inter, out = layer.intermediate, layer.output
-    M, H = x.shape
+def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool):
+    """BertSelfOutput / BertOutput (:561-565, :532-536): LayerNorm(dropout(dense(h)) + res).  ``res`` is the residual
+    input, bf16 or its f32 twin.  Returns (y bf16, y f32, saved)."""
+    M = h.shape[0]
+    H = mod.dense.weight.shape[0]
+    o = _empty(h, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra bf16 rounding)
+    K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
+    y = _empty(h, M, H)
+    yf = _empty(h, M, H, dtype=F32)
+    xhat = _empty(h, M, H) if save else None
+    rstd = _empty(h, M, dtype=F32) if save else None
+    seed_h = A.next_seed() if d.p_hidden > 0 else 0
+    K.ln_fwd(o, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, y_f32=yf, xhat=xhat, rstd=rstd,
+             eps=d.eps, p_drop=d.p_hidden, seed=seed_h)
+    return y, yf, ((xhat, rstd, seed_h) if save else None)
+
+
+def _dense_norm_bwd(A: ParamArena, tag: str, mod, h, d: Dims, saved, dy, dy2):
+    """Returns (do, dres): gradient of the dense OUTPUT (dropout mask applied; the caller turns it into the gradient of
+    ``h`` with the epilogue it wants) and of the residual input.  Queues dW / db (_wgrad) and the LayerNorm parameter
+    reduction; the caller flushes."""
+    xhat, rstd, seed_h = saved
+    M, H = xhat.shape
+    dres = _empty(h, M, H)
+    do = _empty(h, M, H)
+    _ln_bwd_deferred(A, tag, mod.LayerNorm, dy, xhat, rstd, dy2=dy2, dres=dres, dx=do, p_drop=d.p_hidden, seed=seed_h)
+    # the dense bias gradient (column sums of do) rides on the weight-gradient GEMM
+    _wgrad(A, do, h, A.g(mod.dense.weight), A.grad_beta(mod.dense.weight), bias=mod.dense.bias)
+    return do, dres
+
+
+def _inter_fwd(A: ParamArena, inter, x):
+    """BertIntermediate (:548-551): gelu(dense(x)); the pre-activation z is the GEMM's second output."""
+    M = x.shape[0]
     I = inter.dense.weight.shape[0]
     z = _empty(x, M, I)
     g = _empty(x, M, I)
     K.gemm(K.GEMM_NT, x, A.w(inter.dense.weight), g, bias=inter.dense.bias, epilogue=K.EPI_GELU, out2=z)
-    fo = _empty(x, M, H, dtype=F32)
-    K.gemm(K.GEMM_NT, g, A.w(out.dense.weight), fo)
-    y = _empty(x, M, H)
-    yf = _empty(x, M, H, dtype=F32)
-    xhat = _empty(x, M, H) if save else None
-    rstd = _empty(x, M, dtype=F32) if save else None
-    seed_h = A.next_seed() if d.p_hidden > 0 else 0
-    K.ln_fwd(fo, out.dense.bias, x if xres is None else xres, out.LayerNorm.weight, out.LayerNorm.bias, y, y_f32=yf,
-             xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed_h)
-    return y, yf, ((z, g, xhat, rstd, seed_h) if save else None)
+    return g, z
+
+
+def _inter_bwd(A: ParamArena, inter, x, dz, dres):
+    """dz = gradient of the pre-activation.  Returns dx (+ dres when given)."""
+    _wgrad(A, dz, x, A.g(inter.dense.weight), A.grad_beta(inter.dense.weight), bias=inter.dense.bias)
+    dx = _empty(x, x.shape[0], x.shape[1])
+    if dres is not None:
+        K.gemm(K.GEMM_NN, dz, A.w(inter.dense.weight), dx, epilogue=K.EPI_ADD, aux=dres)
+    else:
+        K.gemm(K.GEMM_NN, dz, A.w(inter.dense.weight), dx)
+    return dx
+
+
+def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool):
+    """BertAttention / BertCrossAttention: projections -> fused attention -> out-proj -> bias+dropout+residual+LN.
+    ``att`` is the reference-named module (``.self.{query,key,value}``, ``.output.{dense,LayerNorm}``).
+    x is the bf16 MFMA operand; xres its f32 twin used as the residual (None -> x).  Returns (y bf16, y f32, saved)."""
+    ctx, s_core = _attn_core_fwd(A, att.self, x, kv_src, add_mask, d, Skv, save)
+    y, yf, s_out = _dense_norm_fwd(A, att.output, ctx, x if xres is None else xres, d, save)
+    return y, yf, ((ctx, s_core, s_out) if save else None)
+
+
+def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, saved, dy, dy2, need_dkv_src: bool):
+    """Returns (dx, dkv_src).  dy2 is an optional second gradient of the block output (fused into the LN backward)."""
+    ctx, s_core, s_out = saved
+    dao, dres = _dense_norm_bwd(A, "ln_attn", att.output, ctx, d, s_out, dy, dy2)
+    dctx = _empty(x, x.shape[0], x.shape[1])
+    K.gemm(K.GEMM_NN, dao, A.w(att.output.dense.weight), dctx)
+    return _attn_core_bwd(A, att.self, x, kv_src, add_mask, d, Skv, s_core, ctx, dctx, dres, need_dkv_src)
+
+
+def _ffn_block_fwd(A: ParamArena, layer, x, xres, d: Dims, save: bool):
+    """BertIntermediate + BertOutput.  Returns (y bf16, y f32, saved)."""
+    g, z = _inter_fwd(A, layer.intermediate, x)
+    y, yf, s_out = _dense_norm_fwd(A, layer.output, g, x if xres is None else xres, d, save)
+    return y, yf, ((z, g, s_out) if save else None)
 
 
 def _ffn_block_bwd(A: ParamArena, layer, x, d: Dims, saved, dy, dy2=None):
-    """Returns (dx_ffn, dres): gradient through the dense path (dz @ W1) is returned WITH dres already added."""
-    inter, out = layer.intermediate, layer.output
-    z, g, xhat, rstd, seed_h = saved
-    M, H = x.shape
-    I = z.shape[1]
-    dres = _empty(x, M, H)
-    dfo = _empty(x, M, H)
-    _ln_bwd_deferred(A, "ln_ffn", out.LayerNorm, dy, xhat, rstd, dy2=dy2, dres=dres, dx=dfo, p_drop=d.p_hidden,
-                     seed=seed_h)
-    _wgrad(A, dfo, g, A.g(out.dense.weight), A.grad_beta(out.dense.weight), bias=out.dense.bias)
-    dz = _empty(x, M, I)
-    K.gemm(K.GEMM_NN, dfo, A.w(out.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)
-    _wgrad(A, dz, x, A.g(inter.dense.weight), A.grad_beta(inter.dense.weight), bias=inter.dense.bias)
-    dx = _empty(x, M, H)
-    K.gemm(K.GEMM_NN, dz, A.w(inter.dense.weight), dx, epilogue=K.EPI_ADD, aux=dres)
-    return dx
+    """Returns the gradient of the block input: through the dense path (dz @ W1) WITH the residual gradient added."""
+    z, g, s_out = saved
+    dfo, dres = _dense_norm_bwd(A, "ln_ffn", layer.output, g, d, s_out, dy, dy2)
+    dz = _empty(x, z.shape[0], z.shape[1])
+    K.gemm(K.GEMM_NN, dfo, A.w(layer.output.dense.weight), dz, epilogue=K.EPI_DGELU, aux=z)
+    return _inter_bwd(A, layer.intermediate, x, dz, dres)
 
 
 # =============================================================================================== Functions
@@ -233,8 +263,7 @@ class EmbeddingsFn(torch.autograd.Function):
         ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(d.H))
         tables = (mod.word_embeddings.weight, mod.position_embeddings.weight)
         if A.grad_beta(tables) == 0.0:   # atomically accumulated tables: fresh gradient starts from zero
-            A.g(tables[0]).zero_()
-            A.g(tables[1]).zero_()
+            K.zero_(A.g_cat(tables).view(-1))
         small = (mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
         acc = A.grad_beta(small) > 0
         K.embed_bwd(dy, ids, tt, xhat, rstd, mod.LayerNorm.weight, A.g(tables[0]), A.g(tables[1]), A.g(small[0]),
@@ -294,6 +323,78 @@ class CrossLayerFn(torch.autograd.Function):
         _flush_wgrad(A)
         A.flush_final()
         return None, ds1, None, ds2, None, None, None, None
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """BertSelfAttention.forward(hidden_states, attention_mask) (:478-506) / BertCoAttention.forward(s1, s2, s2_mask)
+    (:590-624) called on its own: projections + fused attention -> context layer [M,H]."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, kv_src, sa, A: ParamArena, add_mask, d: Dims, Skv: int):
+        save = any(ctx.needs_input_grad)
+        c, saved = _attn_core_fwd(A, sa, x, kv_src, add_mask, d, Skv, save)
+        ctx.sa, ctx.A, ctx.d, ctx.Skv, ctx.saved = sa, A, d, Skv, saved
+        ctx.need_kv = kv_src is not None and kv_src.requires_grad
+        ctx.save_for_backward(x, kv_src, add_mask, c)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        x, kv_src, add_mask, c = ctx.saved_tensors
+        A = ctx.A
+        dx, dsrc = _attn_core_bwd(A, ctx.sa, x, kv_src, add_mask, ctx.d, ctx.Skv, ctx.saved, c, _c(dc), None, ctx.need_kv)
+        ctx.saved = None
+        _flush_wgrad(A)
+        A.flush_final()
+        return None, dx, dsrc, None, None, None, None, None
+
+
+class DenseResidualNormFn(torch.autograd.Function):
+    """BertSelfOutput.forward / BertOutput.forward (hidden_states, input_tensor) (:561-565, :532-536):
+    LayerNorm(dropout(dense(hidden_states)) + input_tensor).  ``resf`` is the f32 twin of the residual if it has one."""
+
+    @staticmethod
+    def forward(ctx, anchor, h, res, resf, mod, A: ParamArena, d: Dims):
+        save = any(ctx.needs_input_grad)
+        y, yf, saved = _dense_norm_fwd(A, mod, h, res if resf is None else resf, d, save)
+        ctx.mod, ctx.A, ctx.d, ctx.saved = mod, A, d, saved
+        ctx.save_for_backward(h)
+        ctx.mark_non_differentiable(yf)
+        ctx.set_materialize_grads(False)
+        return y, yf
+
+    @staticmethod
+    def backward(ctx, dy, _dyf=None):
+        (h,) = ctx.saved_tensors
+        mod, A = ctx.mod, ctx.A
+        do, dres = _dense_norm_bwd(A, "ln_sub", mod, h, ctx.d, ctx.saved, _c(dy), None)
+        dh = torch.empty_like(h)
+        K.gemm(K.GEMM_NN, do, A.w(mod.dense.weight), dh)
+        ctx.saved = None
+        _flush_wgrad(A)
+        A.flush_final()
+        return None, dh, dres, None, None, None, None
+
+
+class IntermediateFn(torch.autograd.Function):
+    """BertIntermediate.forward (:548-551): gelu(dense(hidden_states))."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, inter, A: ParamArena):
+        g, z = _inter_fwd(A, inter, x)
+        ctx.inter, ctx.A = inter, A
+        ctx.save_for_backward(x, z)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, z = ctx.saved_tensors
+        A = ctx.A
+        dz = K.dgelu(_c(dg), z, torch.empty_like(z))
+        dx = _inter_bwd(A, ctx.inter, x, dz, None)
+        _flush_wgrad(A)
+        A.flush_final()
+        return None, dx, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -640,8 +741,7 @@ class PromptEmbeddingsFn(torch.autograd.Function):
         ws = A.workspace("embp", S * K._lib.load().icka_ln_slab_slots() * d.H)
         tables = (mod.word_embeddings.weight, mod.position_embeddings.weight)
         if A.grad_beta(tables) == 0.0:
-            A.g(tables[0]).zero_()
-            A.g(tables[1]).zero_()
+            K.zero_(A.g_cat(tables).view(-1))
         small = (mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
         acc = A.grad_beta(small) > 0
         dprompt = torch.empty(ctx.pshape, dtype=BF16, device=dy.device)
@@ -660,10 +760,9 @@ class TokenCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, mask):
         M, C = logits.shape
-        stats = torch.zeros(3, dtype=F32, device=logits.device)
+        stats = torch.empty(3, dtype=F32, device=logits.device)
         dl = torch.empty(M, (C + 7) // 8 * 8, dtype=BF16, device=logits.device)
-        K.token_ce(logits, labels.reshape(-1), mask.reshape(-1), stats[0:1], stats[1:2], dl)
-        K.scalar_ratio(stats[2:3], stats[0:1], stats[1:2])
+        K.token_ce_fused(logits, labels.reshape(-1), mask.reshape(-1), stats, dl)   # sum, count, mean: one launch
         ctx.C = C
         ctx.save_for_backward(dl, stats)
         return stats[2:3].view(())

@@ -265,6 +265,9 @@ int icka_crs_bwd(const float* dcrs, const void* seq, int64_t lds, const void* cr
                  int32_t accumulate, void* stream);
 /* c = a + b (bf16, contiguous n elements; gradient fan-in). */
 int icka_add_bf16(const void* a, const void* b, void* c, int64_t n, void* stream);
+/* dz = dg * gelu'(z), contiguous bf16 (16-byte aligned): backward of BertIntermediate's erf-GELU (:548-551) when the
+ * sub-module is called on its own; inside a layer it is the ICKA_EPI_DGELU epilogue. */
+int icka_dgelu_bf16(const void* dg, const void* z, void* dz, int64_t n, void* stream);
 /* dx = dy * (1 - y*y) (bf16, contiguous n elements): backward of the Tanh inside the prompt mapping networks
  * (Cross_Modal_Interaction_Module.py:914-928: Dropout, Linear, Tanh, Dropout, Linear). */
 int icka_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, void* stream);
@@ -276,6 +279,12 @@ int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const 
 /* y = x * num[0] / max(den[0], 1) for bf16 [n] with DEVICE scalars (NULL = 1): applies dloss / #valid to the
  * logit gradients without a host sync.  y may alias x. */
 int icka_scale_by_ratio(const void* x, void* y, const float* num, const float* den, int64_t n, void* stream);
+/* The same loss in ONE launch without pre-zeroed accumulators: stats f32[3] = {sum of token losses, number of valid
+ * tokens, mean loss}; dlogits as above.  One 1024-thread block, fixed summation order (bitwise reproducible). */
+int icka_token_ce_fused(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* stats,
+                        void* dlogits, int64_t ldd, int32_t M, int32_t C, void* stream);
+/* p[0..n) = 0 (16-byte aligned p): clears the atomically accumulated embedding-table gradients. */
+int icka_zero_f32(float* p, int64_t n, void* stream);
 /* out[0] = num[0] / max(den[0], 1)   (mean loss from the two accumulators of icka_token_ce). */
 int icka_scalar_ratio(float* out, const float* num, const float* den, void* stream);
 /* ---------------------------------------------------------------------------------------------------------------

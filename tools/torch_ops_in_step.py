@@ -22,5 +22,5 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
     model.zero_grad(); step(); torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and e.key not in ("aten::empty","aten::view","aten::as_strided","aten::empty_like","aten::empty_strided","aten::_unsafe_view","aten::reshape","aten::select","aten::slice","aten::t","aten::transpose","aten::detach","aten::alias","aten::unsqueeze","aten::expand","aten::squeeze","aten::stride","aten::is_same_size","aten::result_type","aten::to","aten::item","aten::_local_scalar_dense","aten::lift_fresh","aten::view_as")]
 for e in sorted(rows, key=lambda e: -e.count)[:40]:
-    st = [s for s in e.stack if "icka_amd" in s or "bench" in s or "prof_ops" in s][:2]
-    print(e.key, e.count, " | ".join(s.split("/")[-1][:70] for s in st))
+    st = [s for s in e.stack if "icka_amd" in s or "bench" in s or "prof_ops" in s][:2] or list(e.stack)[:4]
+    print(e.key, e.count, " | ".join(s.split("/")[-1][:90] for s in st))
