@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void token_ce_kernel(const float* __restrict__
 __global__ __launch_bounds__(1024) void token_ce_fused_kernel(const float* __restrict__ logits, int64_t ld,
                                                               const int64_t* __restrict__ labels,
                                                               const int64_t* __restrict__ mask, float* __restrict__ stats,
-                                                              bf16_t* __restrict__ dl, int64_t ldd, int M, int C) {
+                                                              void* __restrict__ dl_, int64_t ldd, int dl_f32, int M, int C) {
     __shared__ float red[2][16];
     float loss = 0.f, cnt = 0.f;
     for (int row = threadIdx.x; row < M; row += 1024) {
@@ -268,11 +268,11 @@ __global__ __launch_bounds__(1024) void token_ce_fused_kernel(const float* __res
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
         const float lse = mx + logf(se);
-        bf16_t* d = dl + (int64_t)row * ldd;
         for (int c = 0; c < (int)ldd; ++c) {
             float gval = 0.f;
             if (valid && c < C) gval = expf(p[c] - lse) - (c == (int)y ? 1.f : 0.f);
-            d[c] = f2bf(gval);
+            if (dl_f32) reinterpret_cast<float*>(dl_)[(int64_t)row * ldd + c] = gval;
+            else reinterpret_cast<bf16_t*>(dl_)[(int64_t)row * ldd + c] = f2bf(gval);
         }
         if (valid && y >= 0 && y < C) { loss += lse - p[y]; cnt += 1.f; }
     }
@@ -460,11 +460,11 @@ extern "C" int icka_token_ce(const float* logits, int64_t ld, const int64_t* lab
     return 0;
 }
 extern "C" int icka_token_ce_fused(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* stats,
-                                   void* dlogits, int64_t ldd, int32_t M, int32_t C, void* stream) {
+                                   void* dlogits, int64_t ldd, int32_t dl_is_f32, int32_t M, int32_t C, void* stream) {
     if (!logits || !labels || !mask || !stats || !dlogits) return ICKA_E_ARG;
     if (M <= 0 || C <= 0 || ldd < C || ld < C) return ICKA_E_SHAPE;
     hipLaunchKernelGGL(token_ce_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld, labels, mask, stats,
-                       (bf16_t*)dlogits, ldd, M, C);
+                       dlogits, ldd, dl_is_f32, M, C);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -582,11 +582,11 @@ def token_ce(logits, labels, mask, loss_sum, count, dlogits):
 
 
 def token_ce_fused(logits, labels, mask, stats, dlogits):
-    """One-launch token CE: stats f32[3] <- (loss sum, #valid, mean loss); dlogits bf16 [M, ldd>=C] unscaled."""
+    """One-launch token CE: stats f32[3] <- (loss sum, #valid, mean loss); dlogits bf16 or f32 [M, ldd>=C] unscaled."""
     M, Cn = logits.shape
     check(_lib.load().icka_token_ce_fused(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
-                                          stats.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), M, Cn, _stream()),
-          "icka_token_ce_fused")
+                                          stats.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
+                                          int(dlogits.dtype == F32), M, Cn, _stream()), "icka_token_ce_fused")
 
 
 def zero_(t: torch.Tensor) -> torch.Tensor:

@@ -495,7 +495,7 @@ class GatedHeadFn(torch.autograd.Function):
         M, H = seq.shape
         C = dlogits.shape[1]
         if dlogits.dtype == BF16 and dlogits.stride(1) == 1 and dlogits.stride(0) % 8 == 0:
-            dl = dlogits                          # fused token-CE hands over a padded bf16 buffer view
+            dl = dlogits
         else:
             buf = torch.empty(M, (C + 7) // 8 * 8, dtype=BF16, device=seq.device)
             K.cast_pad_f32_to_bf16(dlogits.float() if dlogits.dtype != F32 else
@@ -755,15 +755,16 @@ class PromptEmbeddingsFn(torch.autograd.Function):
 
 class TokenCEFn(torch.autograd.Function):
     """Benchmark loss: token-level cross-entropy, mean over valid tokens.  One launch yields
-    the loss accumulators and the unscaled logit gradient; dloss / #valid is applied on device (no host sync)."""
+    the loss sum, the token count, their ratio and the unscaled logit gradient; dloss / #valid is applied on device in
+    the backward (no host sync).  The logits are f32, so their gradient is handed to autograd in f32 (a bf16 gradient
+    would be cast back by the engine with an ATen kernel); the classifier backward packs it to bf16 itself."""
 
     @staticmethod
     def forward(ctx, logits, labels, mask):
         M, C = logits.shape
         stats = torch.empty(3, dtype=F32, device=logits.device)
-        dl = torch.empty(M, (C + 7) // 8 * 8, dtype=BF16, device=logits.device)
+        dl = torch.empty(M, C, dtype=F32, device=logits.device)
         K.token_ce_fused(logits, labels.reshape(-1), mask.reshape(-1), stats, dl)   # sum, count, mean: one launch
-        ctx.C = C
         ctx.save_for_backward(dl, stats)
         return stats[2:3].view(())
 
@@ -774,5 +775,7 @@ class TokenCEFn(torch.autograd.Function):
         if g.dtype != F32:
             raise TypeError("loss gradient must be f32")
         out = torch.empty_like(dl)
-        K.scale_by_ratio(dl, out, num=g.contiguous(), den=stats[1:2])
-        return out[:, :ctx.C], None, None
+        check_rc = K._lib.load().icka_x_scale_by_ratio(dl.data_ptr(), out.data_ptr(), g.data_ptr(), stats[1:2].data_ptr(),
+                                                      dl.numel(), K._stream())
+        K.check(check_rc, "icka_x_scale_by_ratio")
+        return out, None, None

@@ -31,7 +31,7 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
 
 
-@pytest.mark.parametrize("precision,out_tol,grad_tol", [("bf16", 2e-2, 2e-2), ("fp32", 1e-5, 1e-4)])
+@pytest.mark.parametrize("precision,out_tol,grad_tol", [("bf16", 2e-2, 8e-2), ("fp32", 1e-5, 1e-4)])
 def test_composed_sub_modules_equal_the_fused_layers_and_the_oracle(precision, out_tol, grad_tol):
     from icka_amd.modeling import BertCrossAttentionLayer, BertLayer
     from oracle import mner_oracle as O
