@@ -133,7 +133,8 @@ PROTOTYPES = {
     "icka_embed_prompt_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                       c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
     "icka_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
-    "icka_token_ce_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "icka_token_ce_workspace_floats": (c_i64, [c_i32]),
+    "icka_token_ce_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "icka_zero_f32": (c_i32, [c_vp, c_i64, c_vp]),
     "icka_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "icka_scalar_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp]),

@@ -265,6 +265,105 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_) {
     }
 }
 
+// dQ kernel for Skv <= 4 * 64 keys (bert-large at seq 256, config c4): the first pass keeps P and dP of ALL keys of this
+// wave's 16 queries in registers (2 x NKT x 16 floats per lane) and the K tiles resident in LDS, so the second pass only
+// forms dS = P * (dP - delta) and multiplies it into dQ -- no second QK^T / dO.V^T, no re-staging (the two-pass kernel
+// above recomputes both: 158 us -> per launch at B32 x 16 heads x 256 x 256, 12.5 % of the c4 step).
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_keep_kernel(const AttnArgs a_) {
+    AttnArgs a = a_;
+    a.drop = drop_resolve(a.drop);
+    __shared__ __attribute__((aligned(16))) char smem[(3 + NKT) * TILE_B];
+    char* sQ = smem; char* sDO = smem + TILE_B; char* sV = smem + 2 * TILE_B; char* sK = smem + 3 * TILE_B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i15 = lane & 15;
+    const int nqt = (a.Sq + TILE - 1) / TILE;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.h, b = bh / a.h;
+    const bf16_t* Qb = a.Q + (int64_t)b * a.Sq * a.ldq + head * HD;
+    const bf16_t* dOb = a.dO + (int64_t)b * a.Sq * a.lddo + head * HD;
+    const bf16_t* Kb = a.K + (int64_t)b * a.Skv * a.ldk + head * HD;
+    const bf16_t* Vb = a.V + (int64_t)b * a.Skv * a.ldv + head * HD;
+    const float* mb = a.mask + (int64_t)b * a.Skv;
+
+    stage_tile(sQ, Qb, a.ldq, qt * TILE, a.Sq, tid);
+    stage_tile(sDO, dOb, a.lddo, qt * TILE, a.Sq, tid);
+    __syncthreads();
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = frag_row(sQ, 16 * wave, ks, lane);
+        dof[ks] = frag_row(sDO, 16 * wave, ks, lane);
+    }
+    const int q = qt * TILE + 16 * wave + i15;
+    const bool qok = q < a.Sq;
+    const int64_t stat = (int64_t)(b * a.h + head) * a.Sq + q;
+    const float lse_q = qok ? a.lse[stat] : INFINITY;
+    const uint32_t idx_row = ((uint32_t)(b * a.h + head) * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
+
+    // P is kept bf16-packed (dS is rounded to bf16 for the MFMA anyway; dP - delta, where the cancellation is, stays f32):
+    // 2 x NKT x 16 floats pushed the 4-tile instance over 256 VGPRs = one wave per SIMD
+    u32x2 pr[NKT][4];
+    f32x4 dpr[NKT][4];
+    float dl_q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        const int kv0 = t * TILE;
+        if (t) __syncthreads();                      // every wave is done with the previous V tile
+        stage_tile(sK + t * TILE_B, Kb, a.ldk, kv0, a.Skv, tid);
+        stage_tile(sV, Vb, a.ldv, kv0, a.Skv, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = mfma16(frag_row(sK + t * TILE_B, 16 * kt, ks, lane), qf[ks], s);
+                dp = mfma16(frag_row(sV, 16 * kt, ks, lane), dof[ks], dp);
+            }
+            float pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + 16 * kt + 4 * g + r;
+                const float p = key < a.Skv ? __expf(s[r] * a.scale + mb[key] - lse_q) : 0.f;
+                const float d = dp[r] * drop_mul(a.drop, idx_row + (uint32_t)key);
+                pv[r] = p;
+                dpr[t][kt][r] = d;
+                dl_q += p * d;
+            }
+            pr[t][kt] = pack4(pv[0], pv[1], pv[2], pv[3]);
+        }
+    }
+    dl_q += __shfl_xor(dl_q, 16, 64);
+    dl_q += __shfl_xor(dl_q, 32, 64);
+    if (g == 0 && qok) a.delta[stat] = dl_q;    // read by attn_bwd_dkv_kernel (launched after this kernel)
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        f32x4 ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bf16x4 pb = as_bf16x4(pr[t][kt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[kt][r] = bf2f(pb[r]) * (dpr[t][kt][r] - dl_q) * a.scale;
+        }
+        bf16x8 dsf[2];
+        dsf[0] = pack8(ds[0], ds[1]);
+        dsf[1] = pack8(ds[2], ds[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc[dt] = mfma16(frag_tr(sK + t * TILE_B, dt, ks, lane), dsf[ks], acc[dt]);
+    }
+    if (qok) {
+        bf16_t* row = a.dQ + ((int64_t)b * a.Sq + q) * a.lddq + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<u32x2*>(row + 16 * dt + 4 * g) = pack4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- dK/dV kernel
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_) {
     AttnArgs a = a_;
@@ -807,7 +906,14 @@ extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
         return 0;
     }
     // the dQ kernel computes delta = rowsum(P . dP) itself (first pass) and leaves it for the dK/dV kernel
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * heads * ((Sq + TILE - 1) / TILE)), dim3(256), 0, st, a);
+    const dim3 gq(B * heads * ((Sq + TILE - 1) / TILE));
+    switch ((Skv + TILE - 1) / TILE) {   // <= 256 keys: P and dP stay in registers between the two passes
+        case 1: hipLaunchKernelGGL(attn_bwd_dq_keep_kernel<1>, gq, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(attn_bwd_dq_keep_kernel<2>, gq, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(attn_bwd_dq_keep_kernel<3>, gq, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(attn_bwd_dq_keep_kernel<4>, gq, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), 0, st, a); break;
+    }
     ICKA_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * heads * ((Skv + TILE - 1) / TILE)), dim3(256), 0, st, a);
     ICKA_CHECK_LAUNCH();

@@ -251,15 +251,17 @@ __global__ __launch_bounds__(256) void token_ce_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && cnt > 0.f) { atomicAdd(loss_sum, loss); atomicAdd(count, cnt); }
 }
 
-// One block for the whole loss: no atomics, no pre-zeroed accumulators, the mean computed in the same launch (replaces
-// a 3-element fill + token_ce_kernel + scalar_ratio_kernel).  stats = {sum of token losses, #valid tokens, mean loss}.
-__global__ __launch_bounds__(1024) void token_ce_fused_kernel(const float* __restrict__ logits, int64_t ld,
-                                                              const int64_t* __restrict__ labels,
-                                                              const int64_t* __restrict__ mask, float* __restrict__ stats,
-                                                              void* __restrict__ dl_, int64_t ldd, int dl_f32, int M, int C) {
-    __shared__ float red[2][16];
+// Token-CE without pre-zeroed accumulators and without atomics: every 256-row block leaves its (loss, count) partial in
+// part[block][2]; ce_finalize_kernel sums them in a fixed order and writes stats = {sum, count, mean} (this second launch
+// replaces the scalar-ratio launch of the atomic version, the accumulator fill disappears).
+__global__ __launch_bounds__(256) void token_ce_part_kernel(const float* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ labels,
+                                                            const int64_t* __restrict__ mask, float* __restrict__ part,
+                                                            void* __restrict__ dl_, int64_t ldd, int dl_f32, int M, int C) {
+    __shared__ float red[2][4];
+    const int row = blockIdx.x * 256 + threadIdx.x;
     float loss = 0.f, cnt = 0.f;
-    for (int row = threadIdx.x; row < M; row += 1024) {
+    if (row < M) {
         const float* p = logits + (int64_t)row * ld;
         const bool valid = mask[row] != 0;
         const int64_t y = labels[row];
@@ -274,17 +276,23 @@ __global__ __launch_bounds__(1024) void token_ce_fused_kernel(const float* __res
             if (dl_f32) reinterpret_cast<float*>(dl_)[(int64_t)row * ldd + c] = gval;
             else reinterpret_cast<bf16_t*>(dl_)[(int64_t)row * ldd + c] = f2bf(gval);
         }
-        if (valid && y >= 0 && y < C) { loss += lse - p[y]; cnt += 1.f; }
+        if (valid && y >= 0 && y < C) { loss = lse - p[y]; cnt = 1.f; }
     }
     loss = wave_sum(loss);
     cnt = wave_sum(cnt);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float l = 0.f, n = 0.f;
-        for (int w = 0; w < 16; ++w) { l += red[0][w]; n += red[1][w]; }   // fixed order: bitwise reproducible
-        stats[0] = l; stats[1] = n; stats[2] = l / fmaxf(n, 1.f);
+        part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
+}
+__global__ __launch_bounds__(64) void ce_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats) {
+    float l = 0.f, n = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) { l += part[2 * b]; n += part[2 * b + 1]; }
+    l = wave_sum(l);
+    n = wave_sum(n);
+    if (threadIdx.x == 0) { stats[0] = l; stats[1] = n; stats[2] = l / fmaxf(n, 1.f); }
 }
 
 // 16-byte stores, enough blocks to cover the HBM channels (the 94 MB word-embedding gradient table is cleared once per
@@ -459,12 +467,17 @@ extern "C" int icka_token_ce(const float* logits, int64_t ld, const int64_t* lab
     ICKA_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int64_t icka_token_ce_workspace_floats(int32_t M) { return 2 * (int64_t)((M + 255) / 256); }
 extern "C" int icka_token_ce_fused(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* stats,
-                                   void* dlogits, int64_t ldd, int32_t dl_is_f32, int32_t M, int32_t C, void* stream) {
-    if (!logits || !labels || !mask || !stats || !dlogits) return ICKA_E_ARG;
+                                   float* partials, void* dlogits, int64_t ldd, int32_t dl_is_f32, int32_t M, int32_t C,
+                                   void* stream) {
+    if (!logits || !labels || !mask || !stats || !partials || !dlogits) return ICKA_E_ARG;
     if (M <= 0 || C <= 0 || ldd < C || ld < C) return ICKA_E_SHAPE;
-    hipLaunchKernelGGL(token_ce_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld, labels, mask, stats,
-                       dlogits, ldd, dl_is_f32, M, C);
+    const int nblk = (M + 255) / 256;
+    hipLaunchKernelGGL(token_ce_part_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, mask,
+                       partials, dlogits, ldd, dl_is_f32, M, C);
+    ICKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblk, stats);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -582,11 +582,14 @@ def token_ce(logits, labels, mask, loss_sum, count, dlogits):
 
 
 def token_ce_fused(logits, labels, mask, stats, dlogits):
-    """One-launch token CE: stats f32[3] <- (loss sum, #valid, mean loss); dlogits bf16 or f32 [M, ldd>=C] unscaled."""
+    """Token CE without accumulator fill / atomics: stats f32[3] <- (loss sum, #valid, mean loss); dlogits bf16 or f32
+    [M, ldd>=C] unscaled."""
     M, Cn = logits.shape
-    check(_lib.load().icka_token_ce_fused(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
-                                          stats.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
-                                          int(dlogits.dtype == F32), M, Cn, _stream()), "icka_token_ce_fused")
+    lib = _lib.load()
+    part = torch.empty(lib.icka_token_ce_workspace_floats(M), dtype=F32, device=logits.device)
+    check(lib.icka_token_ce_fused(logits.data_ptr(), logits.stride(0), labels.data_ptr(), mask.data_ptr(),
+                                  stats.data_ptr(), part.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
+                                  int(dlogits.dtype == F32), M, Cn, _stream()), "icka_token_ce_fused")
 
 
 def zero_(t: torch.Tensor) -> torch.Tensor:

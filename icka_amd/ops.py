@@ -754,8 +754,9 @@ class PromptEmbeddingsFn(torch.autograd.Function):
 
 
 class TokenCEFn(torch.autograd.Function):
-    """Benchmark loss: token-level cross-entropy, mean over valid tokens.  One launch yields
-    the loss sum, the token count, their ratio and the unscaled logit gradient; dloss / #valid is applied on device in
+    """Benchmark loss: token-level cross-entropy, mean over valid tokens.  Two launches (per-block
+    partials, finalize; no accumulator fill, no atomics) yield the loss sum, the token count, their ratio and the unscaled
+    logit gradient; dloss / #valid is applied on device in
     the backward (no host sync).  The logits are f32, so their gradient is handed to autograd in f32 (a bf16 gradient
     would be cast back by the engine with an ATen kernel); the classifier backward packs it to bf16 itself."""
 
@@ -764,7 +765,7 @@ class TokenCEFn(torch.autograd.Function):
         M, C = logits.shape
         stats = torch.empty(3, dtype=F32, device=logits.device)
         dl = torch.empty(M, C, dtype=F32, device=logits.device)
-        K.token_ce_fused(logits, labels.reshape(-1), mask.reshape(-1), stats, dl)   # sum, count, mean: one launch
+        K.token_ce_fused(logits, labels.reshape(-1), mask.reshape(-1), stats, dl)   # sum, count, mean
         ctx.save_for_backward(dl, stats)
         return stats[2:3].view(())
 

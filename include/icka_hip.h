@@ -279,11 +279,13 @@ int icka_token_ce(const float* logits, int64_t ld, const int64_t* labels, const 
 /* y = x * num[0] / max(den[0], 1) for bf16 [n] with DEVICE scalars (NULL = 1): applies dloss / #valid to the
  * logit gradients without a host sync.  y may alias x. */
 int icka_scale_by_ratio(const void* x, void* y, const float* num, const float* den, int64_t n, void* stream);
-/* The same loss in ONE launch without pre-zeroed accumulators: stats f32[3] = {sum of token losses, number of valid
- * tokens, mean loss}; dlogits [M, ldd] unscaled, bf16 or f32 (dl_is_f32; autograd wants the gradient of the f32 logits in
- * f32).  One 1024-thread block, fixed summation order (bitwise reproducible). */
+/* The same loss without pre-zeroed accumulators and without atomics (fixed summation order, bitwise reproducible):
+ * stats f32[3] = {sum of token losses, number of valid tokens, mean loss}; dlogits [M, ldd] unscaled, bf16 or f32
+ * (dl_is_f32: autograd wants the gradient of the f32 logits in f32); partials = f32 workspace of
+ * icka_token_ce_workspace_floats(M).  Two launches (per-block partials, finalize). */
+int64_t icka_token_ce_workspace_floats(int32_t M);
 int icka_token_ce_fused(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* stats,
-                        void* dlogits, int64_t ldd, int32_t dl_is_f32, int32_t M, int32_t C, void* stream);
+                        float* partials, void* dlogits, int64_t ldd, int32_t dl_is_f32, int32_t M, int32_t C, void* stream);
 /* p[0..n) = 0 (16-byte aligned p): clears the atomically accumulated embedding-table gradients. */
 int icka_zero_f32(float* p, int64_t n, void* stream);
 /* out[0] = num[0] / max(den[0], 1)   (mean loss from the two accumulators of icka_token_ce). */
