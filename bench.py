@@ -188,6 +188,9 @@ def main():
                          "the 'tracked' policy: the optimizer is outside the metric (SURVEY.md section 8d), so the weights do "
                          "not change between the timed steps and the cast -- the tail of an optimizer step -- has nothing to do; "
                          "its cost is reported as shadow_cast_us")
+    ap.add_argument("--capture-collectives", action="store_true",
+                    help="data parallel: capture the all-reduces INSIDE one hipGraph (side-stream branches) instead of the "
+                         "default linear segments with eager all-reduces between them")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (tests the "
                                                               "RCCL path on a single GPU)")
@@ -265,7 +268,22 @@ def main():
     #      cannot be captured): the timed region then replays the graph
     mode = "eager"
     run_step = step
-    if not args.no_graph:
+    if not args.no_graph and reducer is not None and not args.capture_collectives:
+        # data parallel: linear graph segments with the bucket all-reduces issued eagerly between them (graph.SegmentedStep)
+        try:
+            from icka_amd.graph import SegmentedStep
+            log("capturing the step as linear hipGraph segments (eager all-reduces in between)")
+            if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallbacks below
+                raise RuntimeError("simulated capture failure")
+            sstep = SegmentedStep(model, step, reducer)
+            run_step = sstep
+            mode = "hipgraph-segments(%d)+eager-allreduce(%d buckets, overlapped)" % (len(sstep.segments), len(reducer.buckets))
+        except Exception as e:  # noqa: BLE001
+            log("segmented capture failed (%s: %s)" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            reducer.capture = None
+            arena.reducer = reducer
+    if not args.no_graph and mode == "eager":
         try:
             from icka_amd.graph import GraphedStep
             log("capturing the step into a hipGraph")
@@ -279,15 +297,15 @@ def main():
             torch.cuda.synchronize()
             run_step = step
             if reducer is not None:
-                # second attempt: the collectives are what a runtime may refuse to capture -- capture forward + backward
-                # only and launch the bucket all-reduces eagerly after each replay (no overlap, but no host-bound step)
+                # last graph attempt: capture forward + backward only and launch the bucket all-reduces eagerly after each
+                # replay (no overlap, but no host-bound step)
                 try:
                     arena.reducer = None
 
                     def compute_only():
                         loss = model(g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"],
                                      g["visual_embeds_mean"], g["visual_embeds_att"], labels=g["labels"])
-                        loss.backward()
+                        loss.backward(gradient=one)
                         return loss
                     gcomp = GraphedStep(model, compute_only)
 

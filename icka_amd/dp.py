@@ -66,6 +66,10 @@ class GradReducer(object):
         self._seen: Dict[int, int] = {}
         self._waiting = [0] * len(self.buckets)   # per bucket: slots that have not received all their writes yet
         self._launched = [False] * len(self.buckets)
+        # segmented hipGraph capture (graph.SegmentedStep): while ``capture`` is set, a bucket that becomes ready is not
+        # launched but reported -- the capture cuts the graph there and the all-reduce is issued eagerly between the
+        # replayed segments, so no collective and no cross-stream edge ever sits inside a captured graph
+        self.capture = None
         self._stage = None
         if self.comm_bf16:
             self._stage = torch.empty(max(e - s for s, e in self.buckets), dtype=torch.bfloat16, device=arena.device)
@@ -82,9 +86,16 @@ class GradReducer(object):
         self.arena.mark_dirty()
 
     def _launch(self, idx: int) -> None:
+        self._launched[idx] = True
+        if self.capture is not None:
+            self.capture.ready.append(idx)
+            return
+        self.launch_now(idx)
+
+    def launch_now(self, idx: int) -> None:
+        """Issue bucket ``idx``'s all-reduce (side stream on devices, ordered after everything on the current stream)."""
         s, e = self.buckets[idx]
         buf = self.arena.gflat[s:e]
-        self._launched[idx] = True
         if self.is_cuda and self.backend == "nccl":
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -145,6 +156,8 @@ class GradReducer(object):
                 self._waiting[bi] -= 1
                 if self._waiting[bi] == 0 and not self._launched[bi]:
                     self._launch(bi)
+        if self.capture is not None and self.capture.ready:
+            self.capture.cut()
 
     def finish(self) -> None:
         """Launch every bucket not launched yet (parameters that got no gradient this step keep their bucket
@@ -152,8 +165,8 @@ class GradReducer(object):
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch(bi)
-        if self.is_cuda and self.backend == "nccl":
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.capture is None:
+            self.join()
         self._calibrated = True
         # parameters that never receive a gradient (e.g. the pooler when only logits are used) are not waited for
         self._seen = {}
@@ -161,6 +174,11 @@ class GradReducer(object):
         for sid in self._expected:
             self._waiting[self._bucket_of[sid]] += 1
         self._launched = [False] * len(self.buckets)
+
+    def join(self) -> None:
+        """Make the compute stream wait for the reductions issued so far."""
+        if self.is_cuda and self.backend == "nccl":
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def reduce_all(self) -> None:
         """Non-overlapped form: all-reduce every bucket now (after backward)."""

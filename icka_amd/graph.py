@@ -16,6 +16,13 @@ Contract
     parameters is the first kernel inside the captured forward; with "tracked" it runs before the replay when a change
     was seen.
   * ``close()`` (also run by ``__del__``) unregisters the dropout nonce, whose device memory this object owns.
+
+Data parallel (``SegmentedStep``): a captured graph with a side-stream branch per gradient bucket costs ~0.17 ms for the
+first fork and ~25 us for each further one on this runtime (tools/graph_fork_probe.py), and needs the collective library
+to be capturable.  ``SegmentedStep`` instead cuts the step into LINEAR graphs at the points where a gradient bucket
+becomes final and issues the bucket's all-reduce eagerly, on the communication stream, between two segment launches:
+the host enqueues everything ahead of the GPU, the compute stream sees the segments back to back, and RCCL is never
+captured.
 """
 from __future__ import annotations
 
@@ -70,6 +77,102 @@ class GraphedStep(object):
                 pass
             self.nonce = None
         self.graph = None
+
+    def __del__(self):
+        self.close()
+
+
+class _Capture(object):
+    """State of a segmented capture: the graph being recorded, the finished (graph, buckets-after-it) segments, and the
+    buckets that became ready since the last cut (filled by GradReducer._launch)."""
+
+    def __init__(self):
+        self.graph = None
+        self.pool = None
+        self.segments = []
+        self.ready = []
+
+    def begin(self) -> None:
+        self.graph = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.graph.capture_begin(capture_error_mode="thread_local")
+            self.pool = self.graph.pool()
+        else:
+            self.graph.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def end(self) -> None:
+        self.graph.capture_end()
+        self.segments.append((self.graph, self.ready))
+        self.graph, self.ready = None, []
+
+    def cut(self) -> None:
+        self.end()
+        self.begin()
+
+
+class SegmentedStep(object):
+    """Data-parallel step as a chain of linear hipGraphs with eager bucket all-reduces between them (module docstring).
+    ``step_fn`` runs forward + backward + ``reducer.finish()`` and returns the loss; ``reducer`` must already be
+    attached to the model's arena.  Same gradient contract as ``GraphedStep``."""
+
+    def __init__(self, model: torch.nn.Module, step_fn: Callable[[], torch.Tensor], reducer, warmup: int = 3):
+        dev = next(model.parameters()).device
+        self.model, self.reducer = model, reducer
+        self.nonce = torch.zeros(2, dtype=torch.int32, device=dev)
+        K.set_dropout_nonce(self.nonce)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up (the first of these steps calibrates the reducer's write counts)
+            for _ in range(max(warmup, 2)):
+                model.zero_grad()
+                K.bump_dropout_nonce(self.nonce)
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.arena = model._icka_arena
+        model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
+        cap = _Capture()
+        reducer.capture = cap
+        try:
+            # backward on THIS thread: begin / end of a stream capture must come from one thread, and the cuts happen
+            # inside backward (GradReducer.mark_final)
+            with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
+                cap.begin()
+                K.bump_dropout_nonce(self.nonce)
+                self.loss = step_fn()           # its reducer.finish() reports the remaining buckets, without joining
+                # the embedding backward is the last kernel of the step and makes the last bucket final: the segment
+                # opened by that cut would be empty -- give it one (no-op) node
+                self._pad = torch.zeros(2, dtype=torch.int32, device=dev)
+                K.bump_dropout_nonce(self._pad)
+                cap.end()
+        finally:
+            reducer.capture = None
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.segments = cap.segments
+        self._grad_slots = [s for s in self.arena.order if s.live]
+
+    def __call__(self) -> torch.Tensor:
+        if self.segments is None:
+            raise RuntimeError("SegmentedStep is closed")
+        if self.arena.shadow_policy != "always":
+            self.arena.sync()
+        for graph, buckets in self.segments:
+            graph.replay()
+            for bi in buckets:
+                self.reducer.launch_now(bi)
+        self.reducer.join()
+        self.arena.attach_grads(self._grad_slots)
+        return self.loss
+
+    def close(self) -> None:
+        if getattr(self, "nonce", None) is not None:
+            try:
+                K.clear_dropout_nonce_if(self.nonce)
+            except Exception:
+                pass
+            self.nonce = None
+        self.segments = None
 
     def __del__(self):
         self.close()

@@ -41,3 +41,23 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, precision,
               "from inside backward" % (precision, r, res["worst"], res["key"], res["buckets"], res["overlapped"]))
         assert res["worst"] < bar, res
         assert res["buckets"] > 3 and res["overlapped"] >= res["buckets"] - 2, res
+
+
+@pytest.mark.parametrize("comm,bar", [("f32", 1e-6), ("bf16", 6e-3)])
+def test_segmented_step_matches_the_eager_step(tmp_path, comm, bar):
+    """graph.SegmentedStep at world 1 over RCCL: linear graph segments + eager bucket all-reduces == plain eager step
+    (f32 buckets: identical up to the all-reduce being an identity; bf16 buckets: one bf16 rounding of each gradient)."""
+    out = str(tmp_path / "seg.pt")
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_segment_worker.py"), str(_free_port()), out, comm])
+    try:
+        assert p.wait(timeout=300) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+    res = torch.load(out)
+    print("\n[segmented step, %s buckets] %d segments for %d buckets (all-reduces after each: %s); worst gradient rel-L2 vs eager "
+          "%.3e; loss %.5f (eager %.5f)" % (comm, res["segments"], res["buckets"], res["after"], res["worst"], res["loss"],
+                                           res["ref_loss"]))
+    assert res["segments"] > 3 and sum(res["after"]) == res["buckets"]
+    assert res["worst"] < bar, res
+    assert abs(res["loss"] - res["ref_loss"]) < 1e-6
