@@ -88,17 +88,13 @@ class _Capture(object):
 
     def __init__(self):
         self.graph = None
-        self.pool = None
+        self.pool = torch.cuda.graph_pool_handle()   # one allocator pool for all segments: later ones read earlier tensors
         self.segments = []
         self.ready = []
 
     def begin(self) -> None:
         self.graph = torch.cuda.CUDAGraph()
-        if self.pool is None:
-            self.graph.capture_begin(capture_error_mode="thread_local")
-            self.pool = self.graph.pool()
-        else:
-            self.graph.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self.graph.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def end(self) -> None:
         self.graph.capture_end()
