@@ -578,7 +578,9 @@ class BertModel(BertPreTrainedModel):
         self.pooler = BertPooler(config)
         self.apply(self.init_bert_weights)
 
-    def forward(self, input_ids, token_type_ids=None, attention_mask=None, output_all_encoded_layers=True):
+    def encode(self, input_ids, token_type_ids=None, attention_mask=None, output_all_encoded_layers=True):
+        """forward() without the pooler: the list of encoded layers (:364-379).  The MNER heads read only the sequence
+        output (cl_modeling.py:1341-1344), so their trunk does not launch the pooler GEMM for a result nobody uses."""
         if not input_ids.is_cuda:
             raise TypeError("input_ids must be on a ROCm device: icka_amd has no CPU path")
         B, S = input_ids.shape
@@ -588,8 +590,10 @@ class BertModel(BertPreTrainedModel):
                             torch.empty(B, S, dtype=F32, device=input_ids.device))
         extended_attention_mask = add_mask.view(B, 1, 1, S)
         embedding_output = self.embeddings(input_ids, token_type_ids)
-        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
-                                      output_all_encoded_layers=output_all_encoded_layers)
+        return self.encoder(embedding_output, extended_attention_mask, output_all_encoded_layers=output_all_encoded_layers)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, output_all_encoded_layers=True):
+        encoded_layers = self.encode(input_ids, token_type_ids, attention_mask, output_all_encoded_layers)
         sequence_output = encoded_layers[-1]
         pooled_output = self.pooler(sequence_output)
         if not output_all_encoded_layers:
@@ -608,8 +612,11 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     A = self._arena()
     dev = input_ids.device
     # ---- text encoder (cl_modeling.py:1341-1344)
-    sequence_output, _ = self.bert(input_ids, token_type_ids=segment_ids, attention_mask=input_mask,
-                                   output_all_encoded_layers=False)
+    if isinstance(self.bert, BertModel):
+        sequence_output = self.bert.encode(input_ids, segment_ids, input_mask, output_all_encoded_layers=False)[-1]
+    else:   # a caller-supplied text encoder with the reference's BertModel call convention
+        sequence_output, _ = self.bert(input_ids, token_type_ids=segment_ids, attention_mask=input_mask,
+                                       output_all_encoded_layers=False)
     exact = _is_exact(self)
     if exact:
         return _mner_trunk_exact(self, A, sequence_output.view(B * S, H), added_attention_mask, visual_embeds_att, B, S)
