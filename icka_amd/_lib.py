@@ -161,6 +161,12 @@ PROTOTYPES = {
     "icka_x_sample_gate_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "icka_x_sample_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp,
                                        c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_lstm_cell_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_lstm_cell_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_x_embed_prompt_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                        c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "icka_x_embed_prompt_scatter": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                            c_i32, c_vp]),
     "icka_x_token_ce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "icka_x_scale_by_ratio": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }

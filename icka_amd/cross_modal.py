@@ -23,11 +23,12 @@ from typing import Sequence
 import torch
 import torch.nn as nn
 
+from . import exact as X
 from . import kernels as K
 from . import ops
 from .config import check_config
 from .modeling import (BF16, F32, BertCrossEncoder, BertEncoder, BertLayerNorm, BertModel, BertPreTrainedModel,
-                       BertSelfEncoder, _CastFn, _IckaModule, _dims, _mner_trunk, _with_twin, cls_layer_both)
+                       BertSelfEncoder, _CastFn, _IckaModule, _dims, _is_exact, _mner_trunk, _with_twin, cls_layer_both)
 
 
 class PromptRobertaEmbeddings(_IckaModule):
@@ -50,6 +51,10 @@ class PromptRobertaEmbeddings(_IckaModule):
         if S + self.padding_idx + 1 > self.position_embeddings.weight.shape[0]:
             raise IndexError("spliced length %d exceeds max_position_embeddings" % S)
         A = self._arena()
+        if _is_exact(self):
+            d = _dims(self.config, B, S, 0, self.training, True)
+            return X.PromptEmbeddingsFn.apply(A.anchor, prompt_embeddings, self, A, input_ids.contiguous(), src, d,
+                                              self.padding_idx + 1).view(B, S, -1)
         d = _dims(self.config, B, S, 0, self.training)
         y, yf = ops.PromptEmbeddingsFn.apply(A.anchor, prompt_embeddings, self, A, input_ids.contiguous(), src, d,
                                              self.padding_idx + 1)
@@ -134,7 +139,9 @@ class PromptRobertaModel(BertPreTrainedModel):
             spliced[:, S_out:] = 0
         add_mask = K.additive_mask(spliced.contiguous(), S, torch.empty(B, S, dtype=F32, device=input_ids.device))
         pe = prompt_embeddings
-        if pe.dtype != BF16:
+        if _is_exact(self):
+            pe = pe if pe.dtype == F32 else _CastFn.apply(pe.contiguous(), False)
+        elif pe.dtype != BF16:
             pe = _CastFn.apply(pe.contiguous(), True)
         x = self.embeddings(input_ids, src, pe)
         out = self.encoder(x, add_mask.view(B, 1, 1, S), output_all_encoded_layers=False)[-1]
@@ -208,20 +215,27 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
     # ------------------------------------------------------------------------------------------------ pieces
     def _mapping(self, A, seq_mod: nn.Sequential, x2d: torch.Tensor) -> torch.Tensor:
         p = float(seq_mod[0].p) if self.training else 0.0
+        if _is_exact(self):
+            return X.prompt_mapping(A, x2d, seq_mod[1], seq_mod[4], p)
         return ops.PromptMappingFn.apply(A.anchor, x2d, seq_mod[1], seq_mod[4], A, p)
 
     def prompts(self, A, clip_aligned: torch.Tensor, visual_embeds_mean: torch.Tensor) -> torch.Tensor:
         """prefix_emb [B, 2*prompt_len, Hr] (:995-1004).  clip_aligned bf16 [B,H]."""
         B = clip_aligned.shape[0]
         H = self.hidden_size
+        ex = _is_exact(self)
         align = self._mapping(A, self.mapping_network_alignment, clip_aligned).view(B, self.prompt_len, H)
         vm = visual_embeds_mean.reshape(B, 2048)
-        vm = vm if vm.dtype == BF16 else _CastFn.apply(vm.float().contiguous(), True)
+        if ex:
+            vm = vm.float().contiguous()
+        else:
+            vm = vm if vm.dtype == BF16 else _CastFn.apply(vm.float().contiguous(), True)
         vision = self._mapping(A, self.mapping_network_vision, vm).view(B, self.prompt_len, H)
         prefix = torch.cat([vision, align], dim=1)           # [B, 10, H]   (concatenation: data movement only)
         if H != 1024:                                         # :1002-1003
-            prefix = ops.LinearFn.apply(A.anchor, prefix.view(B * 2 * self.prompt_len, H), self.lastproj, A, False,
-                                        K.EPI_NONE).view(B, 2 * self.prompt_len, 1024)
+            flat = prefix.view(B * 2 * self.prompt_len, H)
+            prefix = (X.LinearFn.apply(A.anchor, flat, self.lastproj, A, False) if ex else
+                      ops.LinearFn.apply(A.anchor, flat, self.lastproj, A, False, K.EPI_NONE)).view(B, 2 * self.prompt_len, 1024)
         return prefix
 
     def emissions(self, input_ids, segment_ids, input_mask, ori_input_ids, ori_input_mask, ori_segment_ids,
@@ -233,11 +247,15 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         # ---- trunk: text encoder -> dropout -> regions -> vismap2text -> text->image cross encoder (:950-969)
         A, _, _, cross, _ = _mner_trunk(self, ori_input_ids, ori_segment_ids, ori_input_mask, added_attention_mask,
                                         visual_embeds_att)
-        cross_k, cross_gate = ops.FanOutFn.apply(cross, 2)        # consumers: alignment K/V source, scalar gate + blend
+        ex = _is_exact(self)
+        cross_k, cross_gate = (X.FanOutFn if ex else ops.FanOutFn).apply(cross, 2)   # alignment K/V source; gate + blend
         # ---- CLIP token -> hidden (:954), then two single-query cross encoders over the text (:981-989)
         cf = clip_features.reshape(B, 512)
-        cf = cf if cf.dtype == BF16 else _CastFn.apply(cf.float().contiguous(), True)
-        clip = ops.LinearFn.apply(A.anchor, cf, self.vismapping, A, False, K.EPI_NONE).view(B, 1, H)
+        if ex:
+            clip = X.LinearFn.apply(A.anchor, cf.float().contiguous(), self.vismapping, A, False).view(B, 1, H)
+        else:
+            cf = cf if cf.dtype == BF16 else _CastFn.apply(cf.float().contiguous(), True)
+            clip = ops.LinearFn.apply(A.anchor, cf, self.vismapping, A, False, K.EPI_NONE).view(B, 1, H)
         text_mask = K.additive_mask(ori_input_mask if ori_input_mask.dtype == torch.int64 else ori_input_mask.long(),
                                     S, torch.empty(B, S, dtype=F32, device=dev)).view(B, 1, 1, S)
         cross3 = cross_k.view(B, S, H)
@@ -255,9 +273,16 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
                              % (off2, off2 + self.max_seq_length, enc_out.shape[1], S))
         token_embedding = enc_out[:, off2:off2 + self.max_seq_length, :].contiguous()       # :1024 (copy: data movement)
         # ---- scalar gate + blend (:1029-1036), BiLSTM, classifier (:1042-1043)
-        result = _scalar_gate(self, A, cross_gate, token_embedding.view(B * S, H), B, S)
+        if ex:
+            from .modeling import scalar_gate_fusion
+            result = scalar_gate_fusion(self, cross_gate.view(B, S, H), token_embedding)
+        else:
+            result = _scalar_gate(self, A, cross_gate, token_embedding.view(B * S, H), B, S)
         x, _ = self.lstm(result.view(B, S, H))
-        em = ops.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * H), self.classifier, A, True, K.EPI_NONE)
+        if ex:
+            em = X.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * H), self.classifier, A, False)
+        else:
+            em = ops.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * H), self.classifier, A, True, K.EPI_NONE)
         return em.view(B, S, self.num_labels)
 
     def forward(self, input_ids, segment_ids, input_mask, ori_input_ids, ori_input_mask, ori_segment_ids,

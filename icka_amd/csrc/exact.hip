@@ -479,6 +479,108 @@ __global__ void xscale_ratio_kernel(const float* __restrict__ x, float* __restri
         y[i] = x[i] * s;
 }
 
+
+// =====================================================================================================================
+// BiLSTM recurrence in f32 (nn.LSTM(H, H, batch_first=True, bidirectional=True), Cross_Modal_Interaction_Module.py
+// :905-908): the per-step gate pre-activations are gx[t] + h_{t-1} . W_hh^T, accumulated into the gate buffer by
+// icka_x_gemm (batched over the two directions); these kernels are the pointwise cell update of step k for both
+// directions (forward direction at t = k, reverse direction at t = S-1-k).  Gate order i, f, g, o as in PyTorch.
+__global__ void xlstm_cell_fwd_kernel(float* __restrict__ gates, float* __restrict__ c_all, float* __restrict__ y,
+                                      float* __restrict__ hprev, int B, int S, int H, int k) {
+    const int n = 2 * B * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int dir = i / (B * H), r = i - dir * B * H, b = r / H, j = r - b * H;
+        const int t = dir ? S - 1 - k : k, tp = dir ? t + 1 : t - 1;
+        const int64_t row = (int64_t)b * S + t, rowp = (int64_t)b * S + tp;
+        float* gr = gates + row * 8 * H + dir * 4 * H;
+        const float ig = 1.f / (1.f + expf(-gr[j])), fg = 1.f / (1.f + expf(-gr[H + j]));
+        const float gg = tanhf(gr[2 * H + j]), og = 1.f / (1.f + expf(-gr[3 * H + j]));
+        const float cp = k ? c_all[rowp * 2 * H + dir * H + j] : 0.f;
+        const float c = fg * cp + ig * gg;
+        gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = gg; gr[3 * H + j] = og;      // activations, saved for backward
+        c_all[row * 2 * H + dir * H + j] = c;
+        y[row * 2 * H + dir * H + j] = og * tanhf(c);
+        hprev[row * 2 * H + dir * H + j] = k ? y[rowp * 2 * H + dir * H + j] : 0.f;
+    }
+}
+// backward of step k (run for k = S-1 .. 0): act -> dgates (pre-activation gradients) in place; dh_rec [2,B,H] is the
+// gradient that reached h_t through the NEXT step's recurrent product (ignored at k = S-1); dc_carry [2,B,H] in/out.
+__global__ void xlstm_cell_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dh_rec,
+                                      float* __restrict__ dc_carry, float* __restrict__ act, const float* __restrict__ c_all,
+                                      int B, int S, int H, int k, int first) {
+    const int n = 2 * B * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int dir = i / (B * H), r = i - dir * B * H, b = r / H, j = r - b * H;
+        const int t = dir ? S - 1 - k : k, tp = dir ? t + 1 : t - 1;
+        const int64_t row = (int64_t)b * S + t, rowp = (int64_t)b * S + tp;
+        float* gr = act + row * 8 * H + dir * 4 * H;
+        const float ig = gr[j], fg = gr[H + j], gg = gr[2 * H + j], og = gr[3 * H + j];
+        const float c = c_all[row * 2 * H + dir * H + j], cp = k ? c_all[rowp * 2 * H + dir * H + j] : 0.f;
+        const float tc = tanhf(c);
+        const float dh = dy[row * 2 * H + dir * H + j] + (first ? 0.f : dh_rec[i]);
+        const float dc = (first ? 0.f : dc_carry[i]) + dh * og * (1.f - tc * tc);
+        gr[j] = dc * gg * ig * (1.f - ig);
+        gr[H + j] = dc * cp * fg * (1.f - fg);
+        gr[2 * H + j] = dc * ig * (1.f - gg * gg);
+        gr[3 * H + j] = dh * tc * og * (1.f - og);
+        dc_carry[i] = dc * fg;
+    }
+}
+
+// =====================================================================================================================
+// Embeddings of the prompt-accepting encoder stage (f32 twin of icka_embed_prompt_fwd): out[b, t] = LN(x + pos[t +
+// pos_offset] + type[0]),  x = word[ids[b, src[t]]] for src[t] >= 0, prompt[b, -1-src[t]] otherwise.
+__global__ __launch_bounds__(256) void xembed_prompt_fwd_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ src,
+                                                                const float* __restrict__ prompt, const float* __restrict__ word,
+                                                                const float* __restrict__ pos, const float* __restrict__ typ,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ y, float* __restrict__ xhat,
+                                                                float* __restrict__ rstd, int M, int S_in, int S, int P, int H,
+                                                                int pos_offset, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int b = row / S, sp = row - b * S, sidx = src[sp];
+    const float* w = sidx < 0 ? prompt + ((int64_t)b * P + (-1 - sidx)) * H : word + ids[(int64_t)b * S_in + sidx] * (int64_t)H;
+    const float* p = pos + (int64_t)(sp + pos_offset) * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += (w[c] + p[c]) + typ[c];
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int c = lane; c < H; c += 64) { const float v = (w[c] + p[c]) + typ[c] - mean; q += v * v; }
+    const float rs = 1.f / sqrtf(wave_sum(q) / (float)H + eps);
+    for (int c = lane; c < H; c += 64) {
+        const float xh = ((w[c] + p[c]) + typ[c] - mean) * rs;
+        if (xhat) xhat[(int64_t)row * H + c] = xh;
+        y[(int64_t)row * H + c] = xh * gamma[c] + beta[c];
+    }
+    if (rstd && lane == 0) rstd[row] = rs;
+}
+// backward scatter of the LayerNorm-input gradient: word rows (atomics, padding row skipped), position rows, type row 0,
+// and the prompt block gradient (every [b, p] row has exactly one source position: plain stores)
+__global__ __launch_bounds__(256) void xembed_prompt_scatter_kernel(const float* __restrict__ dpre, const int64_t* __restrict__ ids,
+                                                                    const int32_t* __restrict__ src, float* __restrict__ dword,
+                                                                    float* __restrict__ dpos, float* __restrict__ dtyp,
+                                                                    float* __restrict__ dprompt, int M, int S_in, int S, int P,
+                                                                    int H, int pos_offset, int padding_idx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int b = row / S, sp = row - b * S, sidx = src[sp];
+    const float* g = dpre + (int64_t)row * H;
+    float* p = dpos + (int64_t)(sp + pos_offset) * H;
+    if (sidx < 0) {
+        float* dp = dprompt + ((int64_t)b * P + (-1 - sidx)) * H;
+        for (int c = lane; c < H; c += 64) { dp[c] = g[c]; atomicAdd(p + c, g[c]); atomicAdd(dtyp + c, g[c]); }
+    } else {
+        const int64_t id = ids[(int64_t)b * S_in + sidx];
+        float* w = dword + id * (int64_t)H;
+        for (int c = lane; c < H; c += 64) {
+            if (id != padding_idx) atomicAdd(w + c, g[c]);
+            atomicAdd(p + c, g[c]);
+            atomicAdd(dtyp + c, g[c]);
+        }
+    }
+}
+
 inline int xgrid(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -667,6 +769,48 @@ extern "C" int icka_x_scale_by_ratio(const float* x, float* y, const float* num,
     if (!x || !y) return ICKA_E_ARG;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(xscale_ratio_kernel, dim3(xgrid(n)), dim3(256), 0, (hipStream_t)stream, x, y, num, den, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_x_lstm_cell_fwd(float* gates, float* c_all, float* y, float* hprev, int32_t B, int32_t S, int32_t H,
+                                    int32_t k, void* stream) {
+    if (!gates || !c_all || !y || !hprev) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || k < 0 || k >= S) return ICKA_E_SHAPE;
+    hipLaunchKernelGGL(xlstm_cell_fwd_kernel, dim3(xgrid(2ll * B * H)), dim3(256), 0, (hipStream_t)stream, gates, c_all, y, hprev,
+                       B, S, H, k);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_x_lstm_cell_bwd(const float* dy, const float* dh_rec, float* dc_carry, float* act, const float* c_all,
+                                    int32_t B, int32_t S, int32_t H, int32_t k, int32_t first, void* stream) {
+    if (!dy || !dh_rec || !dc_carry || !act || !c_all) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || k < 0 || k >= S) return ICKA_E_SHAPE;
+    hipLaunchKernelGGL(xlstm_cell_bwd_kernel, dim3(xgrid(2ll * B * H)), dim3(256), 0, (hipStream_t)stream, dy, dh_rec, dc_carry,
+                       act, c_all, B, S, H, k, first);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_x_embed_prompt_fwd(const int64_t* ids, const int32_t* src, const float* prompt, const float* word,
+                                       const float* pos, const float* typ, const float* gamma, const float* beta, float* y,
+                                       float* xhat, float* rstd, int32_t B, int32_t S_in, int32_t S, int32_t P, int32_t H,
+                                       int32_t pos_offset, float eps, void* stream) {
+    if (!ids || !src || !prompt || !word || !pos || !typ || !gamma || !beta || !y) return ICKA_E_ARG;
+    if (B <= 0 || S_in <= 0 || S <= 0 || P <= 0 || H <= 0 || pos_offset < 0) return ICKA_E_SHAPE;
+    const int M = B * S;
+    hipLaunchKernelGGL(xembed_prompt_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, src, prompt, word,
+                       pos, typ, gamma, beta, y, xhat, rstd, M, S_in, S, P, H, pos_offset, eps);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_x_embed_prompt_scatter(const float* dpre, const int64_t* ids, const int32_t* src, float* dword, float* dpos,
+                                           float* dtyp, float* dprompt, int32_t B, int32_t S_in, int32_t S, int32_t P,
+                                           int32_t H, int32_t pos_offset, int32_t padding_idx, void* stream) {
+    if (!dpre || !ids || !src || !dword || !dpos || !dtyp || !dprompt) return ICKA_E_ARG;
+    if (B <= 0 || S_in <= 0 || S <= 0 || P <= 0 || H <= 0 || pos_offset < 0) return ICKA_E_SHAPE;
+    const int M = B * S;
+    hipLaunchKernelGGL(xembed_prompt_scatter_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dpre, ids, src, dword,
+                       dpos, dtyp, dprompt, M, S_in, S, P, H, pos_offset, padding_idx);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -690,3 +690,157 @@ def regions_to_tokens(v: torch.Tensor, B: int, R: int, layout: int) -> torch.Ten
     check(_lib.load().icka_x_regions_to_tokens(v.data_ptr(), out.data_ptr(), B, R, 2048, layout, _stream()),
           "icka_x_regions_to_tokens")
     return out
+
+
+# =============================================================================================== section 8(f) rows
+class FanOutFn(torch.autograd.Function):
+    """y1 = y2 = ... = x for a tensor with several consumers; the backward sums the branch gradients with icka_x_add."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        acc = None
+        for g in grads:
+            if g is None:
+                continue
+            g = _cf(g)
+            if acc is None:
+                acc = g
+            else:
+                g2, a2 = g.view(-1, g.shape[-1]), acc.view(-1, g.shape[-1])
+                out = torch.empty_like(a2)
+                check(_lib.load().icka_x_add(a2.data_ptr(), a2.stride(0), g2.data_ptr(), g2.stride(0), out.data_ptr(),
+                                             out.stride(0), a2.shape[0], a2.shape[1], _stream()), "icka_x_add")
+                acc = out.view(g.shape)
+        return acc, None
+
+
+class LstmFn(torch.autograd.Function):
+    """nn.LSTM(H_in, H, batch_first=True, bidirectional=True) (Cross_Modal_Interaction_Module.py:905-908, call :1042) in
+    f32: input projection of all steps and both directions = one GEMM; per step one batched (2 directions) recurrent GEMM
+    accumulating into the gate buffer + one pointwise cell launch; backward the same in reverse, then the weight / bias /
+    input gradients as GEMMs and column sums over all steps."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, mod, A: ParamArena, B: int, S: int):
+        H = mod.hidden_size
+        M = B * S
+        lib = _lib.load()
+        wih = (mod.weight_ih_l0, mod.weight_ih_l0_reverse)
+        whh = _fw(A, (mod.weight_hh_l0, mod.weight_hh_l0_reverse))            # [2*4H, H]
+        bsum = _new(x, 1, 8 * H)
+        bi, bh = _fb(A, (mod.bias_ih_l0, mod.bias_ih_l0_reverse)), _fb(A, (mod.bias_hh_l0, mod.bias_hh_l0_reverse))
+        check(lib.icka_x_add(bi.data_ptr(), 8 * H, bh.data_ptr(), 8 * H, bsum.data_ptr(), 8 * H, 1, 8 * H, _stream()),
+              "icka_x_add")
+        gates = gemm(GEMM_NT, x, _fw(A, wih), _new(x, M, 8 * H), bias=bsum.view(-1))
+        y, c_all, hprev = _new(x, M, 2 * H), _new(x, M, 2 * H), _new(x, M, 2 * H)
+        for k in range(S):
+            if k:
+                # gates[b, t_dir, dir] += h_{t-1, dir} . W_hh_dir^T ; forward direction t = k (previous k-1), reverse
+                # direction t = S-1-k (previous S-k): the two problems differ by constant element offsets
+                a0, a1 = (k - 1) * 2 * H, (S - k) * 2 * H + H
+                c0, c1 = k * 8 * H, (S - 1 - k) * 8 * H + 4 * H
+                gemm_raw(GEMM_NT, B, 4 * H, H, y.view(-1)[a0:], S * 2 * H, (a1 - a0, 0), whh, H, (4 * H * H, 0),
+                         gates.view(-1)[c0:], S * 8 * H, (c1 - c0, 0), 2, 1, beta=1.0)
+            check(lib.icka_x_lstm_cell_fwd(gates.data_ptr(), c_all.data_ptr(), y.data_ptr(), hprev.data_ptr(), B, S, H, k,
+                                           _stream()), "icka_x_lstm_cell_fwd")
+        ctx.mod, ctx.A, ctx.dims = mod, A, (B, S, H)
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(x, gates, c_all, hprev)
+        ctx.mark_non_differentiable(c_all)
+        return y, c_all
+
+    @staticmethod
+    def backward(ctx, dy, _dc):
+        x, act, c_all, hprev = ctx.saved_tensors
+        mod, A = ctx.mod, ctx.A
+        B, S, H = ctx.dims
+        lib = _lib.load()
+        dy = _cf(dy)
+        whh = _fw(A, (mod.weight_hh_l0, mod.weight_hh_l0_reverse))
+        dgates = act                               # the saved activations are consumed in place (one backward per forward)
+        dh, dc = _new(x, 2, B, H), _new(x, 2, B, H)
+        for k in range(S - 1, -1, -1):
+            check(lib.icka_x_lstm_cell_bwd(dy.data_ptr(), dh.data_ptr(), dc.data_ptr(), dgates.data_ptr(), c_all.data_ptr(),
+                                           B, S, H, k, int(k == S - 1), _stream()), "icka_x_lstm_cell_bwd")
+            if k:
+                # dh_rec[dir] = dgates[b, t_dir, dir] . W_hh_dir   (reaches h of step k-1)
+                c0, c1 = k * 8 * H, (S - 1 - k) * 8 * H + 4 * H
+                gemm_raw(GEMM_NN, B, H, 4 * H, dgates.view(-1)[c0:], S * 8 * H, (c1 - c0, 0), whh, H, (4 * H * H, 0),
+                         dh, H, (B * H, 0), 2, 1)
+        wih = (mod.weight_ih_l0, mod.weight_ih_l0_reverse)
+        gemm(GEMM_TN, dgates, x, A.g_cat(wih), beta=A.grad_beta(wih))
+        for d, w in enumerate((mod.weight_hh_l0, mod.weight_hh_l0_reverse)):
+            gemm(GEMM_TN, dgates[:, d * 4 * H:(d + 1) * 4 * H], hprev[:, d * H:(d + 1) * H], A.g(w), beta=A.grad_beta(w))
+        for bs in ((mod.bias_ih_l0, mod.bias_ih_l0_reverse), (mod.bias_hh_l0, mod.bias_hh_l0_reverse)):
+            colsum(dgates, A.g_cat(bs), accumulate=A.grad_beta(bs) > 0)
+        dx = gemm(GEMM_NN, dgates, _fw(A, wih), torch.empty_like(x)) if ctx.need_dx else None
+        A.flush_final()
+        return None, dx, None, None, None, None
+
+
+class PromptEmbeddingsFn(torch.autograd.Function):
+    """Embeddings of the prompt-accepting encoder stage in f32 (see ops.PromptEmbeddingsFn)."""
+
+    @staticmethod
+    def forward(ctx, anchor, prompt, mod, A: ParamArena, ids, src, d, pos_offset: int):
+        B, S_in = ids.shape
+        S, H = src.shape[0], d.H
+        prompt = _cf(prompt)
+        y = torch.empty(B * S, H, dtype=F32, device=ids.device)
+        xhat = torch.empty_like(y)
+        rstd = torch.empty(B * S, dtype=F32, device=ids.device)
+        check(_lib.load().icka_x_embed_prompt_fwd(ids.data_ptr(), src.data_ptr(), prompt.data_ptr(),
+                                                  mod.word_embeddings.weight.data_ptr(),
+                                                  mod.position_embeddings.weight.data_ptr(),
+                                                  mod.token_type_embeddings.weight.data_ptr(), mod.LayerNorm.weight.data_ptr(),
+                                                  mod.LayerNorm.bias.data_ptr(), y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+                                                  B, S_in, S, prompt.shape[1], H, pos_offset, d.eps, _stream()),
+              "icka_x_embed_prompt_fwd")
+        seed = A.next_seed() if d.p_hidden > 0 else 0
+        if d.p_hidden > 0:
+            y = dropout(y, d.p_hidden, seed)
+        ctx.mod, ctx.A, ctx.d, ctx.seed, ctx.pos_offset, ctx.pshape = mod, A, d, seed, pos_offset, tuple(prompt.shape)
+        ctx.save_for_backward(ids, src, xhat, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import kernels as K
+        mod, A, d = ctx.mod, ctx.A, ctx.d
+        ids, src, xhat, rstd = ctx.saved_tensors
+        dy = _cf(dy)
+        if d.p_hidden > 0:
+            dy = dropout(dy, d.p_hidden, ctx.seed)
+        ln = mod.LayerNorm
+        colsum(dy, A.g(ln.weight), b=xhat, accumulate=A.grad_beta(ln.weight) > 0)
+        colsum(dy, A.g(ln.bias), accumulate=A.grad_beta(ln.bias) > 0)
+        dpre, _ = ln_bwd(dy, xhat, rstd, ln.weight)
+        tables = (mod.word_embeddings.weight, mod.position_embeddings.weight, mod.token_type_embeddings.weight)
+        for t in tables:
+            if A.grad_beta(t) == 0.0:
+                K.zero_(A.g(t).view(-1))
+        dprompt = torch.empty(ctx.pshape, dtype=F32, device=dy.device)
+        pad = mod.word_embeddings.padding_idx
+        B, S_in = ids.shape
+        check(_lib.load().icka_x_embed_prompt_scatter(dpre.data_ptr(), ids.data_ptr(), src.data_ptr(),
+                                                      A.g(tables[0]).data_ptr(), A.g(tables[1]).data_ptr(),
+                                                      A.g(tables[2]).data_ptr(), dprompt.data_ptr(), B, S_in, src.shape[0],
+                                                      ctx.pshape[1], d.H, ctx.pos_offset, -1 if pad is None else pad, _stream()),
+              "icka_x_embed_prompt_scatter")
+        A.flush_final()
+        return None, dprompt, None, None, None, None, None, None
+
+
+def prompt_mapping(A: ParamArena, x, lin1, lin2, p: float):
+    """nn.Sequential(Dropout(p), Linear, Tanh(), Dropout(p), Linear) (Cross_Modal_Interaction_Module.py:914-928)."""
+    if p > 0:
+        x = DropoutFn.apply(x, A, p)
+    h = LinearFn.apply(A.anchor, x, lin1, A, True)
+    if p > 0:
+        h = DropoutFn.apply(h, A, p)
+    return LinearFn.apply(A.anchor, h, lin2, A, False)

@@ -85,6 +85,7 @@ class BiLSTM(ArenaModule):
                              "biases and no dropout (Cross_Modal_Interaction_Module.py:905-908)")
         if hidden_size % 32 or input_size % 8:
             raise ValueError("hidden_size must be a multiple of 32 and input_size of 8 (MFMA / 16-byte tiles)")
+        self.config = None
         self.input_size, self.hidden_size, self.batch_first = input_size, hidden_size, batch_first
         H = hidden_size
         for sfx in ("", "_reverse"):
@@ -116,10 +117,14 @@ class BiLSTM(ArenaModule):
         B, S, _ = x.shape
         if B > 64:
             raise ValueError("at most 64 sequences per call")
-        from .modeling import _hidden2d
+        from .modeling import _hidden2d, _is_exact
         A = self._arena()
         H = self.hidden_size
-        y, c_all = _LstmFn.apply(A.anchor, _hidden2d(x, "input"), self, A, B, S)
+        if _is_exact(self):     # fp32 mode: f32 in / out, per-step f32 GEMMs (icka_amd/exact.py)
+            from . import exact as X
+            y, c_all = X.LstmFn.apply(A.anchor, _hidden2d(x, "input", True), self, A, B, S)
+        else:
+            y, c_all = _LstmFn.apply(A.anchor, _hidden2d(x, "input"), self, A, B, S)
         out = y.view(B, S, 2 * H)
         # h_n / c_n as nn.LSTM: [2, B, H] -- forward direction's last step, reverse direction's step at t = 0
         c4 = c_all.view(B, S, 2, H)

@@ -798,7 +798,10 @@ class MTCCMBertForMMTokenClassificationCRF_gate_1(BertPreTrainedModel):
         A, _, _, cross, _ = _mner_trunk(self, ori_input_ids, ori_segment_ids, ori_input_mask, added_attention_mask,
                                         visual_embeds_att)
         x, _ = self.lstm(cross.view(B, S, self.hidden_size))
-        em = ops.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * self.hidden_size), self.classifier, A, True, K.EPI_NONE)
+        if _is_exact(self):
+            em = X.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * self.hidden_size), self.classifier, A, False)
+        else:
+            em = ops.LinearFn.apply(A.anchor, x.reshape(B * S, 2 * self.hidden_size), self.classifier, A, True, K.EPI_NONE)
         return em.view(B, S, self.num_labels)
 
     def forward(self, input_ids, segment_ids, input_mask, ori_input_ids, ori_input_mask, ori_segment_ids,

@@ -435,6 +435,26 @@ int icka_x_sample_gate_fwd(const float* a, int64_t lda, const float* c, int64_t 
 int icka_x_sample_gate_bwd(const float* dout, int64_t lddo, const float* a, int64_t lda, const float* c, int64_t ldc,
                            const float* gate, int32_t mode, float* da, int64_t ldda, float* dc, int64_t lddc,
                            float* dgate, int32_t B, int32_t S, int32_t H, void* stream);
+/* BiLSTM recurrence of the fp32 mode (nn.LSTM(H, H, batch_first=True, bidirectional=True), :905-908, call :1042).  The
+ * gate pre-activations of step k are accumulated into gates [B*S, 8H] (= x.W_ih^T + b_ih + b_hh for all steps, both
+ * directions: [i f g o | i f g o]) by icka_x_gemm with beta = 1 (h_{t-1} . W_hh^T, batched over the two directions);
+ * cell_fwd then applies the cell update of step k for both directions (forward direction t = k, reverse t = S-1-k):
+ * gates <- activations (saved), c_all / y [B*S, 2H] <- c_t / h_t, hprev <- the h_{t-1} it used (zeros at k = 0).
+ * cell_bwd (k = S-1 .. 0): act <- gate pre-activation gradients in place, from dy, the gradient dh_rec [2,B,H] that
+ * reached h_t through the next step's recurrent product (first != 0: none yet) and the cell-state carry dc_carry [2,B,H]. */
+int icka_x_lstm_cell_fwd(float* gates, float* c_all, float* y, float* hprev, int32_t B, int32_t S, int32_t H, int32_t k,
+                         void* stream);
+int icka_x_lstm_cell_bwd(const float* dy, const float* dh_rec, float* dc_carry, float* act, const float* c_all, int32_t B,
+                         int32_t S, int32_t H, int32_t k, int32_t first, void* stream);
+/* f32 twins of icka_embed_prompt_fwd / _bwd (the LayerNorm parameter gradients come from icka_x_colsum; the scatter
+ * takes the LayerNorm-input gradient; dprompt f32 [B,P,H], every row written exactly once) */
+int icka_x_embed_prompt_fwd(const int64_t* ids, const int32_t* src, const float* prompt, const float* word, const float* pos,
+                            const float* typ, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
+                            int32_t B, int32_t S_in, int32_t S, int32_t P, int32_t H, int32_t pos_offset, float eps,
+                            void* stream);
+int icka_x_embed_prompt_scatter(const float* dpre, const int64_t* ids, const int32_t* src, float* dword, float* dpos,
+                                float* dtyp, float* dprompt, int32_t B, int32_t S_in, int32_t S, int32_t P, int32_t H,
+                                int32_t pos_offset, int32_t padding_idx, void* stream);
 /* f32 twins of icka_token_ce / icka_scale_by_ratio (dlogits f32 [M,C] contiguous, unscaled) */
 int icka_x_token_ce(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* loss_sum,
                     float* count, float* dlogits, int32_t M, int32_t C, void* stream);

@@ -223,3 +223,74 @@ def test_fp32_mode_other_head_size():
     assert (pooled.cpu() - ref_pooled).abs().max().item() < FP32_TOL
     with pytest.raises(ValueError):
         icka_amd.set_precision(m, "bf16")(b["input_ids"].cuda(), b["segment_ids"].cuda(), b["input_mask"].cuda())
+
+
+# ----------------------------------------------------------------------------------------- SURVEY.md section 8(f) rows
+@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (3, 40, 256), (8, 24, 1024)])
+def test_fp32_bilstm_against_aten(B, S, H):
+    """nn.LSTM on the CPU (the arithmetic the reference itself calls, :905-908) vs the fp32-mode BiLSTM."""
+    import icka_amd
+    from icka_amd.lstm import BiLSTM
+    torch.manual_seed(B * 100 + S)
+    ref = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
+    mine = BiLSTM(H, H)
+    mine.load_state_dict(ref.state_dict())
+    mine = icka_amd.set_precision(mine.cuda(), "fp32")
+    x = torch.randn(B, S, H) * 0.5
+    xg = x.cuda().requires_grad_(True)
+    out, (h_n, c_n) = mine(xg)
+    xr = x.clone().requires_grad_(True)
+    ro, (rh, rc) = ref(xr)
+    assert out.dtype == torch.float32
+    err = (out.cpu() - ro).abs().max().item()
+    assert err < 1e-5, err
+    assert (h_n.cpu() - rh).abs().max().item() < 1e-5 and (c_n.cpu() - rc).abs().max().item() < 1e-5
+    w = torch.randn(B, S, 2 * H, generator=torch.Generator().manual_seed(1))
+    (out * w.cuda()).sum().backward()
+    (ro * w).sum().backward()
+    worst = _rel(xg.grad.cpu(), xr.grad)
+    for n, p in mine.named_parameters():
+        worst = max(worst, _rel(p.grad.cpu(), dict(ref.named_parameters())[n].grad))
+    print("\n[fp32 BiLSTM B%d S%d H%d] max abs out err %.3e, worst gradient rel-L2 %.3e" % (B, S, H, err, worst))
+    assert worst < 1e-4
+
+
+def test_fp32_published_model_against_reference_fixture():
+    """The reference's published model (Cross_Modal_Interaction_Module.py:887-1057) in fp32 mode: emissions of the
+    fixture made by the reference's own forward within 1e-3, loss and every parameter gradient against the CPU oracle."""
+    import os
+    import icka_amd
+    from test_cross_modal_cpu import build_case, oracle_emissions
+    from test_cross_modal_gpu import _args
+    from oracle import crf_oracle as OC
+    fx = np.load(os.path.join(GOLDEN_DIR, "cross_modal_h1024_l1.npz"))
+    model, ocfg, ocfg_r, b = build_case(fx)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = icka_amd.set_precision(model.cuda().eval(), "fp32")
+    g = {k: v.cuda() for k, v in b.items()}
+    em = model(**_args(g))
+    ref = torch.from_numpy(fx["emissions"])
+    err = (em.cpu() - ref).abs().max().item()
+    loss = model(mode="train", **_args(g))
+    loss.backward()
+    oem, _ = oracle_emissions(P, ocfg, ocfg_r, b)
+    mask = b["output_mask"].bool()
+    crfP = [P["crf.start_transitions"], P["crf.end_transitions"], P["crf.transitions"]]
+    rloss = -OC.crf_reduce(OC.crf_llh(oem, b["labels"], mask, *crfP), mask, "token_mean")
+    rloss.backward()
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst, wkey, n = 0.0, "", 0
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        rel = ((p.grad.cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item()
+        n += 1
+        if rel > worst:
+            worst, wkey = rel, k
+    print("\n[fp32 published model] emissions vs reference fixture max abs err %.3e (tol %.0e), loss %.6f (oracle %.6f), worst "
+          "gradient rel-L2 %.3e at %s over %d tensors" % (err, FP32_TOL, loss.item(), rloss.item(), worst, wkey, n))
+    assert err < FP32_TOL
+    assert abs(loss.item() - rloss.item()) < FP32_TOL
+    assert n > 100 and worst < GRAD_TOL, (wkey, worst)
+    assert model(mode="test", **_args(g)) == OC.crf_decode(em.cpu(), mask, *[p.detach() for p in crfP])
