@@ -294,3 +294,50 @@ def test_fp32_published_model_against_reference_fixture():
     assert abs(loss.item() - rloss.item()) < FP32_TOL
     assert n > 100 and worst < GRAD_TOL, (wkey, worst)
     assert model(mode="test", **_args(g)) == OC.crf_decode(em.cpu(), mask, *[p.detach() for p in crfP])
+
+
+def test_fp32_gate1_tagger_against_cpu_composition():
+    """`_gate_1` (trunk -> BiLSTM -> classifier -> CRF, :2383-2483) in fp32 mode vs trunk oracle + ATen nn.LSTM + CRF oracle."""
+    import torch.nn.functional as F
+    import icka_amd
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF_gate_1
+    from oracle import crf_oracle as OC
+    from oracle import mner_oracle as O
+    B, S, H, C = 4, 32, 128, 13
+    cfg = BertConfig(512, hidden_size=H, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=64)
+    model = MTCCMBertForMMTokenClassificationCRF_gate_1(cfg, num_labels=C)
+    synth.fill_module_(model)
+    with torch.no_grad():
+        for n, p in model.lstm.named_parameters():
+            p.mul_(4.0)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = icka_amd.set_precision(model.cuda().eval(), "fp32")
+    b = synth.synthetic_batch(B, S, 49, vocab_size=512, seed=3, layout="BCHW")
+    g = {k: v.cuda() for k, v in b.items()}
+    args = dict(input_ids=g["input_ids"], segment_ids=g["segment_ids"], input_mask=g["input_mask"],
+                ori_input_ids=g["input_ids"], ori_input_mask=g["input_mask"], ori_segment_ids=g["segment_ids"],
+                added_attention_mask=g["added_attention_mask"], visual_embeds_att=g["visual_embeds_att"],
+                output_mask=g["input_mask"], labels=g["labels"])
+    em = model(**args)
+    loss = model(mode="train", **args)
+    loss.backward()
+    ocfg = O.OracleConfig(vocab_size=512, hidden_size=H, num_hidden_layers=2, num_attention_heads=2,
+                          intermediate_size=256, max_position_embeddings=64)
+    _, cross, _ = O.mner_trunk(P, ocfg, b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
+                               b["visual_embeds_att"], 1, 49, False)
+    lstm = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
+    x, _ = torch.func.functional_call(lstm, {k[len("lstm."):]: v for k, v in P.items() if k.startswith("lstm.")}, (cross,))
+    ref_em = F.linear(x, P["classifier.weight"], P["classifier.bias"])
+    mask = b["input_mask"].bool()
+    crfP = [P["crf.start_transitions"], P["crf.end_transitions"], P["crf.transitions"]]
+    rloss = -OC.crf_reduce(OC.crf_llh(ref_em, b["labels"], mask, *crfP), mask, "token_mean")
+    rloss.backward()
+    err = (em.cpu() - ref_em.detach()).abs().max().item()
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst = max(((p.grad.cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item()
+                for k, p in model.named_parameters() if P[k].grad is not None)
+    print("\n[fp32 _gate_1 tagger] emissions max abs err %.3e, loss %.6f (oracle %.6f), worst gradient rel-L2 %.3e"
+          % (err, loss.item(), rloss.item(), worst))
+    assert err < FP32_TOL and abs(loss.item() - rloss.item()) < FP32_TOL and worst < GRAD_TOL
