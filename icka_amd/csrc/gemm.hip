@@ -985,6 +985,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     // MFMA tile cover 64 contiguous bytes per row; the stores of adjacent tiles merge in L2.  This skips two block barriers and
     // 128 KB of LDS traffic of the staged epilogue below, and the loader waves retire at once.
     if (g_direct_epilogue(g)) {
+#ifdef ICKA_GEMM_STAMP
+        if (g.stamp && lane == 0 && wave == 0) {
+            unsigned long long* o = g.stamp + (size_t)bid * 16 + 11;
+            o[0] = ph1 - ph0; o[1] = ph2 - ph1; o[2] = 0;
+        }
+#endif
         if (wave < 4) {
             if (do_cs && lane < 16) {
 #pragma unroll
@@ -1229,8 +1235,8 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
     }
     if (aligned) {
 #ifdef ICKA_GEMM_ABLATE
-        if (g_abl == 1) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(256), 0, st, g);
-        else if (g_abl == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(256), 0, st, g);
+        if (g_abl == 1 && !g_ws) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(256), 0, st, g);
+        else if (g_abl == 2 && !g_ws) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(256), 0, st, g);
         else
 #endif
         {
@@ -1239,6 +1245,11 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
             // tools/gemm_bench.py)
             if (g_ws) {
 #ifdef ICKA_GEMM_ABLATE
+                if (g_bn == 96 && g.n96ok) {   // the 128x96-tile kernel (icka_gemm_set_tile_n(96))
+                    const int nb96 = (g.M / BM) * (g.N / 96);
+                    if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                    if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                }
                 if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
 #endif

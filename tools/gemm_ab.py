@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""A/B of one library knob on the N = 768 GEMM shapes of the c2 step, COLD operands (12 buffer sets), variants
+interleaved round by round in one process (median over rounds).  usage: gemm_ab.py knob v0 v1 [...]
+knob: ring | tile_n | direct"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from icka_amd import _lib, kernels as K  # noqa: E402
+
+BF16 = torch.bfloat16
+lib = _lib.load()
+knob = sys.argv[1]
+vals = [int(v) for v in sys.argv[2:]]
+setter = {"ring": lib.icka_gemm_set_ring,
+          "tile_n": lib.icka_gemm_set_tile_n, "direct": lib.icka_gemm_set_direct_epilogue}[knob]
+
+
+def timed(fn, sets, reps=3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for s in sets:
+            fn(*s)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * len(sets))
+
+
+SHAPES = (("outproj NT f32", "NT", 4096, 768, 768, True), ("ffndn NT f32", "NT", 4096, 768, 3072, True),
+          ("dffnup NN bf16", "NN", 4096, 768, 3072, False), ("dqkv NN bf16", "NN", 4096, 768, 2304, False),
+          ("dout NN bf16", "NN", 4096, 768, 768, False), ("ffnup NT bf16", "NT", 4096, 3072, 768, False))
+for name, op, M, N, Kd, f32 in SHAPES:
+    sets = []
+    for _ in range(12):
+        A = torch.randn(M, Kd, device="cuda").to(BF16)
+        B = (torch.randn(N, Kd, device="cuda") if op == "NT" else torch.randn(Kd, N, device="cuda")).to(BF16)
+        sets.append((A, B, torch.empty(M, N, dtype=torch.float32 if f32 else BF16, device="cuda")))
+    kop = {"NT": K.GEMM_NT, "NN": K.GEMM_NN}[op]
+    ref = None
+    res = {v: [] for v in vals}
+    for rnd in range(7):
+        for v in vals:
+            assert setter(v) == 0
+            t = timed(lambda A, B, o: K.gemm(kop, A, B, o), sets)
+            if rnd:
+                res[v].append(t)
+            out = sets[0][2].float().clone()
+            if ref is None:
+                ref = (sets[0][0].float() @ (sets[0][1].float().t() if op == "NT" else sets[0][1].float()))
+            err = ((out - ref).norm() / ref.norm()).item()
+            assert err < 1e-2, (name, v, err)
+    setter(0)
+    fl = 2.0 * M * N * Kd
+    line = "%-15s %4dx%4dx%4d " % (name, M, N, Kd)
+    for v in vals:
+        r = sorted(res[v])
+        med = r[len(r) // 2]
+        line += "| %s=%d %6.1f us (min %5.1f) %6.1f TF/s " % (knob, v, med, r[0], fl / med * 1e-6)
+    print(line, flush=True)

@@ -33,6 +33,9 @@ for name, op, M, N, Kd in (("Wo TN", K.GEMM_TN, 768, 768, 4096), ("ffndn NT", K.
     b = buf.double().cpu()
     b = b[b[:, 6] > 0]
     nb = b.shape[0]
+    if nb == 0:
+        print("%-10s (kernel without stamps)" % name)
+        continue
     nk = b[:, 6].mean().item()
     tot = b[:, 4]
     clk = (b[:, 4] / b[:, 5] * 100.0).median().item()   # MHz
@@ -70,6 +73,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "chain":
         torch.cuda.synchronize()
         b = buf.double().cpu()
         b = b[b[:, 6] > 0]
+        if b.shape[0] == 0:
+            print("chain %-8s (kernel without stamps)" % seq[target][0])
+            continue
         nk = b[:, 6].mean().item()
         per = b[:, :4].mean(0) / nk
         ph = b[:, 11:14].mean(0)
