@@ -209,6 +209,8 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in icka_amd)")
+    if os.environ.get("ICKA_BENCH_ONE_GPU"):   # rehearsal of the N > 1 flow on a one-GPU box (with ICKA_BENCH_BACKEND=gloo)
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
@@ -218,7 +220,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("ICKA_BENCH_BACKEND", "nccl")   # "nccl" = RCCL; gloo only for the one-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from icka_amd import kernels as K
     from icka_amd import synth
