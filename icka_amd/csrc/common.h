@@ -180,6 +180,17 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// the same fragment registers holding IEEE fp16 operands (v_mfma_f32_16x16x32_f16, same rate and layout)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16t(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return mfma16(a, b, c);
+}
+
 // LDS reads
 __device__ __forceinline__ bf16x8 lds_read_b128(const char* base, uint32_t off) {
     return *reinterpret_cast<const bf16x8*>(base + off);

@@ -42,6 +42,9 @@ struct GemmArgs {
     int direct;                 // plain outputs skip the LDS-staged epilogue (icka_gemm_set_direct_epilogue)
     unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
+    int f16;           // operands are IEEE fp16 (v_mfma_f32_16x16x32_f16; NT only): the "mixed16" forward GEMMs
+    int c_f16;         // main output C is fp16 (c_f32 == 0)
+    bf16_t* C3; int64_t ldc3;   // optional bf16 copy of the main output (the weight-gradient operand of an fp16 activation)
 };
 
 // k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
@@ -200,6 +203,11 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
             for (int r = 0; r < 4; ++r)
                 if (r < nvalid) p[r] = v[r] + (g.beta != 0.f ? g.beta * p[r] : 0.f);
         }
+    } else if (g.c_f16) {
+        _Float16* p = reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n;
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) p[r] = (_Float16)fminf(fmaxf(v[r], -65504.f), 65504.f);
+        if (g.C3) store4_bf16(g.C3, g.ldc3, m, n, nvalid, v);
     } else {
         bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
         if (g.beta != 0.f) {
@@ -226,7 +234,7 @@ __device__ __forceinline__ void fetch_tiles(const GemmArgs& g, int kt, int m0, i
     g2r<B_KM, ALIGNED>(rb, Bp, lb, n0, g.N, k0, klim, tid, g.b_vec);
 }
 
-template <bool A_KM, bool B_KM, bool ALIGNED>
+template <bool A_KM, bool B_KM, bool ALIGNED, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;  // local copy: lets SROA scalarise the descriptor instead of spilling the kernarg struct
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [2 buffers][A tile | B tile]
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs gp) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
         }
         if (kt + 1 < nk) {
             char* dA = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
@@ -433,6 +441,16 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     st_out(reinterpret_cast<u32x4*>(p), as_u32x4(o));
 }
 
+// fp16 outputs saturate at the largest finite half instead of overflowing to inf (an inf would turn the next LayerNorm
+// row into NaNs); real BERT activations stay orders of magnitude below it.
+__device__ __forceinline__ _Float16 f2h(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ void store8_f16(void* p, const float (&v)[8]) {
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2h(v[e]);
+    st_out(reinterpret_cast<u32x4*>(p), __builtin_bit_cast(u32x4, o));
+}
+
 // Block -> output tile.  Blocks b and b+8 share an XCD (round-robin dispatch); each XCD has a private 4 MiB L2.
 //  * few column tiles: every XCD takes a contiguous run of row-major tiles (its A row panels + all of B stay in L2);
 //  * many column tiles (N >= 1536): the 8 XCDs form a 4 x 2 grid over the tile matrix, so an XCD touches nbm/4 A
@@ -541,6 +559,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
             }
             st_out(reinterpret_cast<f32x4*>(p), o0);
             st_out(reinterpret_cast<f32x4*>(p + 4), o1);
+        } else if (g.c_f16) {   // fp16 main output (+ optional bf16 copy); beta is rejected on the host
+            store8_f16(reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n, v);
+            if (g.C3) store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, v);
         } else {
             bf16_t* p = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
             if (g.beta != 0.f) {
@@ -750,7 +771,7 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -882,7 +903,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+                        for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
                     if (do_cs) {
 #pragma unroll
                         for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, fa[mi], cs[mi]);
@@ -902,7 +923,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #define ICKA_MMA(FA, FB)                                                                             \
     if (ABL != 1) do {                                                                               \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-            _Pragma("unroll") for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16(FB[ni], FA[mi], acc[mi][ni]); \
+            _Pragma("unroll") for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16t<F16>(FB[ni], FA[mi], acc[mi][ni]); \
         if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, FA[mi], cs[mi]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
@@ -919,7 +940,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         _Pragma("unroll") for (int t = 0; t < 4; ++t) RA[t] = read_frag<A_KM>(b_, wr + 16 * t, KS, lane);              \
         _Pragma("unroll") for (int t = 0; t < NTN; ++t) RB[t] = read_frag<B_KM>(b_ + TILE_BYTES, wc + 16 * t, KS, lane); \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-            _Pragma("unroll") for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16(MB[ni], MA[mi], acc[mi][ni]); \
+            _Pragma("unroll") for (int ni = 0; ni < NTN; ++ni) acc[mi][ni] = mfma16t<F16>(MB[ni], MA[mi], acc[mi][ni]); \
         if constexpr (NR_ > NM_) __builtin_amdgcn_sched_group_barrier(0x100, NR_ - NM_, 0);          \
         _Pragma("unroll") for (int i_ = 0; i_ < NP_; ++i_) {                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
@@ -1050,21 +1071,21 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT>(g, smem, blockIdx.x, gridDim.x);
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
 // tiles per CU one block's prologue (first DMA latency, ~2.8k cycles) and epilogue (~5.5k) overlap the other
 // block's main loop (stamps: at K = 768 they are 40 % of a tile's time).
-template <bool A_KM, bool B_KM, int BNT = 128>
+template <bool A_KM, bool B_KM, int BNT = 128, bool F16 = false>
 __global__ __launch_bounds__(512, 4) void gemm_ws2_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, 2, 0, 1, BNT>(g, smem, blockIdx.x, gridDim.x);
+    gemm_ws_body<A_KM, B_KM, 2, 0, 1, BNT, F16>(g, smem, blockIdx.x, gridDim.x);
 }
 
 template <bool A_KM, bool B_KM, int NBUF, int ABL>
@@ -1120,7 +1141,7 @@ __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) 
 // straight from the accumulators through the general 4-column epilogue.  A is k-contiguous (NT and NN).
 constexpr int W3_A = 2 * TILE_BYTES, W3_B = 2 * TILE_BYTES;   // one k-tile of A (2 x 128 rows) / of B (2 x 96 columns)
 constexpr int W3_NA = 3, W3_NB = 2;                           // ring depths: 3 x 32 KiB + 2 x 32 KiB = 160 KiB = the whole LDS
-template <bool B_KM>
+template <bool B_KM, bool F16 = false>
 __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
@@ -1196,7 +1217,7 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = mfma16(fb[ni], fa[mi], acc[mi][ni]);
+                    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
             }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
@@ -1223,12 +1244,12 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool F16 = false>
 int launch(GemmArgs g, bool aligned, hipStream_t st) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if constexpr (!A_KM && !B_KM) {
         if (!aligned && g.n64ok && g_ws) {   // 64-channel convolutions of the ResNet stem / layer1: 128x64 tiles
-            hipLaunchKernelGGL((gemm_ws_kernel<false, false, 3, 0, 64>), dim3((g.M / BM) * (g.N / 64)), dim3(512), 0, st, g);
+            hipLaunchKernelGGL((gemm_ws_kernel<false, false, 3, 0, 64, F16>), dim3((g.M / BM) * (g.N / 64)), dim3(512), 0, st, g);
             ICKA_CHECK_LAUNCH();
             return 0;
         }
@@ -1243,7 +1264,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
             // ring depth: many tiles per CU -> two co-resident blocks (64 KiB ring of 2) overlap one block's
             // epilogue with the other's main loop; few tiles -> one block per CU with a deeper ring (measured,
             // tools/gemm_bench.py)
-            if (g_ws) {
+            if (g_ws || F16) {   // (fp16 operands exist on the warp-specialised kernels only)
 #ifdef ICKA_GEMM_ABLATE
                 if (g_bn == 96 && g.n96ok) {   // the 128x96-tile kernel (icka_gemm_set_tile_n(96))
                     const int nb96 = (g.M / BM) * (g.N / 96);
@@ -1260,7 +1281,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     const int rounds3 = (nb3 + 255) / 256;
                     if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
                         nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
-                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM>), dim3(nb3), dim3(768), 0, st, g);
+                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }
@@ -1273,13 +1294,13 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     const int nb96 = (g.M / BM) * (g.N / 96);
                     if (g_bn == 96 || (nb < 256 && nb96 <= 256 && nb96 > nb)) {
                         if ((g_ws == 2 || (g_ws == 1 && nb96 >= 448 && g.K <= 1024)) && !A_KM)
-                            hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_nbuf == 4)
+                            hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
+                        else if (g_nbuf == 4 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_nbuf == 5)
+                        else if (g_nbuf == 5 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else
-                            hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
+                            hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }
@@ -1287,10 +1308,10 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 // measured (tools/gemm_bench.py): two co-resident blocks win only for short reductions on grids of
                 // >= ~2 tiles per CU (qkv, ffn-up, d-ffn-down); long-K shapes prefer the deeper ring of one block
                 if ((g_ws == 2 || (g_ws == 1 && nb >= 448 && g.K <= 1024)) && !A_KM)
-                    hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM>), dim3(nb), dim3(512), 0, st, g);
-                else if (g_nbuf == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
-                else if (g_nbuf == 5) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5>), dim3(nb), dim3(512), 0, st, g);
-                else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3>), dim3(nb), dim3(512), 0, st, g);
+                    hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 128, F16>), dim3(nb), dim3(512), 0, st, g);
+                else if (g_nbuf == 4 && !F16) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
+                else if (g_nbuf == 5 && !F16) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5>), dim3(nb), dim3(512), 0, st, g);
+                else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 128, F16>), dim3(nb), dim3(512), 0, st, g);
                 ICKA_CHECK_LAUNCH();
                 return 0;
             }
@@ -1320,7 +1341,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
             g.beta = 0.f;
             g.ksplit = ks;
         }
-        hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, false>), dim3(nb, ks), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, false, F16>), dim3(nb, ks), dim3(256), 0, st, g);
     }
     ICKA_CHECK_LAUNCH();
     return 0;
@@ -1381,7 +1402,14 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.A2 = (const bf16_t*)d->A2; g.lda2 = d->lda2; g.B2 = (const bf16_t*)d->B2; g.ldb2 = d->ldb2;
     g.C = d->C; g.ldc = d->ldc; g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
     g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux; g.bias = d->bias; g.bias2 = d->bias2;
-    g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue; g.c_f32 = d->c_is_f32;
+    g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue;
+    if (d->c_is_f32 < 0 || d->c_is_f32 > 2) return ICKA_E_ARG;
+    g.c_f32 = d->c_is_f32 == 1; g.c_f16 = d->c_is_f32 == 2;
+    g.f16 = d->ab_f16 != 0; g.C3 = (bf16_t*)d->C3; g.ldc3 = d->ldc3;
+    if (g.f16 && d->op != ICKA_GEMM_NT) return ICKA_E_ARG;       // fp16 operands: forward (NT) GEMMs only
+    if (g.c_f16 && d->beta != 0.f) return ICKA_E_ARG;              // fp16 outputs are never accumulated into
+    if (g.C3 && !g.c_f16) return ICKA_E_ARG;                       // C3 = bf16 twin of an fp16 main output
+    if (g.c_f16 && d->colsum_out) return ICKA_E_ARG;
     g.abl = g_abl;
     g.stamp = g_stamp;
 #ifdef ICKA_GEMM_STAMP
@@ -1407,12 +1435,12 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     };
     if (d->colsum_out && d->op != ICKA_GEMM_TN) return ICKA_E_ARG;
     aligned = (d->M % BM == 0) && (d->N % BN == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
-              al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
-              al(d->bias, 4, 4) && al(d->bias2, 4, 4);
+              al(d->C, d->ldc, d->c_is_f32 == 1 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
+              al(d->bias, 4, 4) && al(d->bias2, 4, 4) && al(d->C3, d->ldc3, 8);
     g.n96ok = aligned && d->N % 96 == 0;
     g.n64ok = !aligned && (d->M % BM == 0) && (d->N % 64 == 0) && (d->K % BK == 0) && g.a_vec && g.b_vec &&
-              al(d->C, d->ldc, d->c_is_f32 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
-              al(d->bias, 4, 4) && al(d->bias2, 4, 4) && d->K1 == 0 && !d->colsum_out;
+              al(d->C, d->ldc, d->c_is_f32 == 1 ? 4 : 8) && al(d->C2, d->ldc2, 8) && al(d->aux, d->ldaux, 8) &&
+              al(d->bias, 4, 4) && al(d->bias2, 4, 4) && al(d->C3, d->ldc3, 8) && d->K1 == 0 && !d->colsum_out;
     return 0;
 }
 
@@ -1423,6 +1451,7 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     if (rc) return rc;
     if (g.colsum && !(aligned && g_ws)) return ICKA_E_ARG;   // fused column sums exist on the warp-specialised path
     hipStream_t st = (hipStream_t)stream;
+    if (g.f16) return launch<false, false, true>(g, aligned, st);
     switch (d->op) {
         case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st);
         case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
@@ -1890,7 +1919,7 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
         GroupArgs ga;
         int cnt = 0, total = 0;
         const int op = descs[i].op;
-        while (i + cnt < n && cnt < MAX_GROUP && descs[i + cnt].op == op) {
+        while (i + cnt < n && cnt < MAX_GROUP && descs[i + cnt].op == op && !descs[i + cnt].ab_f16) {   // (fp16 problems go alone)
             bool aligned = false;
             const int rc = convert(&descs[i + cnt], ga.p[cnt], aligned);
             if (rc) return rc;

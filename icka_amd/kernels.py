@@ -18,6 +18,7 @@ from ._lib import (EPI_ADD, EPI_ADD_RELU, EPI_DGELU, EPI_GATE, EPI_GELU, EPI_NON
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+F16 = torch.float16
 
 
 def _stream() -> int:
@@ -86,16 +87,22 @@ def profile_gemm(enable: bool, reps: int = 5):
 
 def _gemm_bytes(d) -> float:
     """algorithmic HBM bytes of one GEMM: both operands once + the output once (bf16 in, bf16/f32 out)"""
-    return 2.0 * (d.M * d.K + d.N * d.K) + d.M * d.N * (4.0 if d.c_is_f32 else 2.0)
+    return 2.0 * (d.M * d.K + d.N * d.K) + d.M * d.N * (4.0 if d.c_is_f32 == 1 else 2.0) + (2.0 * d.M * d.N if d.C3 else 0.0)
 
 
 def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
               epilogue: int = EPI_NONE, aux: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
               alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
               B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
-              colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> GemmDesc:
-    """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched)."""
-    _mat(A, "A"); _mat(B, "B")
+              colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False,
+              out3: Optional[torch.Tensor] = None) -> GemmDesc:
+    """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched).
+    Operands are bf16, or -- op NT only, the "mixed16" forward GEMMs -- both fp16; ``out`` may then be fp16 too, with
+    ``out3`` an optional bf16 copy of it."""
+    odt = A.dtype if A.dtype == F16 else BF16     # operand dtype of this launch
+    if odt == F16 and op != GEMM_NT:
+        raise ValueError("fp16 operands: NT (forward) GEMMs only")
+    _mat(A, "A", odt); _mat(B, "B", odt)
     if op == GEMM_NT:
         M, K = A.shape; N, Kb = B.shape
     elif op == GEMM_NN:
@@ -110,17 +117,26 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
     if A2 is not None or B2 is not None:
         if A2 is None or B2 is None:
             raise ValueError("A2 and B2 go together")
-        _mat(A2, "A2"); _mat(B2, "B2")
+        _mat(A2, "A2", odt); _mat(B2, "B2", odt)
         K2 = A2.shape[0] if op == GEMM_TN else A2.shape[1]
         K1, K = K, K + K2
     _dev(out, "out")
-    if out.dtype not in (BF16, F32) or out.dim() != 2 or tuple(out.shape) != (M, N) or (N > 1 and out.stride(1) != 1):
-        raise ValueError("out must be [%d,%d] bf16/f32 row-major, got %s %s" % (M, N, tuple(out.shape), out.dtype))
+    if out.dtype not in (BF16, F32, F16) or out.dim() != 2 or tuple(out.shape) != (M, N) or (N > 1 and out.stride(1) != 1):
+        raise ValueError("out must be [%d,%d] bf16/f32/fp16 row-major, got %s %s" % (M, N, tuple(out.shape), out.dtype))
+    if out.dtype == F16 and (beta != 0.0 or colsum_out is not None):
+        raise ValueError("fp16 outputs are plain forward outputs (no accumulate, no fused column sums)")
+    if out3 is not None:
+        if out.dtype != F16:
+            raise ValueError("out3 is the bf16 copy of an fp16 main output")
+        _mat(out3, "out3")
+        if tuple(out3.shape) != (M, N):
+            raise ValueError("out3 must be [%d,%d]" % (M, N))
     d = GemmDesc()
     d.op, d.M, d.N, d.K, d.K1 = op, M, N, K, K1
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
     d.A2, d.lda2, d.B2, d.ldb2 = _ptr(A2), _ld(A2), _ptr(B2), _ld(B2)
-    d.C, d.ldc, d.c_is_f32 = out.data_ptr(), out.stride(0), int(out.dtype == F32)
+    d.C, d.ldc, d.c_is_f32 = out.data_ptr(), out.stride(0), {BF16: 0, F32: 1, F16: 2}[out.dtype]
+    d.ab_f16, d.C3, d.ldc3 = int(odt == F16), _ptr(out3), _ld(out3)
     if out2 is not None:
         _mat(out2, "out2")
     d.C2, d.ldc2 = _ptr(out2), _ld(out2)
@@ -143,7 +159,7 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
             raise ValueError("fused column sums need the aligned fast path (M, N % 128 == 0, K % 64 == 0)")
     d.colsum_out, d.colsum_accumulate = _ptr(colsum_out), int(colsum_accumulate)
     if _PROF is not None:   # the recorded launch is re-issued later: its operands must outlive the step
-        d._keep = (A, B, out, bias, aux, out2, A2, B2, bias2, colsum_out)
+        d._keep = (A, B, out, bias, aux, out2, A2, B2, bias2, colsum_out, out3)
     return d
 
 

@@ -55,7 +55,7 @@ typedef struct icka_gemm_desc {
     const void* B;  int64_t ldb;    /* bf16 */
     const void* A2; int64_t lda2;   /* second-segment operands (K1 > 0) */
     const void* B2; int64_t ldb2;
-    void* C;  int64_t ldc;  int32_t c_is_f32;   /* output bf16 (0) or f32 (1) */
+    void* C;  int64_t ldc;  int32_t c_is_f32;   /* output bf16 (0), f32 (1) or fp16 (2, see ab_f16 below) */
     void* C2; int64_t ldc2;                     /* bf16 second output (GELU: z, GATE: g) */
     const void* aux; int64_t ldaux;             /* bf16 epilogue operand */
     const float* bias;                          /* f32 [N] or NULL */
@@ -65,6 +65,11 @@ typedef struct icka_gemm_desc {
     float* colsum_out;     /* op TN only, fast path (M,N %128, K %64): colsum_out[m] (+)= sum_k A[k,m]  -- the bias
                               gradient db = colsum(dY) produced by the weight-gradient GEMM dW = dY^T.X itself */
     int32_t colsum_accumulate;
+    /* "mixed16" forward GEMMs (op NT only): operands A, B (A2, B2) are IEEE fp16 instead of bf16
+     * (v_mfma_f32_16x16x32_f16, same rate); c_is_f32 == 2 makes the main output fp16 (saturating at +-65504, beta must
+     * be 0) and C3, if not NULL, receives a bf16 copy of it (the operand the bf16 weight-gradient GEMM reads later). */
+    int32_t ab_f16;
+    void* C3; int64_t ldc3;
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that

@@ -41,6 +41,60 @@ def test_gemm_nt(M, N, K):
     assert rel_err(outf, A.float() @ B.float().t()) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (4096, 768, 768), (4096, 768, 3072), (4096, 2304, 768), (4096, 3072, 768),
+                                   (8192, 1024, 1024), (100, 13, 1536), (77, 200, 72), (1152, 768, 2048), (1024, 64, 576)])
+def test_gemm_nt_fp16_operands(M, N, K):
+    """the "mixed16" forward GEMMs: fp16 operands on v_mfma_f32_16x16x32_f16, outputs bf16 / f32 / fp16 (+ bf16 copy);
+    every NT kernel of the dispatch (256x192, 128x96, 128x128, two-blocks-per-CU, 128x64, general path).  The fp16 product
+    must sit ~8x closer to the f32 product than the bf16 one (11 vs 8 significand bits)."""
+    k = _k()
+    F16 = torch.float16
+    A32, B32 = rnd(M, K, seed=1, dtype=F32), rnd(N, K, seed=2, dtype=F32)
+    A, B = A32.to(F16), B32.to(F16)
+    bias = rnd(N, seed=3, dtype=F32)
+    ref = A.float() @ B.float().t()
+    outf = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, outf)
+    assert rel_err(outf, ref) < 1e-4
+    exact = A32 @ B32.t()
+    outb = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(k.GEMM_NT, A32.to(BF16), B32.to(BF16), outb)
+    e16, eb = (outf - exact).norm().item(), (outb - exact).norm().item()
+    assert e16 < 0.25 * eb, (e16, eb)
+    out = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, out, bias=bias)
+    assert rel_err(out, ref + bias) < 1e-2
+    oh, ob = torch.empty(M, N, dtype=F16, device="cuda"), torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, oh, bias=bias, out3=ob)
+    assert rel_err(oh, ref + bias) < 2e-3
+    assert rel_err(ob, ref + bias) < 1e-2
+    # GELU epilogue: z -> out2 (bf16), gelu(z) -> fp16 main output + bf16 copy
+    z = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, oh, bias=bias, epilogue=k.EPI_GELU, out2=z, out3=ob)
+    zr = (ref + bias) * 0.05
+    A2 = (A32 * 0.05).to(F16)
+    k.gemm(k.GEMM_NT, A2, B, oh, bias=bias * 0.05, epilogue=k.EPI_GELU, out2=z, out3=ob)
+    zr = A2.float() @ B.float().t() + bias * 0.05
+    gr = torch.nn.functional.gelu(zr)
+    assert rel_err(z, zr) < 1e-2
+    assert (oh.float() - gr).abs().max().item() < 2e-3 * max(1.0, gr.abs().max().item())
+    assert (ob.float() - gr).abs().max().item() < 1e-2 * max(1.0, gr.abs().max().item())
+    with pytest.raises(ValueError):
+        k.gemm(k.GEMM_NN, A, B.t().contiguous(), outf)          # fp16 operands are NT only
+    with pytest.raises(TypeError):
+        k.gemm(k.GEMM_NT, A, B32.to(BF16), outf)                # mixed operand types
+
+
+def test_gemm_fp16_output_saturates():
+    k = _k()
+    F16 = torch.float16
+    A = torch.full((128, 64), 200.0, dtype=F16, device="cuda")
+    B = torch.full((128, 64), 200.0, dtype=F16, device="cuda")
+    oh = torch.empty(128, 128, dtype=F16, device="cuda")
+    k.gemm(k.GEMM_NT, A, B, oh)       # 64 * 4e4 = 2.56e6 > 65504
+    assert torch.isfinite(oh).all() and (oh.float() == 65504.0).all()
+
+
 def test_gemm_identity_asymmetric():
     """A = I with an asymmetric B catches a transposed / permuted C write (cdna guide section 3)."""
     k = _k()
