@@ -72,6 +72,8 @@ PROTOTYPES = {
     "icka_gemm_set_stamp_buffer": (c_i32, [c_vp]),
     "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
                             c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_ln_fwd_h": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
+                            c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_ln_bwd_workspace_floats": (c_i64, [c_i32]),
     "icka_ln_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                             c_vp, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
@@ -81,10 +83,14 @@ PROTOTYPES = {
     "icka_ln_slab_slots": (c_i32, []),
     "icka_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_embed_fwd_h": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                               c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
     "icka_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_attn_fwd_ex": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
+                                 c_i32, c_f32, c_f32, c_u64, c_i32, c_vp]),
     "icka_attn_fwd_fp8": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_set_whole_head": (None, [c_i32]),
@@ -112,6 +118,8 @@ PROTOTYPES = {
                               c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
                               c_vp]),
     "icka_cast_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "icka_cast_to_f16": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "icka_cast_f32_to_bf16_f16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "icka_cast_bf16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "icka_cast_pad_f32_to_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "icka_additive_mask": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),

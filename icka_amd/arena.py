@@ -62,6 +62,7 @@ class ParamArena(object):
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        self.shadow16 = None   # fp16 shadow of the same layout: forward operands of the "mixed16" mode (enable_fp16_shadow)
         with torch.no_grad():
             for s in self.order:
                 view = self.flat[s.off:s.off + s.numel].view(s.shape)
@@ -127,6 +128,27 @@ class ParamArena(object):
             raise RuntimeError("%s is an embedding table: it has no bf16 shadow (kernels gather the f32 master)" % s.name)
         return self.shadow[s.off:s.off + s.numel].view(s.shape)
 
+    # -- "mixed16": fp16 shadow for the forward GEMMs (the bf16 shadow keeps serving dgrad in backward)
+    def enable_fp16_shadow(self) -> None:
+        if self.shadow16 is None:
+            if self.shadow is None:
+                raise RuntimeError("ParamArena.enable_fp16_shadow: needs a ROCm device (no CPU path)")
+            self.shadow16 = torch.zeros(self.total, dtype=torch.float16, device=self.device)
+            self._synced = None   # the next sync fills it
+
+    def w16(self, p: nn.Parameter) -> torch.Tensor:
+        """fp16 shadow view of a parameter (enable_fp16_shadow first)."""
+        s = self.slots[id(p)]
+        if s.is_table or self.shadow16 is None:
+            raise RuntimeError("%s has no fp16 shadow (embedding table, or enable_fp16_shadow() was not called)" % s.name)
+        return self.shadow16[s.off:s.off + s.numel].view(s.shape)
+
+    def w16_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
+        first, rows = self._adjacent(ps)
+        if self.shadow16 is None:
+            raise RuntimeError("enable_fp16_shadow() was not called")
+        return self.shadow16[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+
     def w_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
         """bf16 view of several 2-D [o_i, in] parameters as ONE [sum o_i, in] matrix (must be adjacent slots)."""
         first, rows = self._adjacent(ps)
@@ -169,7 +191,10 @@ class ParamArena(object):
         if force or self.shadow_policy == "always" or v != self._synced:
             from . import kernels
             for lo, hi in self._cast_ranges:
-                kernels.cast_f32_to_bf16(self.flat[lo:hi], self.shadow[lo:hi])
+                if self.shadow16 is not None:
+                    kernels.cast_f32_to_bf16_f16(self.flat[lo:hi], self.shadow[lo:hi], self.shadow16[lo:hi])
+                else:
+                    kernels.cast_f32_to_bf16(self.flat[lo:hi], self.shadow[lo:hi])
             self._synced = v
 
     def mark_dirty(self) -> None:

@@ -60,6 +60,7 @@ struct AttnArgs {
     const bf16_t* Q; int64_t ldq; const bf16_t* K; int64_t ldk; const bf16_t* V; int64_t ldv;
     const float* mask; const bf16_t* O; int64_t ldo; const bf16_t* dO; int64_t lddo;
     bf16_t* Ow; float* lse; float* delta;
+    _Float16* Ow16;   // optional fp16 copy of the context (same leading dimension): "mixed16" forward operand of out-proj
     bf16_t* dQ; int64_t lddq; bf16_t* dK; int64_t lddk; bf16_t* dV; int64_t lddv;
     int B, h, Sq, Skv; float scale; DropCfg drop;
 #ifdef ICKA_ATTN_STAMP
@@ -159,6 +160,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_) {
         for (int dt = 0; dt < 4; ++dt)
             *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) =
                 pack4(acc_o[dt][0] * inv, acc_o[dt][1] * inv, acc_o[dt][2] * inv, acc_o[dt][3] * inv);
+        if (a.Ow16) {
+            _Float16* hrow = a.Ow16 + ((int64_t)b * a.Sq + q) * a.ldo + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f16x4*>(hrow + 16 * dt + 4 * g) =
+                    f16x4{(_Float16)(acc_o[dt][0] * inv), (_Float16)(acc_o[dt][1] * inv), (_Float16)(acc_o[dt][2] * inv),
+                          (_Float16)(acc_o[dt][3] * inv)};
+        }
         if (g == 0 && a.lse) a.lse[(int64_t)(b * a.h + head) * a.Sq + q] = m_run + logf(l_run);
     }
 }
@@ -619,6 +628,14 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
                 *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) =
                     pack4(acc[qi][dt][0] * inv[qi], acc[qi][dt][1] * inv[qi], acc[qi][dt][2] * inv[qi],
                           acc[qi][dt][3] * inv[qi]);
+            if (a.Ow16) {   // (the context is a convex combination of value rows: no fp16 overflow beyond V's own range)
+                _Float16* hrow = a.Ow16 + ((int64_t)b * a.Sq + q) * a.ldo + head * HD;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<f16x4*>(hrow + 16 * dt + 4 * g) =
+                        f16x4{(_Float16)(acc[qi][dt][0] * inv[qi]), (_Float16)(acc[qi][dt][1] * inv[qi]),
+                              (_Float16)(acc[qi][dt][2] * inv[qi]), (_Float16)(acc[qi][dt][3] * inv[qi])};
+            }
         }
     }
 }
@@ -876,6 +893,36 @@ extern "C" int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int6
     a.mask = add_mask; a.Ow = (bf16_t*)O; a.ldo = ldo; a.lse = lse;
     a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
     try_small(a, 2, (hipStream_t)stream);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+// Forward with an additional fp16 copy of the context ("mixed16": fp16 operand of the out-proj GEMM; the bf16 copy stays
+// the operand of the weight-gradient GEMM and of the attention backward).  fp8 != 0 selects the fp8 QK^T / PV form.
+extern "C" int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                                const float* add_mask, void* O, void* O_f16, int64_t ldo, float* lse, int32_t B,
+                                int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed,
+                                int32_t fp8, void* stream) {
+    if (!Q || !K || !V || !add_mask || !O) return ICKA_E_ARG;
+    if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) return ICKA_E_SHAPE;
+    if (fp8 && (Sq > 128 || Skv > 128)) return ICKA_E_SHAPE;
+    if ((int64_t)B * heads * Sq * Skv >= (1ll << 32)) return ICKA_E_SHAPE;
+    if (!ok16(Q, ldq) || !ok16(K, ldk) || !ok16(V, ldv) || !ok16(O, ldo) || (O_f16 && !ok16(O_f16, ldo))) return ICKA_E_ALIGN;
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+    a.mask = add_mask; a.Ow = (bf16_t*)O; a.Ow16 = (_Float16*)O_f16; a.ldo = ldo; a.lse = lse;
+    a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
+    if (fp8) {
+        try_small(a, 2, (hipStream_t)stream);
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
+    if (g_small && try_small(a, 0, (hipStream_t)stream)) {
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
+    const int grid = B * heads * ((Sq + TILE - 1) / TILE);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -33,6 +33,34 @@ __global__ void cast_f2b_kernel(const float* __restrict__ src, bf16_t* __restric
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nch << 3) + threadIdx.x] = f2bf(src[(nch << 3) + threadIdx.x]);
 }
+// both 16-bit shadows of the f32 master weights in one pass: bf16 (dgrad / wgrad operands) and fp16 ("mixed16" forward)
+__global__ void cast_f2bh_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, _Float16* __restrict__ dsth, int64_t n) {
+    const int64_t nch = n >> 3;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + c * 8), b = *reinterpret_cast<const f32x4*>(src + c * 8 + 4);
+        bf16x8 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+        *reinterpret_cast<u32x4*>(dst + c * 8) = as_u32x4(o);
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)fminf(fmaxf(a[e], -65504.f), 65504.f);
+            h[4 + e] = (_Float16)fminf(fmaxf(b[e], -65504.f), 65504.f);
+        }
+        *reinterpret_cast<u32x4*>(dsth + c * 8) = __builtin_bit_cast(u32x4, h);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const float v = src[(nch << 3) + threadIdx.x];
+        dst[(nch << 3) + threadIdx.x] = f2bf(v);
+        dsth[(nch << 3) + threadIdx.x] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+    }
+}
+// bf16 (kind 0) or f32 (kind 1) -> fp16, saturating: block inputs of the "mixed16" mode that arrive without an fp16 twin
+__global__ void cast_to_f16_kernel(const void* __restrict__ src, int kind, _Float16* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = kind ? reinterpret_cast<const float*>(src)[i] : bf2f(reinterpret_cast<const bf16_t*>(src)[i]);
+        dst[i] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+    }
+}
 __global__ void cast_b2f_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = bf2f(src[i]);
@@ -345,6 +373,23 @@ extern "C" int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, voi
     if (!al16(src) || !al16(dst)) return ICKA_E_ALIGN;
     hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for((n + 7) / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
                        (bf16_t*)dst, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_cast_f32_to_bf16_f16(const float* src, void* dst_bf16, void* dst_f16, int64_t n, void* stream) {
+    if (!src || !dst_bf16 || !dst_f16) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    if (!al16(src) || !al16(dst_bf16) || !al16(dst_f16)) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(cast_f2bh_kernel, dim3(grid_for((n + 7) / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst_bf16, (_Float16*)dst_f16, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_cast_to_f16(const void* src, int32_t src_is_f32, void* dst, int64_t n, void* stream) {
+    if (!src || !dst) return ICKA_E_ARG;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cast_to_f16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (int)src_is_f32,
+                       (_Float16*)dst, n);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

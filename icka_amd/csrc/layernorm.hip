@@ -15,8 +15,9 @@ constexpr int SLOTS = 4;            // column-sum slots per slab
 struct LnFwdArgs {
     const void* x; int64_t ldx; int x_f32; const float* bias; const void* res; int64_t ldr; int r_f32;
     const float* gamma; const float* beta;
-    bf16_t* y; int64_t ldy; bf16_t* y2; int64_t ldy2; float* yf; bf16_t* xhat; float* rstd;
+    bf16_t* y; int64_t ldy; bf16_t* y2; int64_t ldy2; void* yf; bf16_t* xhat; float* rstd;
     int M, H; float eps; DropCfg drop;
+    int yf_f16;   // the twin output ``yf`` is fp16 (the "mixed16" forward operand + residual) instead of f32
 };
 
 __device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
@@ -28,9 +29,16 @@ __device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
 }
-// row element loads in either precision (GEMM outputs / the residual stream are kept in f32, operands in bf16)
-__device__ __forceinline__ void load8x(const void* base, int is_f32, int64_t off, float (&o)[8]) {
-    if (is_f32) load8f(reinterpret_cast<const float*>(base) + off, o);
+__device__ __forceinline__ void load8h(const _Float16* p, float (&o)[8]) {
+    const f16x8 v = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+// row element loads in either precision: kind 0 = bf16, 1 = f32 (GEMM outputs, the f32 residual twin), 2 = fp16 (the
+// residual stream of the "mixed16" mode)
+__device__ __forceinline__ void load8x(const void* base, int kind, int64_t off, float (&o)[8]) {
+    if (kind == 1) load8f(reinterpret_cast<const float*>(base) + off, o);
+    else if (kind == 2) load8h(reinterpret_cast<const _Float16*>(base) + off, o);
     else load8(reinterpret_cast<const bf16_t*>(base) + off, o);
 }
 __device__ __forceinline__ void store8f(float* p, const float (&v)[8]) {
@@ -42,6 +50,18 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
     *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
+}
+
+__device__ __forceinline__ void store8h(_Float16* p, const float (&v)[8]) {
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
+    *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, o);
+}
+// the twin copy of a LayerNorm output: f32, or fp16 in the "mixed16" mode
+__device__ __forceinline__ void store8t(void* base, int is_f16, int64_t off, const float (&v)[8]) {
+    if (is_f16) store8h(reinterpret_cast<_Float16*>(base) + off, v);
+    else store8f(reinterpret_cast<float*>(base) + off, v);
 }
 
 template <int NCH>
@@ -106,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
                 for (int e = 0; e < 8; ++e) { xh[e] = (s[i][e] - mean) * rstd; o[e] = g[e] * xh[e] + b[e]; }
                 store8(a.y + (int64_t)row * a.ldy + c * 8, o);
                 if (a.y2) store8(a.y2 + (int64_t)row * a.ldy2 + c * 8, o);
-                if (a.yf) store8f(a.yf + (int64_t)row * a.H + c * 8, o);
+                if (a.yf) store8t(a.yf, a.yf_f16, (int64_t)row * a.H + c * 8, o);
                 if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
             }
         }
@@ -311,11 +331,12 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------- embeddings
 struct EmbFwdArgs {
     const int64_t* ids; const int64_t* tt; const float* word; const float* pos; const float* type;
-    const float* gamma; const float* beta; bf16_t* y; float* yf; bf16_t* xhat; float* rstd;
+    const float* gamma; const float* beta; bf16_t* y; void* yf; bf16_t* xhat; float* rstd;
     int M, S, H, vocab, n_type; float eps; DropCfg drop;
     // prompt splice (icka_embed_prompt_fwd): output position t takes token src[t] of the S_in-long id row, or, for
     // src[t] < 0, prompt vector -1-src[t] of this sample's [P,H] bf16 prompt block; position row = t + pos_offset
     const int32_t* src; const bf16_t* prompt; int S_in, P, pos_offset;
+    int yf_f16;   // twin output is fp16 ("mixed16") instead of f32
 };
 
 template <int NCH>
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbFwdArgs a_) {
                     o[e] = (g[e] * xh[e] + b[e]) * drop_mul(a.drop, base + e);
                 }
                 store8(a.y + (int64_t)row * a.H + c * 8, o);
-                if (a.yf) store8f(a.yf + (int64_t)row * a.H + c * 8, o);
+                if (a.yf) store8t(a.yf, a.yf_f16, (int64_t)row * a.H + c * 8, o);
                 if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
             }
         }
@@ -589,22 +610,39 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int64_t icka_ln_bwd_workspace_floats(int32_t H) { return (int64_t)BWD_BLOCKS * SLOTS * H; }
 
-extern "C" int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual,
+static int ln_fwd_impl(int32_t twin_f16, const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual,
                            int64_t ldr, int32_t res_is_f32, const float* gamma, const float* beta, void* y,
-                           int64_t ldy, void* y2, int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M,
+                           int64_t ldy, void* y2, int64_t ldy2, void* y_twin, void* xhat, float* rstd, int32_t M,
                            int32_t H, float eps, float p_drop, uint64_t seed, void* stream) {
     if (!x || !gamma || !beta || !y) return ICKA_E_ARG;
+    if (x_is_f32 < 0 || x_is_f32 > 2 || res_is_f32 < 0 || res_is_f32 > 2) return ICKA_E_ARG;
     if (M <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH) return ICKA_E_SHAPE;
     if (ldx % 8 || ldy % 8 || (residual && ldr % 8) || (y2 && ldy2 % 8)) return ICKA_E_ALIGN;
     if (!al16(x) || !al16(y) || (residual && !al16(residual)) || (y2 && !al16(y2)) || (xhat && !al16(xhat)) ||
-        (bias && !al16(bias)) || !al16(gamma) || !al16(beta) || (y_f32 && !al16(y_f32)))
+        (bias && !al16(bias)) || !al16(gamma) || !al16(beta) || (y_twin && !al16(y_twin)))
         return ICKA_E_ALIGN;
     LnFwdArgs a{x, ldx, x_is_f32, bias, residual, ldr, res_is_f32, gamma, beta, (bf16_t*)y, ldy,
-                (bf16_t*)y2, ldy2, y_f32, (bf16_t*)xhat, rstd, M, H, eps, make_drop(p_drop, seed)};
+                (bf16_t*)y2, ldy2, y_twin, (bf16_t*)xhat, rstd, M, H, eps, make_drop(p_drop, seed), twin_f16};
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), ln_fwd_kernel, row_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual,
+                           int64_t ldr, int32_t res_is_f32, const float* gamma, const float* beta, void* y,
+                           int64_t ldy, void* y2, int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M,
+                           int32_t H, float eps, float p_drop, uint64_t seed, void* stream) {
+    return ln_fwd_impl(0, x, ldx, x_is_f32, bias, residual, ldr, res_is_f32, gamma, beta, y, ldy, y2, ldy2, y_f32, xhat, rstd,
+                       M, H, eps, p_drop, seed, stream);
+}
+// "mixed16" form: the twin copy of the output is fp16 (forward GEMM operand + residual of the next block)
+extern "C" int icka_ln_fwd_h(const void* x, int64_t ldx, int32_t x_kind, const float* bias, const void* residual,
+                             int64_t ldr, int32_t res_kind, const float* gamma, const float* beta, void* y,
+                             int64_t ldy, void* y2, int64_t ldy2, void* y_f16, void* xhat, float* rstd, int32_t M,
+                             int32_t H, float eps, float p_drop, uint64_t seed, void* stream) {
+    return ln_fwd_impl(1, x, ldx, x_kind, bias, residual, ldr, res_kind, gamma, beta, y, ldy, y2, ldy2, y_f16, xhat, rstd,
+                       M, H, eps, p_drop, seed, stream);
 }
 
 extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* xhat,
@@ -686,21 +724,38 @@ extern "C" int icka_ln_bwd_slabs(const void* dy, int64_t lddy, const void* dy2, 
     return 0;
 }
 
-extern "C" int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
-                              const float* type, const float* gamma, const float* beta, void* y, float* y_f32,
+static int embed_fwd_impl(int32_t twin_f16, const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                              const float* type, const float* gamma, const float* beta, void* y, void* y_twin,
                               void* xhat, float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab,
                               int32_t n_type, float eps, float p_drop, uint64_t seed, void* stream) {
     if (!ids || !word || !pos || !type || !gamma || !beta || !y) return ICKA_E_ARG;
     if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || n_type <= 0)
         return ICKA_E_SHAPE;
-    if (!al16(word) || !al16(pos) || !al16(type) || !al16(gamma) || !al16(beta) || !al16(y) || (xhat && !al16(xhat)))
+    if (!al16(word) || !al16(pos) || !al16(type) || !al16(gamma) || !al16(beta) || !al16(y) || (xhat && !al16(xhat)) ||
+        (y_twin && !al16(y_twin)))
         return ICKA_E_ALIGN;
-    EmbFwdArgs a{ids, token_type, word, pos, type, gamma, beta, (bf16_t*)y, y_f32, (bf16_t*)xhat, rstd,
-                 B * S, S, H, vocab, n_type, eps, make_drop(p_drop, seed), nullptr, nullptr, S, 0, 0};
+    EmbFwdArgs a{ids, token_type, word, pos, type, gamma, beta, (bf16_t*)y, y_twin, (bf16_t*)xhat, rstd,
+                 B * S, S, H, vocab, n_type, eps, make_drop(p_drop, seed), nullptr, nullptr, S, 0, 0, twin_f16};
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), embed_fwd_kernel, row_grid(B * S), 0, st, a);
     ICKA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                              const float* type, const float* gamma, const float* beta, void* y, float* y_f32,
+                              void* xhat, float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab,
+                              int32_t n_type, float eps, float p_drop, uint64_t seed, void* stream) {
+    return embed_fwd_impl(0, ids, token_type, word, pos, type, gamma, beta, y, y_f32, xhat, rstd, B, S, H, vocab, n_type, eps,
+                          p_drop, seed, stream);
+}
+// "mixed16" form: fp16 twin of the output
+extern "C" int icka_embed_fwd_h(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                                const float* type, const float* gamma, const float* beta, void* y, void* y_f16,
+                                void* xhat, float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab,
+                                int32_t n_type, float eps, float p_drop, uint64_t seed, void* stream) {
+    return embed_fwd_impl(1, ids, token_type, word, pos, type, gamma, beta, y, y_f16, xhat, rstd, B, S, H, vocab, n_type, eps,
+                          p_drop, seed, stream);
 }
 
 // Embeddings of a prompt-spliced sequence (the prompt-accepting encoder stage of the current reference model,
@@ -718,7 +773,7 @@ extern "C" int icka_embed_prompt_fwd(const int64_t* ids, const int32_t* src, con
         !al16(prompt))
         return ICKA_E_ALIGN;
     EmbFwdArgs a{ids, nullptr, word, pos, type, gamma, beta, (bf16_t*)y, y_f32, (bf16_t*)xhat, rstd,
-                 B * S, S, H, vocab, 1, eps, make_drop(p_drop, seed), src, (const bf16_t*)prompt, S_in, P, pos_offset};
+                 B * S, S, H, vocab, 1, eps, make_drop(p_drop, seed), src, (const bf16_t*)prompt, S_in, P, pos_offset, 0};
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), embed_fwd_kernel, row_grid(B * S), 0, st, a);
     ICKA_CHECK_LAUNCH();

@@ -243,18 +243,31 @@ def gemm_grouped(descs, reductions=None) -> None:
 
 
 # ------------------------------------------------------------------------------------------------- LayerNorm
-def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, y_f32=None, xhat=None, rstd=None, eps=1e-12, p_drop=0.0,
-           seed=0):
-    """x / residual may be bf16 or f32 [M,H] row-major; y (and y2) bf16; y_f32 optional contiguous f32 copy."""
+def _kind(t: torch.Tensor) -> int:
+    """element-type code of the LayerNorm launchers: 0 bf16, 1 f32, 2 fp16"""
+    return {BF16: 0, F32: 1, F16: 2}[t.dtype]
+
+
+def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, y_f32=None, y_f16=None, xhat=None, rstd=None, eps=1e-12,
+           p_drop=0.0, seed=0):
+    """x / residual may be bf16, f32 or fp16 [M,H] row-major; y (and y2) bf16; twin copy of the output: y_f32 (contiguous
+    f32) or y_f16 (contiguous fp16, the "mixed16" forward operand + residual) -- at most one of the two."""
     lib = _lib.load()
-    _mat(x, "x", x.dtype if x.dtype in (BF16, F32) else BF16); _mat(y, "y")
+    _mat(x, "x", x.dtype if x.dtype in (BF16, F32, F16) else BF16); _mat(y, "y")
     if residual is not None:
-        _mat(residual, "residual", residual.dtype if residual.dtype in (BF16, F32) else BF16)
+        _mat(residual, "residual", residual.dtype if residual.dtype in (BF16, F32, F16) else BF16)
+    if y_f32 is not None and y_f16 is not None:
+        raise ValueError("one twin copy: y_f32 or y_f16")
     M, H = x.shape
-    check(lib.icka_ln_fwd(x.data_ptr(), x.stride(0), int(x.dtype == F32), _ptr(bias), _ptr(residual), _ld(residual),
-                          int(residual is not None and residual.dtype == F32), gamma.data_ptr(), beta.data_ptr(),
-                          y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), _ptr(y_f32), _ptr(xhat), _ptr(rstd),
-                          M, H, eps, p_drop, seed, _stream()), "icka_ln_fwd")
+    twin = y_f16 if y_f16 is not None else y_f32
+    if twin is not None and (twin.dtype != (F16 if y_f16 is not None else F32) or not twin.is_contiguous()
+                             or tuple(twin.shape) != (M, H)):
+        raise ValueError("twin output must be contiguous [M,H] f32 (y_f32) / fp16 (y_f16)")
+    fn = lib.icka_ln_fwd_h if y_f16 is not None else lib.icka_ln_fwd
+    check(fn(x.data_ptr(), x.stride(0), _kind(x), _ptr(bias), _ptr(residual), _ld(residual),
+             0 if residual is None else _kind(residual), gamma.data_ptr(), beta.data_ptr(),
+             y.data_ptr(), y.stride(0), _ptr(y2), _ld(y2), _ptr(twin), _ptr(xhat), _ptr(rstd),
+             M, H, eps, p_drop, seed, _stream()), "icka_ln_fwd")
     return y
 
 
@@ -286,15 +299,21 @@ def ln_bwd(dy, xhat, rstd, gamma, *, dy2=None, dres=None, dx=None, dgamma=None, 
 
 
 # ------------------------------------------------------------------------------------------------- embeddings
-def embed_fwd(ids, token_type, word, pos, typ, gamma, beta, y, *, y_f32=None, xhat=None, rstd=None, eps=1e-12,
+def embed_fwd(ids, token_type, word, pos, typ, gamma, beta, y, *, y_f32=None, y_f16=None, xhat=None, rstd=None, eps=1e-12,
               p_drop=0.0, seed=0):
     lib = _lib.load()
     _dev(ids, "ids")
     B, S = ids.shape
     H = word.shape[1]
-    check(lib.icka_embed_fwd(ids.data_ptr(), _ptr(token_type), word.data_ptr(), pos.data_ptr(), typ.data_ptr(),
-                             gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(y_f32), _ptr(xhat), _ptr(rstd),
-                             B, S, H, word.shape[0], typ.shape[0], eps, p_drop, seed, _stream()), "icka_embed_fwd")
+    if y_f32 is not None and y_f16 is not None:
+        raise ValueError("one twin copy: y_f32 or y_f16")
+    twin = y_f16 if y_f16 is not None else y_f32
+    if twin is not None and (twin.dtype != (F16 if y_f16 is not None else F32) or not twin.is_contiguous()):
+        raise ValueError("twin output must be contiguous f32 (y_f32) / fp16 (y_f16)")
+    fn = lib.icka_embed_fwd_h if y_f16 is not None else lib.icka_embed_fwd
+    check(fn(ids.data_ptr(), _ptr(token_type), word.data_ptr(), pos.data_ptr(), typ.data_ptr(),
+             gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(twin), _ptr(xhat), _ptr(rstd),
+             B, S, H, word.shape[0], typ.shape[0], eps, p_drop, seed, _stream()), "icka_embed_fwd")
     return y
 
 
@@ -374,14 +393,23 @@ def dgelu(dg, z, dz):
 
 
 # ------------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False):
+def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False, out16=None):
     """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection).
-    fp8=True: QK^T and PV on the fp8 matrix cores (Sq, Skv <= 128 only)."""
+    fp8=True: QK^T and PV on the fp8 matrix cores (Sq, Skv <= 128 only).  out16: optional fp16 copy of the context with
+    the strides of ``out`` (the "mixed16" operand of the out-proj GEMM)."""
     lib = _lib.load()
     for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         _mat(t, n)
     if scale is None:
         scale = 1.0 / math.sqrt(64.0)
+    if out16 is not None:
+        _mat(out16, "out16", F16)
+        if tuple(out16.shape) != tuple(out.shape) or out16.stride(0) != out.stride(0):
+            raise ValueError("out16 must have the shape and row stride of out")
+        check(lib.icka_attn_fwd_ex(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                   add_mask.data_ptr(), out.data_ptr(), out16.data_ptr(), out.stride(0), _ptr(lse), B, heads,
+                                   Sq, Skv, scale, p_drop, seed, int(bool(fp8)), _stream()), "icka_attn_fwd_ex")
+        return out
     fn = lib.icka_attn_fwd_fp8 if fp8 else lib.icka_attn_fwd
     check(fn(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), add_mask.data_ptr(),
              out.data_ptr(), out.stride(0), _ptr(lse), B, heads, Sq, Skv, scale, p_drop, seed, _stream()),
@@ -511,6 +539,26 @@ def crf_decode(emissions, mask, start, end, trans, best_tags, best_score=None):
 def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     _dev(src, "src"); _dev(dst, "dst")
     check(_lib.load().icka_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "icka_cast")
+    return dst
+
+
+def cast_f32_to_bf16_f16(src: torch.Tensor, dst: torch.Tensor, dsth: torch.Tensor) -> None:
+    """both 16-bit shadows of an f32 range in one launch: dst bf16, dsth fp16"""
+    _dev(src, "src"); _dev(dst, "dst"); _dev(dsth, "dsth")
+    if src.dtype != F32 or dst.dtype != BF16 or dsth.dtype != F16 or dst.numel() != src.numel() or dsth.numel() != src.numel():
+        raise TypeError("cast_f32_to_bf16_f16: f32 source, bf16 + fp16 destinations of the same length")
+    check(_lib.load().icka_cast_f32_to_bf16_f16(src.data_ptr(), dst.data_ptr(), dsth.data_ptr(), src.numel(), _stream()),
+          "icka_cast_f32_to_bf16_f16")
+
+
+def cast_to_f16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """contiguous bf16 / f32 -> fp16 (saturating)"""
+    _dev(src, "src"); _dev(dst, "dst")
+    if src.dtype not in (BF16, F32) or dst.dtype != F16 or not src.is_contiguous() or not dst.is_contiguous() \
+            or src.numel() != dst.numel():
+        raise TypeError("cast_to_f16: contiguous bf16/f32 source, contiguous fp16 destination of the same size")
+    check(_lib.load().icka_cast_to_f16(src.data_ptr(), int(src.dtype == F32), dst.data_ptr(), src.numel(), _stream()),
+          "icka_cast_to_f16")
     return dst
 
 

@@ -92,12 +92,17 @@ def _add_mask2d(mask: torch.Tensor, B: int, T: int) -> torch.Tensor:
     return mask.reshape(B, T).contiguous()
 
 
-PRECISIONS = ("bf16", "fp32")
+PRECISIONS = ("bf16", "mixed16", "fp32")
 
 
 def set_precision(module: nn.Module, precision: str) -> nn.Module:
     """Select the arithmetic of every icka block under ``module``:
     "bf16" (default): bf16 MFMA operands, f32 accumulation / statistics / residual stream -- the product path;
+    "mixed16": the FORWARD GEMMs of the encoder layers read IEEE fp16 operands (activations: an fp16 copy that is also
+               the residual stream; weights: an fp16 shadow of the masters) on v_mfma_f32_16x16x32_f16 -- 11 significand
+               bits instead of 8, same MFMA rate; q/k/v, the attention kernels, the gated head and the WHOLE backward
+               stay bf16 (no loss scaling needed: no gradient is ever held in fp16).  For deep stacks whose bf16 rounding
+               noise exceeds the 2e-2 logit bar (bert-large, BASELINE config c4);
     "fp32": f32 storage and f32-input MFMA arithmetic (icka_amd/exact.py) for the 1e-3 parity bar of BASELINE.json."""
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %s" % (PRECISIONS,))
@@ -110,12 +115,16 @@ def _is_exact(module: nn.Module) -> bool:
     return getattr(module, "icka_precision", "bf16") == "fp32"
 
 
-def _dims(config, B, S, R, train: bool, exact: bool = False) -> ops.Dims:
+def _is_mixed(module: nn.Module) -> bool:
+    return getattr(module, "icka_precision", "bf16") == "mixed16"
+
+
+def _dims(config, B, S, R, train: bool, exact: bool = False, mixed: bool = False) -> ops.Dims:
     if not exact:
         check_head_size_bf16(config)
     return ops.Dims(B, S, R, config.hidden_size, config.intermediate_size, config.num_attention_heads,
                     float(getattr(config, "layer_norm_eps", 1e-12)), float(config.hidden_dropout_prob),
-                    float(config.attention_probs_dropout_prob), train)
+                    float(config.attention_probs_dropout_prob), train, h16=mixed and not exact)
 
 
 class _IckaModule(ArenaModule):
@@ -195,7 +204,7 @@ class BertEmbeddings(_IckaModule):
         if _is_exact(self):
             d = _dims(self.config, B, S, 0, self.training, True)
             return X.EmbeddingsFn.apply(A.anchor, self, A, ids, tt, d).view(B, S, -1)
-        d = _dims(self.config, B, S, 0, self.training)
+        d = _dims(self.config, B, S, 0, self.training, mixed=_is_mixed(self))
         y, yf = ops.EmbeddingsFn.apply(A.anchor, self, A, ids, tt, d)
         return _with_twin(y, yf, (B, S, -1))
 
@@ -348,7 +357,7 @@ class BertLayer(_IckaModule):
             return X.BertLayerFn.apply(A.anchor, _hidden2d(hidden_states, exact=True), self, A,
                                        _add_mask2d(attention_mask, B, S), d).view(B, S, H)
         x = _hidden2d(hidden_states)
-        d = _dims(self.config, B, S, 0, self.training)
+        d = _dims(self.config, B, S, 0, self.training, mixed=_is_mixed(self))
         y, yf = ops.BertLayerFn.apply(A.anchor, x, _twin(hidden_states), self, A, _add_mask2d(attention_mask, B, S), d)
         return _with_twin(y, yf, (B, S, H))
 
@@ -404,7 +413,7 @@ class BertCrossAttentionLayer(_IckaModule):
                                         _add_mask2d(s2_attention_mask, B, R), d).view(B, S, H)
         s1 = _hidden2d(s1_hidden_states, "s1_hidden_states")
         s2 = _hidden2d(s2_hidden_states, "s2_hidden_states")
-        d = _dims(self.config, B, S, R, self.training)
+        d = _dims(self.config, B, S, R, self.training, mixed=_is_mixed(self))
         y, yf = ops.CrossLayerFn.apply(A.anchor, s1, _twin(s1_hidden_states), s2, self, A,
                                        _add_mask2d(s2_attention_mask, B, R), d)
         return _with_twin(y, yf, (B, S, H))
@@ -643,8 +652,8 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     else:
         cross = seq
     crossf = seqf
-    d = _dims(cfg, B, S, R, self.training)
     for layer in self.txt2img_attention.layer:
+        d = _dims(cfg, B, S, R, self.training, mixed=_is_mixed(layer))
         cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
     return A, seq, seqf, cross, crossf
 

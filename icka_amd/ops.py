@@ -18,7 +18,7 @@ import torch
 from . import kernels as K
 from .arena import ParamArena
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
 
 
 def _empty(ref: torch.Tensor, *shape, dtype=BF16) -> torch.Tensor:
@@ -34,13 +34,29 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 class Dims(object):
     """Static description of one call: batch, query length, kv length, sizes, dropout probabilities."""
-    __slots__ = ("B", "S", "R", "H", "I", "heads", "eps", "p_hidden", "p_attn", "train")
+    __slots__ = ("B", "S", "R", "H", "I", "heads", "eps", "p_hidden", "p_attn", "train", "h16")
 
-    def __init__(self, B, S, R, H, I, heads, eps, p_hidden, p_attn, train):
+    def __init__(self, B, S, R, H, I, heads, eps, p_hidden, p_attn, train, h16=False):
         self.B, self.S, self.R, self.H, self.I, self.heads, self.eps = B, S, R, H, I, heads, eps
         self.p_hidden = p_hidden if train else 0.0
         self.p_attn = p_attn if train else 0.0
         self.train = train
+        # "mixed16": the forward GEMMs of the encoder layers read fp16 operands (activations: the fp16 twin that is also the
+        # residual stream; weights: the arena's fp16 shadow); backward stays on the bf16 copies
+        self.h16 = bool(h16)
+
+
+def _fwd_twin(A: ParamArena, x, xf, d: Dims):
+    """The forward twin of a block input.  bf16 mode: the f32 residual twin (or None).  mixed16: the fp16 copy that is both
+    the forward GEMM operand and the residual (made from the bf16 tensor when the producer did not leave one)."""
+    if not d.h16:
+        return xf
+    if A.shadow16 is None:      # first mixed16 call on this arena: create and fill the fp16 weight shadow
+        A.enable_fp16_shadow()
+        A.sync(force=True)
+    if xf is not None and xf.dtype == F16:
+        return xf
+    return K.cast_to_f16(x if xf is None else xf, _empty(x, x.shape[0], x.shape[1], dtype=F16))
 
 
 # Weight gradients (dW = dY^T . X, reduction over the tokens) have no consumer inside backward: each block queues
@@ -86,30 +102,35 @@ def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres
 # CrossLayerFn) chain them with the gradient fan-ins fused into GEMM epilogues, the sub-module Functions further down
 # (AttnCoreFn, DenseResidualNormFn, IntermediateFn) expose the same pairs one by one for callers that compose
 # BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput themselves (as BertAttention.forward :451-454 does).
-def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, save: bool):
+def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, save: bool, x16=None):
     """BertSelfAttention / BertCoAttention (:478-506, :590-624): fused projection GEMM -> fused attention kernel.
-    Returns (ctx bf16 [M,H], saved)."""
+    Returns (ctx bf16 [M,H], ctx fp16 or None, saved).  x16: fp16 copy of x (mixed16) -> the projections of x read fp16
+    operands; q/k/v stay bf16 (the attention kernels' operand type), the K/V projection of ``kv_src`` stays bf16."""
     M, H = x.shape
+    h16 = x16 is not None
+    xa = x16 if h16 else x
     if kv_src is None:
         qkv = _empty(x, M, 3 * H)
-        K.gemm(K.GEMM_NT, x, A.w_cat((sa.query.weight, sa.key.weight, sa.value.weight)), qkv,
+        wq = (sa.query.weight, sa.key.weight, sa.value.weight)
+        K.gemm(K.GEMM_NT, xa, A.w16_cat(wq) if h16 else A.w_cat(wq), qkv,
                bias=A.f_cat((sa.query.bias, sa.key.bias, sa.value.bias)))
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
         kvbuf = None
     else:
         qkv = _empty(x, M, H)
-        K.gemm(K.GEMM_NT, x, A.w(sa.query.weight), qkv, bias=sa.query.bias)
+        K.gemm(K.GEMM_NT, xa, A.w16(sa.query.weight) if h16 else A.w(sa.query.weight), qkv, bias=sa.query.bias)
         kvbuf = _empty(x, kv_src.shape[0], 2 * H)
         K.gemm(K.GEMM_NT, kv_src, A.w_cat((sa.key.weight, sa.value.weight)), kvbuf,
                bias=A.f_cat((sa.key.bias, sa.value.bias)))
         q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
     ctx = _empty(x, M, H)
+    ctx16 = _empty(x, M, H, dtype=F16) if h16 else None
     lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
     seed_a = A.next_seed() if d.p_attn > 0 else 0
     # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
-    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8)
-    return ctx, ((qkv, kvbuf, lse, seed_a) if save else None)
+    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8, out16=ctx16)
+    return ctx, ctx16, ((qkv, kvbuf, lse, seed_a) if save else None)
 
 
 def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, saved, ctx, dctx, dres, need_dkv_src: bool):
@@ -146,20 +167,24 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     return dx, dsrc
 
 
-def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool):
+def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool, h16=None):
     """BertSelfOutput / BertOutput (:561-565, :532-536): LayerNorm(dropout(dense(h)) + res).  ``res`` is the residual
-    input, bf16 or its f32 twin.  Returns (y bf16, y f32, saved)."""
+    input: bf16, its f32 twin, or (mixed16) its fp16 twin.  h16: fp16 copy of h -> the dense GEMM reads fp16 operands and
+    the twin of the output is fp16.  Returns (y bf16, y twin, saved)."""
     M = h.shape[0]
     H = mod.dense.weight.shape[0]
-    o = _empty(h, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra bf16 rounding)
-    K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
+    o = _empty(h, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra 16-bit rounding)
+    if h16 is not None:
+        K.gemm(K.GEMM_NT, h16, A.w16(mod.dense.weight), o)
+    else:
+        K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
     y = _empty(h, M, H)
-    yf = _empty(h, M, H, dtype=F32)
+    yf = _empty(h, M, H, dtype=F16 if d.h16 else F32)
     xhat = _empty(h, M, H) if save else None
     rstd = _empty(h, M, dtype=F32) if save else None
     seed_h = A.next_seed() if d.p_hidden > 0 else 0
-    K.ln_fwd(o, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, y_f32=yf, xhat=xhat, rstd=rstd,
-             eps=d.eps, p_drop=d.p_hidden, seed=seed_h)
+    K.ln_fwd(o, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, xhat=xhat, rstd=rstd,
+             eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **({"y_f16": yf} if d.h16 else {"y_f32": yf}))
     return y, yf, ((xhat, rstd, seed_h) if save else None)
 
 
@@ -177,14 +202,20 @@ def _dense_norm_bwd(A: ParamArena, tag: str, mod, h, d: Dims, saved, dy, dy2):
     return do, dres
 
 
-def _inter_fwd(A: ParamArena, inter, x):
-    """BertIntermediate (:548-551): gelu(dense(x)); the pre-activation z is the GEMM's second output."""
+def _inter_fwd(A: ParamArena, inter, x, x16=None):
+    """BertIntermediate (:548-551): gelu(dense(x)); the pre-activation z is the GEMM's second output.  x16 (mixed16): fp16
+    operands; the GEMM then writes gelu(z) twice, fp16 (operand of the BertOutput GEMM) and bf16 (operand of its weight
+    gradient).  Returns (g bf16, z bf16, g fp16 or None)."""
     M = x.shape[0]
     I = inter.dense.weight.shape[0]
     z = _empty(x, M, I)
     g = _empty(x, M, I)
+    if x16 is not None:
+        g16 = _empty(x, M, I, dtype=F16)
+        K.gemm(K.GEMM_NT, x16, A.w16(inter.dense.weight), g16, bias=inter.dense.bias, epilogue=K.EPI_GELU, out2=z, out3=g)
+        return g, z, g16
     K.gemm(K.GEMM_NT, x, A.w(inter.dense.weight), g, bias=inter.dense.bias, epilogue=K.EPI_GELU, out2=z)
-    return g, z
+    return g, z, None
 
 
 def _inter_bwd(A: ParamArena, inter, x, dz, dres):
@@ -201,9 +232,11 @@ def _inter_bwd(A: ParamArena, inter, x, dz, dres):
 def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool):
     """BertAttention / BertCrossAttention: projections -> fused attention -> out-proj -> bias+dropout+residual+LN.
     ``att`` is the reference-named module (``.self.{query,key,value}``, ``.output.{dense,LayerNorm}``).
-    x is the bf16 MFMA operand; xres its f32 twin used as the residual (None -> x).  Returns (y bf16, y f32, saved)."""
-    ctx, s_core = _attn_core_fwd(A, att.self, x, kv_src, add_mask, d, Skv, save)
-    y, yf, s_out = _dense_norm_fwd(A, att.output, ctx, x if xres is None else xres, d, save)
+    x is the bf16 MFMA operand; xres its forward twin: f32 (residual only; None -> x) or, in the mixed16 mode, fp16
+    (residual AND forward GEMM operand).  Returns (y bf16, y twin, saved)."""
+    xres = _fwd_twin(A, x, xres, d)
+    ctx, ctx16, s_core = _attn_core_fwd(A, att.self, x, kv_src, add_mask, d, Skv, save, x16=xres if d.h16 else None)
+    y, yf, s_out = _dense_norm_fwd(A, att.output, ctx, x if xres is None else xres, d, save, h16=ctx16)
     return y, yf, ((ctx, s_core, s_out) if save else None)
 
 
@@ -217,9 +250,10 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
 
 
 def _ffn_block_fwd(A: ParamArena, layer, x, xres, d: Dims, save: bool):
-    """BertIntermediate + BertOutput.  Returns (y bf16, y f32, saved)."""
-    g, z = _inter_fwd(A, layer.intermediate, x)
-    y, yf, s_out = _dense_norm_fwd(A, layer.output, g, x if xres is None else xres, d, save)
+    """BertIntermediate + BertOutput.  Returns (y bf16, y twin, saved)."""
+    xres = _fwd_twin(A, x, xres, d)
+    g, z, g16 = _inter_fwd(A, layer.intermediate, x, xres if d.h16 else None)
+    y, yf, s_out = _dense_norm_fwd(A, layer.output, g, x if xres is None else xres, d, save, h16=g16)
     return y, yf, ((z, g, s_out) if save else None)
 
 
@@ -242,13 +276,14 @@ class EmbeddingsFn(torch.autograd.Function):
         H = d.H
         save = any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
         y = torch.empty(B * S, H, dtype=BF16, device=ids.device)
-        yf = torch.empty(B * S, H, dtype=F32, device=ids.device)
+        yf = torch.empty(B * S, H, dtype=F16 if d.h16 else F32, device=ids.device)   # forward twin (see _fwd_twin)
         xhat = torch.empty_like(y) if save else None
         rstd = torch.empty(B * S, dtype=F32, device=ids.device) if save else None
         seed = A.next_seed() if d.p_hidden > 0 else 0
         K.embed_fwd(ids, tt, mod.word_embeddings.weight, mod.position_embeddings.weight,
-                    mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias, y, y_f32=yf,
-                    xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed)
+                    mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias, y,
+                    xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed,
+                    **({"y_f16": yf} if d.h16 else {"y_f32": yf}))
         ctx.mod, ctx.A, ctx.d, ctx.seed = mod, A, d, seed
         ctx.save_for_backward(ids, tt, xhat, rstd)
         ctx.mark_non_differentiable(yf)
@@ -332,7 +367,7 @@ class AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, kv_src, sa, A: ParamArena, add_mask, d: Dims, Skv: int):
         save = any(ctx.needs_input_grad)
-        c, saved = _attn_core_fwd(A, sa, x, kv_src, add_mask, d, Skv, save)
+        c, _c16, saved = _attn_core_fwd(A, sa, x, kv_src, add_mask, d, Skv, save)
         ctx.sa, ctx.A, ctx.d, ctx.Skv, ctx.saved = sa, A, d, Skv, saved
         ctx.need_kv = kv_src is not None and kv_src.requires_grad
         ctx.save_for_backward(x, kv_src, add_mask, c)
@@ -381,7 +416,7 @@ class IntermediateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, x, inter, A: ParamArena):
-        g, z = _inter_fwd(A, inter, x)
+        g, z, _g16 = _inter_fwd(A, inter, x)
         ctx.inter, ctx.A = inter, A
         ctx.save_for_backward(x, z)
         return g

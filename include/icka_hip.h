@@ -125,6 +125,13 @@ int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias,
                 int32_t res_is_f32, const float* gamma, const float* beta, void* y, int64_t ldy, void* y2,
                 int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop,
                 uint64_t seed, void* stream);
+/* "mixed16" form of the same call: x_kind / res_kind are 0 = bf16, 1 = f32, 2 = fp16, and the twin copy of the output is
+ * fp16 (y_f16, contiguous, saturating at +-65504): it is both the fp16 MFMA operand of the next forward GEMM and the
+ * residual input of the next block, while y (bf16) stays the operand of the bf16 weight-gradient GEMM in backward. */
+int icka_ln_fwd_h(const void* x, int64_t ldx, int32_t x_kind, const float* bias, const void* residual, int64_t ldr,
+                  int32_t res_kind, const float* gamma, const float* beta, void* y, int64_t ldy, void* y2,
+                  int64_t ldy2, void* y_f16, void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop,
+                  uint64_t seed, void* stream);
 /* Backward of the above.  dy (+ optional dy2) are the incoming gradients of y.  Outputs: dres = gradient of the
  * residual input (bf16, may be NULL), dx = gradient of x (dropout mask re-generated from seed; may be NULL),
  * and the f32 parameter gradients dgamma[H], dbeta[H], dbias[H] (dbias may be NULL): added to the existing values
@@ -151,6 +158,11 @@ int icka_embed_fwd(const int64_t* ids, const int64_t* token_type, const float* w
                    const float* type, const float* gamma, const float* beta, void* y, float* y_f32, void* xhat,
                    float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps,
                    float p_drop, uint64_t seed, void* stream);
+/* "mixed16" form: the twin copy of the output is fp16 (see icka_ln_fwd_h). */
+int icka_embed_fwd_h(const int64_t* ids, const int64_t* token_type, const float* word, const float* pos,
+                     const float* type, const float* gamma, const float* beta, void* y, void* y_f16, void* xhat,
+                     float* rstd, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, float eps,
+                     float p_drop, uint64_t seed, void* stream);
 /* Backward.  dword / dpos are ALWAYS accumulated into with f32 atomics (the caller zeroes them for a fresh
  * gradient); dtype / dgamma / dbeta follow `accumulate` as in icka_ln_bwd.  Row `padding_idx` of the word table
  * receives no gradient (nn.Embedding(padding_idx=0), :387).  partials: icka_ln_bwd_workspace_floats(H) floats. */
@@ -197,6 +209,12 @@ int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
 int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                       const float* add_mask, void* O, int64_t ldo, float* lse, int32_t B, int32_t heads, int32_t Sq,
                       int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
+/* icka_attn_fwd / icka_attn_fwd_fp8 (fp8 != 0) with an additional fp16 copy O_f16 (may be NULL; same leading dimension
+ * ldo) of the context: the "mixed16" mode feeds it to the out-proj GEMM as fp16 operand, O (bf16) stays the operand of
+ * the bf16 weight-gradient GEMM and of icka_attn_bwd. */
+int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                     const float* add_mask, void* O, void* O_f16, int64_t ldo, float* lse, int32_t B, int32_t heads,
+                     int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, int32_t fp8, void* stream);
 /* Heads with Sq <= 128 and Skv <= 128 (the reference's max_seq_length 128 and 36/49 regions) take the whole-head
  * kernels: one block per (batch, head), forward without online-softmax rescaling, backward (dQ, dK, dV, delta) in
  * one launch.  icka_attn_set_whole_head(0) forces the tiled flash-style kernels for every shape (default 1). */
@@ -213,6 +231,11 @@ int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
 /* fp32 -> bf16 cast of a flat buffer (parameter shadow refresh); n elements. */
 int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int icka_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* both 16-bit weight shadows from the f32 masters in one pass: bf16 (backward operands) and fp16 (saturating; the
+ * forward operands of the "mixed16" mode).  16-byte aligned pointers. */
+/* contiguous bf16 (src_is_f32 = 0) or f32 (1) -> fp16, saturating at +-65504 */
+int icka_cast_to_f16(const void* src, int32_t src_is_f32, void* dst, int64_t n, void* stream);
+int icka_cast_f32_to_bf16_f16(const float* src, void* dst_bf16, void* dst_f16, int64_t n, void* stream);
 /* 2-D cast with zero padding: dst bf16 [M, ldd] ; dst[:, :N] = src f32 [M,N] (row stride lds), dst[:, N:ldd] = 0.
  * (logit gradients [M,C] -> a 16-byte-aligned bf16 GEMM operand.) */
 int icka_cast_pad_f32_to_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int32_t M, int32_t N,
