@@ -1,9 +1,10 @@
 """GPU: the HIP path at the FULL BASELINE.json configurations against the live CPU oracle (eval mode, same by-key
 seeded weights and seeded inputs): logits, loss and every parameter gradient, in both arithmetic modes.
 
-  c2  bert-base  (L12, H768)   seq 128, 36 regions, batch 32                      bf16 <= 2e-2, fp32 <= 1e-3
-  c4  bert-large (L24, H1024)  seq 256, 50 regions, batch 4 (tiled attention)     bf16: see C4_BF16_LOGIT_BAR, fp32 <= 1e-3
-  c5  bert-base, fp8 QK^T/PV in the cross-attention, batch 64                     within the bf16 budget
+  c2  bert-base  (L12, H768)   seq 128, 36 regions, batch 32                      bf16 <= 2e-2, mixed16 <= 2e-2, fp32 <= 1e-3
+  c4  bert-large (L24, H1024)  seq 256, 50 regions, batch 4 (tiled attention)     bf16: see C4_BF16_LOGIT_BAR, mixed16 <= 2e-2,
+                                                                                  fp32 <= 1e-3
+  c5  bert-base, fp8 QK^T/PV in the cross-attention, batch 64                     within the bf16 budget (bf16 and mixed16)
 
 The oracle (oracle/mner_oracle.py, pinned bit-exactly to the reference by tests/golden/make_golden.py) runs ONCE per
 configuration on the host cores; the gradient bars are 2x the values measured on MI355X (printed with the worst key).
@@ -107,6 +108,12 @@ def _both_modes(tag, cfgkw, B, S, R, seed, grad_bf16, grad_fp32, fp8=False, logi
         print("  [%s bf16] NOTE: %.3e exceeds north_star's 2e-2 bf16 tolerance (known gap at this depth; bar used %.1e)"
               % (tag, err, logit_bf16))
     del m16
+    torch.cuda.empty_cache()
+    # mixed16 (fp16 forward operands in the encoder layers, bf16 backward): must meet north_star's 2e-2 at EVERY depth
+    mx = icka_amd.set_precision(copy.deepcopy(model).cuda(), "mixed16")
+    errx, _ = _compare(tag + " mixed16" + ("+fp8 cross" if fp8 else ""), mx, P, ref, rloss, batch, LOGIT_TOL_BF16, grad_bf16)
+    assert errx < 0.75 * err, "mixed16 logits (%.3e) are not clearly closer to the reference than bf16 (%.3e)" % (errx, err)
+    del mx
     torch.cuda.empty_cache()
     m32 = icka_amd.set_precision(model.cuda(), "fp32")
     _compare(tag + " fp32", m32, P, ref, rloss, batch, LOGIT_TOL_FP32, grad_fp32)
