@@ -836,7 +836,22 @@ static void launch_small(const AttnArgs& a, int mode, hipStream_t st) {
 }
 // whole-head path when the head fits (returns false -> caller uses the tiled kernels).
 // mode 0: forward, 1: backward, 2: forward with fp8 QK^T / PV
+// forward only: up to 256 keys (bert-large, seq 256: BASELINE config c4) and any number of queries as 64-query blocks
+// (grid.y) that each stage the head's whole K and V (<= 64 KiB) once and keep their 16 x Skv scores per wave in
+// registers: no online-softmax rescaling, one barrier, where the tiled kernel re-stages and re-synchronises per 64 keys
+template <int KT>
+static void launch_small_fwd_blocks(const AttnArgs& a, hipStream_t st) {
+    const dim3 grid(a.B * a.h, (a.Sq + 63) / 64);
+    if (a.drop.thr) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, false, false>), grid, dim3(256), 0, st, a);
+}
 static bool try_small(const AttnArgs& a, int mode, hipStream_t st) {
+    if (mode == 0 && a.Skv <= 256 && (a.Sq > 128 || a.Skv > 128)) {
+        if (a.Skv > 128) launch_small_fwd_blocks<16>(a, st);
+        else if (a.Skv > 64) launch_small_fwd_blocks<8>(a, st);
+        else launch_small_fwd_blocks<4>(a, st);
+        return true;
+    }
     if (a.Sq > 128 || a.Skv > 128) return false;
     const bool q2 = a.Sq > 64, k8 = a.Skv > 64;
     if (q2 && k8) launch_small<2, 8>(a, mode, st);
