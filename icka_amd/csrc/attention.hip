@@ -640,14 +640,27 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
     }
 }
 
+// Heads of up to 256 x 256 (bert-large at seq 256: BASELINE config c4) run as <QT = 4, KT = 16>: one block per CU with
+// the whole 512-register file per wave (Pd and dS of a wave's 64 queries x 256 keys stay packed in 256 registers), the
+// mask read from LDS instead of registers, and the phase-B exchange done in groups of NCH 64-key chunks that fit the
+// dead K/V region (the [QR x KR] matrix no longer does).
 template <int QT, int KT, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a_) {
+__global__ __launch_bounds__(256, (QT * KT >= 64 ? 1 : 2)) void attn_bwd_small_kernel(const AttnArgs a_) {
     AttnArgs a = a_;
     a.drop = drop_resolve(a.drop);
     constexpr int QR = 64 * QT, KR = 16 * KT, KW = KT / 4;
-    __shared__ __attribute__((aligned(16))) char smem[(2 * QR + 2 * KR) * 128 + QR * 4];
+    // exchange region X (= the K/V tiles, dead after phase A, grown to one chunk when they are smaller): NCH chunks of
+    // [QR queries x 64 keys] bf16 at a time, NG groups per pass
+    constexpr int KV_BYTES = 2 * KR * 128, CH_BYTES = QR * 128;
+    constexpr int X_BYTES = KV_BYTES > CH_BYTES ? KV_BYTES : CH_BYTES;
+    constexpr int NCH = (X_BYTES / CH_BYTES) < KW ? (X_BYTES / CH_BYTES) : KW;
+    constexpr int NG = KW / NCH;
+    static_assert(KW % NCH == 0, "chunk groups");
+    constexpr bool MASK_LDS = KT >= 16;
+    __shared__ __attribute__((aligned(16))) char smem[2 * QR * 128 + X_BYTES + QR * 4 + (MASK_LDS ? KR * 4 : 0)];
     char* sQ = smem; char* sDO = smem + QR * 128; char* sK = sDO + QR * 128; char* sV = sK + KR * 128;
-    float* s_lse = reinterpret_cast<float*>(sV + KR * 128);
+    float* s_lse = reinterpret_cast<float*>(sK + X_BYTES);
+    float* s_mask = s_lse + QR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i15 = lane & 15;
     const int bh = blockIdx.x, head = bh % a.h, b = bh / a.h;
     const float* mb = a.mask + (int64_t)b * a.Skv;
@@ -658,6 +671,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
     stage_rows<KR>(sK, a.K + (int64_t)b * a.Skv * a.ldk + head * HD, a.ldk, a.Skv, tid);
     stage_rows<KR>(sV, a.V + (int64_t)b * a.Skv * a.ldv + head * HD, a.ldv, a.Skv, tid);
     if (tid < QR) s_lse[tid] = tid < a.Sq ? a.lse[(int64_t)bh * a.Sq + tid] : INFINITY;
+    if constexpr (MASK_LDS) {
+        static_assert(KR <= 256, "one mask element per thread");
+        if (tid < KR) s_mask[tid] = tid < a.Skv ? mb[tid] : -INFINITY;
+    }
     ATTN_STAMP(1);
     __syncthreads();
     ATTN_STAMP(2);
@@ -679,15 +696,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
         return;
     }
 
-    f32x4 mk[KT];   // additive mask of key 16*kt + 4*g + r; -inf past the end
+    f32x4 mk[MASK_LDS ? 1 : KT];   // additive mask of key 16*kt + 4*g + r; -inf past the end (large heads: from LDS)
+    if constexpr (!MASK_LDS) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * g + r;
-            const float mv = mb[key < a.Skv ? key : a.Skv - 1];   // clamped load + select: no divergent branch
-            mk[kt][r] = key < a.Skv ? mv : -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * g + r;
+                const float mv = mb[key < a.Skv ? key : a.Skv - 1];   // clamped load + select: no divergent branch
+                mk[kt][r] = key < a.Skv ? mv : -INFINITY;
+            }
+    }
+    // Large heads with dropout: all keep/drop decisions of this lane's (query, key) pairs are hashed FIRST, while nothing
+    // else is live, into one bit each (QT*KT*4 bits = 8 registers at 256 x 256); phase A then only tests bits.  With the
+    // hashes inside phase A the <4, 16> instance needed ~60 registers more than the 512 a wave can have (308 spilled,
+    // 175 us instead of ~90 per launch at B32 x 16 heads).
+    constexpr bool DROP_BITS = MASK_LDS && DROP;
+    uint32_t dbits[DROP_BITS ? QT * KT * 4 / 32 : 1];
+    if constexpr (DROP_BITS) {
+#pragma unroll
+        for (int w = 0; w < QT * KT * 4 / 32; ++w) dbits[w] = 0u;
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) {
+            const int q = 16 * (QT * wave + qi) + i15;
+            const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
+            const uint32_t hx = (idx_row + 4u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bit = (qi * KT + kt) * 4 + r;
+                    const uint32_t keep = icka_hash_tail(hx + (uint32_t)(16 * kt + r) * ICKA_HASH_C0, a.drop.s1) >= a.drop.thr ? 1u : 0u;
+                    dbits[bit >> 5] |= keep << (bit & 31);
+                }
         }
+#pragma unroll
+        for (int w = 0; w < QT * KT * 4 / 32; ++w) asm volatile("" : "+v"(dbits[w]));   // the hashes stay up here
+    }
     // ---- phase A: this wave owns queries [16*QT*wave, +16*QT) against every key: P, dP, delta = rowsum(P.dP), dS,
     //      dQ^T = K^T.dS^T straight from the accumulators.  Pd = dropout(P) and dS stay packed in registers for the
     //      exchange below (lane: query i15, keys 16kt + 4g .. +3 -> 8 bytes per kt).
@@ -700,7 +745,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
         const float lse_q = s_lse[q];
         const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
         const uint32_t hx = (idx_row + 4u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
-        f32x4 pr[KT], dpm[KT];   // P and dropout-masked dP
+        // P and dropout-masked dP of this query row block.  Large heads keep P bf16-packed (dS is rounded to bf16 for its
+        // MFMA anyway; dP - delta, where the cancellation is, stays f32): 32 registers fewer at the 512-register cap
+        f32x4 pr[MASK_LDS ? 1 : KT], dpm[KT];
         float dl = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -708,25 +755,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
             sc = mfma16(frag_row(sK, 16 * kt, 1, lane), qf1, sc);
             f32x4 dp = mfma16(frag_row(sV, 16 * kt, 0, lane), do0, f32x4{0.f, 0.f, 0.f, 0.f});
             dp = mfma16(frag_row(sV, 16 * kt, 1, lane), do1, dp);
-            f32x4 pd;
+            f32x4 pd, pvv;
+            f32x4 mkv;
+            if constexpr (MASK_LDS) mkv = *reinterpret_cast<const f32x4*>(s_mask + 16 * kt + 4 * g);
+            else mkv = mk[kt];
+            const uint32_t hk = hx + (uint32_t)(16 * kt) * ICKA_HASH_C0;
+            // large heads run at the 512-register cap: keep hipcc from overlapping the key tiles of a row block (it hoists
+            // the fragment reads, MFMAs and hashes of later tiles above the softmax of this one: +250 live registers)
+            if constexpr (MASK_LDS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(sc[r] * a.scale + mk[kt][r] - lse_q);   // mask -inf (key >= Skv) -> exactly 0
-                const float dm = drop_mul_x<DROP>(a.drop, hx + (uint32_t)(16 * kt + r) * ICKA_HASH_C0);
+                const float pv = __expf(sc[r] * a.scale + mkv[r] - lse_q);   // mask -inf (key >= Skv) -> exactly 0
+                float dm;
+                if constexpr (DROP_BITS) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int bit = (qi * KT + kt) * 4 + r;
+                    dm = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? a.drop.scale : 0.f;
+                } else {
+                    dm = drop_mul_x<DROP>(a.drop, hk + (uint32_t)r * ICKA_HASH_C0);
+                }
                 const float dv = dp[r] * dm;
-                pr[kt][r] = pv;
+                pvv[r] = pv;
                 dpm[kt][r] = dv;
                 pd[r] = pv * dm;
                 dl += pv * dv;
             }
-            pdp[qi][kt] = pack4(pd[0], pd[1], pd[2], pd[3]);
+            if constexpr (MASK_LDS) {
+                // large heads keep ONE packed copy per element: P itself (the dropout factor is applied from the keep bits
+                // when Pd is written to the exchange buffer in phase B): a second copy does not fit the register file
+                pdp[qi][kt] = pack4(pvv[0], pvv[1], pvv[2], pvv[3]);
+            } else {
+                pr[kt] = pvv;
+                pdp[qi][kt] = pack4(pd[0], pd[1], pd[2], pd[3]);
+            }
         }
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
         if (g == 0 && q < a.Sq) a.delta[(int64_t)bh * a.Sq + q] = dl;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const f32x4 d = pr[kt] * (dpm[kt] - dl) * a.scale;
+            f32x4 pk;
+            if constexpr (MASK_LDS) {
+                const bf16x4 pb = as_bf16x4(pdp[qi][kt]);
+                pk = f32x4{bf2f(pb[0]), bf2f(pb[1]), bf2f(pb[2]), bf2f(pb[3])};
+            } else {
+                pk = pr[kt];
+            }
+            const f32x4 d = pk * (dpm[kt] - dl) * a.scale;
             dsp[qi][kt] = pack4(d[0], d[1], d[2], d[3]);
         }
         f32x4 acc[4];
@@ -752,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
     //      phase A and hold exactly one [QR x KR] bf16 matrix, stored as KR/64 column tiles of the off_t image
     //      ([query row][64 keys]) so the reader takes it with the same transposing fragment read as dO^T / Q^T.
     char* sX = sK;
-    f32x4 acc_k[KW][4], acc_v[KW][4];
+    f32x4 acc_k[KW][4], acc_v[KW][4];   // tile index gi * NCH + j: 16-key tile 4*NCH*gi + NCH*wave + j of the head
 #pragma unroll
     for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
@@ -762,53 +837,73 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
         }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {   // 0: Pd -> dV, 1: dS -> dK
-        __syncthreads();                     // everyone is done reading K/V (pass 0) or Pd (pass 1)
 #pragma unroll
-        for (int qi = 0; qi < QT; ++qi)
+        for (int gi = 0; gi < NG; ++gi) {    // group of NCH 64-key chunks = 16-key tiles [4*NCH*gi, 4*NCH*(gi+1))
+            __syncthreads();                 // everyone is done reading K/V (first round) or the previous group
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const int qrow = 16 * (QT * wave + qi) + i15;
-                char* dst = sX + (kt >> 2) * (QR * 128) + off_t(qrow, 2 * (kt & 3) + (g >> 1)) + 8 * (g & 1);
-                *reinterpret_cast<u32x2*>(dst) = pass == 0 ? pdp[qi][kt] : dsp[qi][kt];
+            for (int qi = 0; qi < QT; ++qi)
+#pragma unroll
+                for (int kl = 0; kl < 4 * NCH; ++kl) {
+                    const int kt = 4 * NCH * gi + kl;
+                    const int qrow = 16 * (QT * wave + qi) + i15;
+                    char* dst = sX + (kl >> 2) * CH_BYTES + off_t(qrow, 2 * (kl & 3) + (g >> 1)) + 8 * (g & 1);
+                    u32x2 val = pass == 0 ? pdp[qi][kt] : dsp[qi][kt];
+                    if constexpr (DROP_BITS) {
+                        if (pass == 0) {   // Pd = P * dropout factor, from the packed P and the keep bits
+                            const bf16x4 pb = as_bf16x4(val);
+                            float pd4[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int bit = (qi * KT + kt) * 4 + r;
+                                pd4[r] = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? bf2f(pb[r]) * a.drop.scale : 0.f;
+                            }
+                            val = pack4(pd4[0], pd4[1], pd4[2], pd4[3]);
+                        }
+                    }
+                    *reinterpret_cast<u32x2*>(dst) = val;
+                }
+            __syncthreads();
+            ATTN_STAMP(4 + 2 * pass);
+            const char* other = pass == 0 ? sDO : sQ;
+#pragma unroll
+            for (int ks = 0; ks < 2 * QT; ++ks) {   // 32 queries per MFMA k-slot
+                bf16x8 xf[NCH];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int kk = NCH * wave + j;   // 16-key tile owned by this wave, inside the group
+                    xf[j] = frag_tr(sX + (kk >> 2) * CH_BYTES, kk & 3, ks, lane);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 of = frag_tr(other, dt, ks, lane);
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        if (pass == 0) acc_v[gi * NCH + j][dt] = mfma16(of, xf[j], acc_v[gi * NCH + j][dt]);
+                        else acc_k[gi * NCH + j][dt] = mfma16(of, xf[j], acc_k[gi * NCH + j][dt]);
+                    }
+                }
             }
-        __syncthreads();
-        ATTN_STAMP(4 + 2 * pass);
-        const char* other = pass == 0 ? sDO : sQ;
+            ATTN_STAMP(5 + 2 * pass);
+        }
+    }
 #pragma unroll
-        for (int ks = 0; ks < 2 * QT; ++ks) {   // 32 queries per MFMA k-slot
-            bf16x8 xf[KW];
+    for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int kk = KW * wave + kw;   // 16-key tile owned by this wave
-                xf[kw] = frag_tr(sX + (kk >> 2) * (QR * 128), kk & 3, ks, lane);
-            }
+        for (int j = 0; j < NCH; ++j) {
+            const int kw = gi * NCH + j;
+            const int key = 16 * (4 * NCH * gi + NCH * wave + j) + i15;
+            if (key < a.Skv) {
+                bf16_t* krow = a.dK + ((int64_t)b * a.Skv + key) * a.lddk + head * HD;
+                bf16_t* vrow = a.dV + ((int64_t)b * a.Skv + key) * a.lddv + head * HD;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 of = frag_tr(other, dt, ks, lane);
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
-                    if (pass == 0) acc_v[kw][dt] = mfma16(of, xf[kw], acc_v[kw][dt]);
-                    else acc_k[kw][dt] = mfma16(of, xf[kw], acc_k[kw][dt]);
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<u32x2*>(krow + 16 * dt + 4 * g) =
+                        pack4(acc_k[kw][dt][0], acc_k[kw][dt][1], acc_k[kw][dt][2], acc_k[kw][dt][3]);
+                    *reinterpret_cast<u32x2*>(vrow + 16 * dt + 4 * g) =
+                        pack4(acc_v[kw][dt][0], acc_v[kw][dt][1], acc_v[kw][dt][2], acc_v[kw][dt][3]);
                 }
             }
         }
-        ATTN_STAMP(5 + 2 * pass);
-    }
-#pragma unroll
-    for (int kw = 0; kw < KW; ++kw) {
-        const int key = 16 * (KW * wave + kw) + i15;
-        if (key < a.Skv) {
-            bf16_t* krow = a.dK + ((int64_t)b * a.Skv + key) * a.lddk + head * HD;
-            bf16_t* vrow = a.dV + ((int64_t)b * a.Skv + key) * a.lddv + head * HD;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                *reinterpret_cast<u32x2*>(krow + 16 * dt + 4 * g) =
-                    pack4(acc_k[kw][dt][0], acc_k[kw][dt][1], acc_k[kw][dt][2], acc_k[kw][dt][3]);
-                *reinterpret_cast<u32x2*>(vrow + 16 * dt + 4 * g) =
-                    pack4(acc_v[kw][dt][0], acc_v[kw][dt][1], acc_v[kw][dt][2], acc_v[kw][dt][3]);
-            }
-        }
-    }
     ATTN_RSTAMP(9);
 }
 
@@ -821,13 +916,16 @@ static void launch_small2(const AttnArgs& a, int mode, hipStream_t st) {
     // forward: heads of more than 64 queries run as two 64-query blocks (grid.y = 2, K/V staged twice) when that
     // balances the grid: B*h = 384 whole heads put 2 blocks on half of the 256 CUs and 1 on the rest, 768 half heads
     // put 3 on each
-    if (QT == 2 && (a.B * a.h) % 256 != 0) {
+    if constexpr (QT > 2) return;   // (QT = 4 exists for the backward only; the forward takes 64-query blocks)
+    else if (QT == 2 && (a.B * a.h) % 256 != 0) {
         if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, true>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, false>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
         return;
     }
-    if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true>), dim3(a.B * a.h), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, false>), dim3(a.B * a.h), dim3(256), 0, st, a);
+    if constexpr (QT <= 2) {
+        if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true>), dim3(a.B * a.h), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, false>), dim3(a.B * a.h), dim3(256), 0, st, a);
+    }
 }
 template <int QT, int KT>
 static void launch_small(const AttnArgs& a, int mode, hipStream_t st) {
@@ -850,6 +948,13 @@ static bool try_small(const AttnArgs& a, int mode, hipStream_t st) {
         if (a.Skv > 128) launch_small_fwd_blocks<16>(a, st);
         else if (a.Skv > 64) launch_small_fwd_blocks<8>(a, st);
         else launch_small_fwd_blocks<4>(a, st);
+        return true;
+    }
+    if (mode == 1 && a.Sq <= 256 && a.Skv <= 256 && (a.Sq > 128 || a.Skv > 128)) {
+        // whole 256-query heads, one block per CU: every key-length instance shares QT = 4
+        if (a.Skv > 128) launch_small<4, 16>(a, mode, st);
+        else if (a.Skv > 64) launch_small<4, 8>(a, mode, st);
+        else launch_small<4, 4>(a, mode, st);
         return true;
     }
     if (a.Sq > 128 || a.Skv > 128) return false;
