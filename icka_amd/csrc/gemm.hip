@@ -479,10 +479,12 @@ __device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, i
 
 // Second half of the LDS-staged epilogue: thread t finishes 8 consecutive columns (c8 = t & 15) of rows
 // (t >> 4) + RSTEP*i; 16 lanes cover a whole 128-column row -> 16-byte row-contiguous global accesses.
-template <int RSTEP, int NC8 = 16, bool WIDE = false>
+// WIDE: 0 = a 128-row tile of the 8-wave kernels; 1 / 2 = one 128-row pass of gemm_w3_kernel's 192- / 128-column tile (the
+// staged rows are 32-row slabs of four 64-row wave tiles; 192 columns use the off_cw image)
+template <int RSTEP, int NC8 = 16, int WIDE = 0>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
-    // NC8 = 8-column groups per tile row: 16 (128-wide tile) or 12 (96-wide: 12 lanes per row, 384 of 512 threads)
-    if (NC8 != 16 && tid >= RSTEP * NC8) return;
+    // NC8 = 8-column groups per tile row: 16 (128-wide tile), 12 (96-wide: 384 of 512 threads) or 24 (192-wide, 768 threads)
+    if (tid >= RSTEP * NC8) return;
     const int c8 = NC8 == 16 ? (tid & 15) : tid % NC8;   // 8-column group of the row
     const int rb = NC8 == 16 ? (tid >> 4) : tid / NC8;
     const int n = n0 + 8 * c8;
@@ -506,8 +508,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
         const int row = rb + RSTEP * i;
         // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
         const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + (WIDE ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + (WIDE ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
         float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
                       hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
         float a[8];
@@ -1141,17 +1143,21 @@ __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) 
 // straight from the accumulators through the general 4-column epilogue.  A is k-contiguous (NT and NN).
 constexpr int W3_A = 2 * TILE_BYTES, W3_B = 2 * TILE_BYTES;   // one k-tile of A (2 x 128 rows) / of B (2 x 96 columns)
 constexpr int W3_NA = 3, W3_NB = 2;                           // ring depths: 3 x 32 KiB + 2 x 32 KiB = 160 KiB = the whole LDS
-template <bool B_KM, bool F16 = false>
+template <bool B_KM, bool F16 = false, int BNW = 192>
 __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
-    const int nbn = g.N / 192, nb = gridDim.x;
+    // BNW = tile width: 192 (two 96-column halves) or 128 (two 64-column halves: N = 1024 at bert-large, 256 tiles = one
+    // round where 128x128 tiles take two); the B images keep their 16 KiB slots either way
+    constexpr int BH = BNW / 2, NB16 = BH / 16;
+    static_assert(BNW == 192 || BNW == 128, "tile width");
+    const int nbn = g.N / BNW, nb = gridDim.x;
     // blocks b and b+8 share an XCD: each XCD takes a contiguous row-major run of tiles (nb % 8 == 0, host-checked)
     const int sw = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-    const int m0 = (sw / nbn) * 256, n0 = (sw % nbn) * 192;
+    const int m0 = (sw / nbn) * 256, n0 = (sw % nbn) * BNW;
     const int nk = g.K / BK;
     if (wave >= 8) {
         // ------------------------------------------------------------------------------------------- loader waves
@@ -1165,10 +1171,10 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
         const bf16_t* pb1[4];
         dma_init<false>(pa0, g.A, g.lda, m0, lw, lane);
         dma_init<false>(pa1, g.A, g.lda, m0 + 128, lw, lane);
-        dma_init<B_KM, 96>(pb0, g.B, g.ldb, n0, lw, lane);
-        dma_init<B_KM, 96>(pb1, g.B, g.ldb, n0 + 96, lw, lane);
+        dma_init<B_KM, BH>(pb0, g.B, g.ldb, n0, lw, lane);
+        dma_init<B_KM, BH>(pb1, g.B, g.ldb, n0 + BH, lw, lane);
         const int64_t sa = BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
-        constexpr int NJB = B_KM ? 4 : 3;
+        constexpr int NJB = B_KM ? 4 : BH / 32;
         const uint32_t ldsB = lds0 + W3_NA * W3_A;
 #define ICKA_W3_A(SLOT)                                                          \
     do {                                                                         \
@@ -1185,7 +1191,7 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
         if (nk > 1) ICKA_W3_A(1);
         int sa3 = 2;   // A slot of tile kt+2
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();   // A(kt+1) may still be in flight
+            if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();   // A(kt+1) may still be in flight (8 pieces: 2 x 4)
             __builtin_amdgcn_s_barrier();        // tile kt published; every compute wave is done with tile kt-1
             if (kt + 1 < nk) ICKA_W3_B((kt + 1) & 1);
             if (kt + 2 < nk) ICKA_W3_A(sa3);
@@ -1195,13 +1201,13 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
 #undef ICKA_W3_B
     }
     // ---------------------------------------------------------------------------------------------- compute waves
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 96;
-    f32x4 acc[4][6];
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * BH;
+    f32x4 acc[4][NB16];
     if (wave < 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1209,15 +1215,15 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
             const char* sB = smem + W3_NA * W3_A + (kt & 1) * W3_B + (wave & 1) * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[4], fb[6];
+                bf16x8 fa[4], fb[NB16];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) fa[t] = read_frag<false>(sA, (wr & 127) + 16 * t, ks, lane);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) fb[t] = read_frag<B_KM>(sB, 16 * t, ks, lane);
+                for (int t = 0; t < NB16; ++t) fb[t] = read_frag<B_KM>(sB, 16 * t, ks, lane);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
+                    for (int ni = 0; ni < NB16; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
             }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
@@ -1234,13 +1240,14 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
             for (int h = 0; h < 2; ++h) {
                 const int row = (wave >> 1) * 32 + 16 * h + (lane & 15);
 #pragma unroll
-                for (int ni = 0; ni < 6; ++ni)
-                    *reinterpret_cast<f32x4*>(smem + off_cw(row, (wc >> 2) + 4 * ni + (lane >> 4))) =
-                        acc[2 * pass + h][ni] * g.alpha;
+                for (int ni = 0; ni < NB16; ++ni) {
+                    const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
+                    *reinterpret_cast<f32x4*>(smem + (BNW == 192 ? off_cw(row, ch) : off_c(row, ch))) = acc[2 * pass + h][ni] * g.alpha;
+                }
             }
         }
         __syncthreads();
-        epilogue_rows<32, 24, true>(g, smem, m0 + 32 * pass, n0, tid);
+        epilogue_rows<32, BNW / 8, BNW == 192 ? 1 : 2>(g, smem, m0 + 32 * pass, n0, tid);
     }
 }
 
@@ -1282,6 +1289,17 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
                         nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
                         hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
+                        ICKA_CHECK_LAUNCH();
+                        return 0;
+                    }
+                    // 256x128 tiles (the same kernel, 64-column halves) where 128x128 tiles would take exactly two rounds of
+                    // the CUs with one block each (N = 1024 at bert-large / M = 8192: 256 tiles), any K
+                    const int nb2 = (g.M / 256) * (g.N / 128);
+                    if (g_w3 && g.M % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nb2 % 8 == 0 && nb2 >= 192 && nb2 <= 256 &&
+                        !(g.n96ok && g_bn == 96) && !(g.K <= 1024 && g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f)) {
+                        // (short reductions with a plain f32 output stay on the 128-wide kernel: its direct epilogue beats
+                        //  the two staged passes here, 25.9 vs 28.3 us at 8192 x 1024 x 1024)
+                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }

@@ -183,9 +183,11 @@ def test_gemm_epilogues_and_dual_k():
 
 @pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("op", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K", [(4096, 2304, 768), (4096, 3072, 768), (2048, 3072, 64), (4096, 1536, 1024), (4096, 3072, 192)])
+@pytest.mark.parametrize("M,N,K", [(4096, 2304, 768), (4096, 3072, 768), (2048, 3072, 64), (4096, 1536, 1024), (4096, 3072, 192),
+                                   (8192, 1024, 1024), (8192, 1024, 3072), (8192, 768, 768), (6144, 1024, 192)])
 def test_gemm_wide_tiles(M, N, K, op, wide, request):
-    """256x192-tile kernel (qkv / ffn-up / d-ffn-down shapes: 128..256 tiles of one round) against fp32 matmul, with
+    """256x192-tile kernel (qkv / ffn-up / d-ffn-down shapes: 128..256 tiles of one round) and its 256x128-tile form (192..256
+    tiles: N = 1024 / 768 at M = 8192, long and short reductions) against fp32 matmul, with
     every epilogue those GEMMs use: bias, GELU (two outputs), GELU' (aux), fan-in add, f32 and bf16 outputs, odd and even
     k-tile counts; wide=0 runs the same calls on the 128x128 path."""
     k = _k()

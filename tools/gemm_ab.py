@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of one library knob on the N = 768 GEMM shapes of the c2 step, COLD operands (12 buffer sets), variants
 interleaved round by round in one process (median over rounds).  usage: gemm_ab.py knob v0 v1 [...]
-knob: ring | tile_n | direct"""
+knob: wide | ring | tile_n | direct"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ BF16 = torch.bfloat16
 lib = _lib.load()
 knob = sys.argv[1]
 vals = [int(v) for v in sys.argv[2:]]
-setter = {"ring": lib.icka_gemm_set_ring,
+setter = {"wide": lib.icka_gemm_set_wide_tiles, "ring": lib.icka_gemm_set_ring,
           "tile_n": lib.icka_gemm_set_tile_n, "direct": lib.icka_gemm_set_direct_epilogue}[knob]
 
 
@@ -29,7 +29,11 @@ def timed(fn, sets, reps=3):
     return e0.elapsed_time(e1) * 1e3 / (reps * len(sets))
 
 
-SHAPES = (("outproj NT f32", "NT", 4096, 768, 768, True), ("ffndn NT f32", "NT", 4096, 768, 3072, True),
+SHAPES = (("c4 outproj NT f32", "NT", 8192, 1024, 1024, True), ("c4 ffndn NT f32", "NT", 8192, 1024, 4096, True),
+          ("c4 dffnup NN bf16", "NN", 8192, 1024, 4096, False), ("c4 dqkv NN bf16", "NN", 8192, 1024, 3072, False),
+          ("c4 dout NN bf16", "NN", 8192, 1024, 1024, False), ("c5 ffndn NT f32", "NT", 8192, 768, 3072, True),
+          ("c5 dffnup NN bf16", "NN", 8192, 768, 3072, False), ("c5 outproj NT f32", "NT", 8192, 768, 768, True)) if os.environ.get("ICKA_AB_C4") else (
+          ("outproj NT f32", "NT", 4096, 768, 768, True), ("ffndn NT f32", "NT", 4096, 768, 3072, True),
           ("dffnup NN bf16", "NN", 4096, 768, 3072, False), ("dqkv NN bf16", "NN", 4096, 768, 2304, False),
           ("dout NN bf16", "NN", 4096, 768, 768, False), ("ffnup NT bf16", "NT", 4096, 3072, 768, False))
 for name, op, M, N, Kd, f32 in SHAPES:
