@@ -208,6 +208,13 @@ def main():
     if args.precision is None:
         args.precision = "bf16"
 
+    # stdout carries exactly ONE line (the JSON).  Native libraries write there too -- RCCL prints a five-line version banner
+    # to fd 1 when its first communicator is created -- so fd 1 is pointed at stderr for the whole run and the JSON line is
+    # written to a duplicate of the original stdout at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -458,7 +465,8 @@ def main():
             out["ms_per_step_with_adamw"] = round(opt_ms, 3)
         if cpu is not None:
             out["gpu_over_cpu"] = round(samples_per_s / cpu["value"], 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

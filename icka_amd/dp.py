@@ -30,6 +30,10 @@ import torch.distributed as dist
 from .arena import ParamArena
 
 
+import os as _os
+_DIAG = _os.environ.get("ICKA_DP_DIAG", "")   # "", or any of "none" / "cast" / "comm" (comma-separated): see _allreduce
+
+
 class GradReducer(object):
     def __init__(self, arena: ParamArena, group=None, bucket_mb: float = 64.0, comm_dtype: Optional[str] = None,
                  comm_bf16: Optional[bool] = None):
@@ -104,6 +108,15 @@ class GradReducer(object):
             self._allreduce(buf)
 
     def _allreduce(self, buf: torch.Tensor) -> None:
+        if _DIAG:   # diagnostic only (tools/fd_sweep.sh): leave out parts of the exchange to price them; wrong gradients
+            from . import kernels as K
+            if "cast" in _DIAG and self.comm_bf16:
+                st = self._stage[:buf.numel()]
+                K.cast_f32_to_bf16(buf, st)
+                K.cast_bf16_to_f32(st, buf)
+            if "comm" in _DIAG:
+                dist.all_reduce(self._stage[:buf.numel()] if self.comm_bf16 else buf, op=dist.ReduceOp.AVG, group=self.group)
+            return
         if self.backend == "nccl":
             if self.comm_bf16:
                 from . import kernels as K
