@@ -32,7 +32,9 @@ def timed(fn, sets, reps=3):
 SHAPES = (("c4 outproj NT f32", "NT", 8192, 1024, 1024, True), ("c4 ffndn NT f32", "NT", 8192, 1024, 4096, True),
           ("c4 dffnup NN bf16", "NN", 8192, 1024, 4096, False), ("c4 dqkv NN bf16", "NN", 8192, 1024, 3072, False),
           ("c4 dout NN bf16", "NN", 8192, 1024, 1024, False), ("c5 ffndn NT f32", "NT", 8192, 768, 3072, True),
-          ("c5 dffnup NN bf16", "NN", 8192, 768, 3072, False), ("c5 outproj NT f32", "NT", 8192, 768, 768, True)) if os.environ.get("ICKA_AB_C4") else (
+          ("c5 dffnup NN bf16", "NN", 8192, 768, 3072, False), ("c5 outproj NT f32", "NT", 8192, 768, 768, True),
+          ("c4 ffnup NT bf16", "NT", 8192, 4096, 1024, False), ("c4 dffndn NN bf16", "NN", 8192, 4096, 1024, False),
+          ("c5 ffnup NT bf16", "NT", 8192, 3072, 768, False), ("c5 qkv NT bf16", "NT", 8192, 2304, 768, False)) if os.environ.get("ICKA_AB_C4") else (
           ("outproj NT f32", "NT", 4096, 768, 768, True), ("ffndn NT f32", "NT", 4096, 768, 3072, True),
           ("dffnup NN bf16", "NN", 4096, 768, 3072, False), ("dqkv NN bf16", "NN", 4096, 768, 2304, False),
           ("dout NN bf16", "NN", 4096, 768, 768, False), ("ffnup NT bf16", "NT", 4096, 3072, 768, False))
