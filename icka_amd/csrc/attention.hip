@@ -768,7 +768,6 @@ __global__ __launch_bounds__(256, (QT * KT >= 64 ? 1 : 2)) void attn_bwd_small_k
                 const float pv = __expf(sc[r] * a.scale + mkv[r] - lse_q);   // mask -inf (key >= Skv) -> exactly 0
                 float dm;
                 if constexpr (DROP_BITS) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int bit = (qi * KT + kt) * 4 + r;
                     dm = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? a.drop.scale : 0.f;
                 } else {

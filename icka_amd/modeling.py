@@ -102,7 +102,9 @@ def set_precision(module: nn.Module, precision: str) -> nn.Module:
                the residual stream; weights: an fp16 shadow of the masters) on v_mfma_f32_16x16x32_f16 -- 11 significand
                bits instead of 8, same MFMA rate; q/k/v, the attention kernels, the gated head and the WHOLE backward
                stay bf16 (no loss scaling needed: no gradient is ever held in fp16).  For deep stacks whose bf16 rounding
-               noise exceeds the 2e-2 logit bar (bert-large, BASELINE config c4);
+               noise exceeds the 2e-2 logit bar (bert-large, BASELINE config c4).  It is implemented by the fused layer
+               Functions (BertEmbeddings, BertLayer, BertCrossAttentionLayer and the models built from them); sub-modules
+               called one by one (BertAttention, BertIntermediate, ...) and the hf_style shim keep bf16 operands;
     "fp32": f32 storage and f32-input MFMA arithmetic (icka_amd/exact.py) for the 1e-3 parity bar of BASELINE.json."""
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %s" % (PRECISIONS,))
