@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
 // mask read from LDS instead of registers, and the phase-B exchange done in groups of NCH 64-key chunks that fit the
 // dead K/V region (the [QR x KR] matrix no longer does).
 template <int QT, int KT, bool DROP>
-__global__ __launch_bounds__(256, (QT * KT >= 64 ? 1 : 2)) void attn_bwd_small_kernel(const AttnArgs a_) {
+__global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_bwd_small_kernel(const AttnArgs a_) {
     AttnArgs a = a_;
     a.drop = drop_resolve(a.drop);
     constexpr int QR = 64 * QT, KR = 16 * KT, KW = KT / 4;
@@ -653,10 +653,11 @@ __global__ __launch_bounds__(256, (QT * KT >= 64 ? 1 : 2)) void attn_bwd_small_k
     // [QR queries x 64 keys] bf16 at a time, NG groups per pass
     constexpr int KV_BYTES = 2 * KR * 128, CH_BYTES = QR * 128;
     constexpr int X_BYTES = KV_BYTES > CH_BYTES ? KV_BYTES : CH_BYTES;
-    constexpr int NCH = (X_BYTES / CH_BYTES) < KW ? (X_BYTES / CH_BYTES) : KW;
+    constexpr int NCAP = (X_BYTES / CH_BYTES) < KW ? (X_BYTES / CH_BYTES) : KW;
+    constexpr int NCH = KW % NCAP == 0 ? NCAP : 1;   // chunks per group: the largest that fits and divides KW (else one)
     constexpr int NG = KW / NCH;
     static_assert(KW % NCH == 0, "chunk groups");
-    constexpr bool MASK_LDS = KT >= 16;
+    constexpr bool MASK_LDS = QT * KT >= 36;          // the large instances: <3, 12> (192 x 192) and <4, *> (256 queries)
     __shared__ __attribute__((aligned(16))) char smem[2 * QR * 128 + X_BYTES + QR * 4 + (MASK_LDS ? KR * 4 : 0)];
     char* sQ = smem; char* sDO = smem + QR * 128; char* sK = sDO + QR * 128; char* sV = sK + KR * 128;
     float* s_lse = reinterpret_cast<float*>(sK + X_BYTES);
@@ -712,10 +713,10 @@ __global__ __launch_bounds__(256, (QT * KT >= 64 ? 1 : 2)) void attn_bwd_small_k
     // hashes inside phase A the <4, 16> instance needed ~60 registers more than the 512 a wave can have (308 spilled,
     // 175 us instead of ~90 per launch at B32 x 16 heads).
     constexpr bool DROP_BITS = MASK_LDS && DROP;
-    uint32_t dbits[DROP_BITS ? QT * KT * 4 / 32 : 1];
+    uint32_t dbits[DROP_BITS ? (QT * KT * 4 + 31) / 32 : 1];
     if constexpr (DROP_BITS) {
 #pragma unroll
-        for (int w = 0; w < QT * KT * 4 / 32; ++w) dbits[w] = 0u;
+        for (int w = 0; w < (QT * KT * 4 + 31) / 32; ++w) dbits[w] = 0u;
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi) {
             const int q = 16 * (QT * wave + qi) + i15;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(256, (QT * KT >= 64 ? 1 : 2)) void attn_bwd_small_k
                 }
         }
 #pragma unroll
-        for (int w = 0; w < QT * KT * 4 / 32; ++w) asm volatile("" : "+v"(dbits[w]));   // the hashes stay up here
+        for (int w = 0; w < (QT * KT * 4 + 31) / 32; ++w) asm volatile("" : "+v"(dbits[w]));   // the hashes stay up here
     }
     // ---- phase A: this wave owns queries [16*QT*wave, +16*QT) against every key: P, dP, delta = rowsum(P.dP), dS,
     //      dQ^T = K^T.dS^T straight from the accumulators.  Pd = dropout(P) and dS stay packed in registers for the
@@ -944,14 +945,17 @@ static void launch_small_fwd_blocks(const AttnArgs& a, hipStream_t st) {
 }
 static bool try_small(const AttnArgs& a, int mode, hipStream_t st) {
     if (mode == 0 && a.Skv <= 256 && (a.Sq > 128 || a.Skv > 128)) {
-        if (a.Skv > 128) launch_small_fwd_blocks<16>(a, st);
+        if (a.Skv > 192) launch_small_fwd_blocks<16>(a, st);
+        else if (a.Skv > 128) launch_small_fwd_blocks<12>(a, st);
         else if (a.Skv > 64) launch_small_fwd_blocks<8>(a, st);
         else launch_small_fwd_blocks<4>(a, st);
         return true;
     }
     if (mode == 1 && a.Sq <= 256 && a.Skv <= 256 && (a.Sq > 128 || a.Skv > 128)) {
-        // whole 256-query heads, one block per CU: every key-length instance shares QT = 4
-        if (a.Skv > 128) launch_small<4, 16>(a, mode, st);
+        // whole heads of up to 256 queries, one block per CU (192 x 192 has its own instance: the prompt-spliced sequences
+        // of the published model are 180 long)
+        if (a.Sq <= 192 && a.Skv <= 192 && a.Skv > 128) launch_small<3, 12>(a, mode, st);
+        else if (a.Skv > 128) launch_small<4, 16>(a, mode, st);
         else if (a.Skv > 64) launch_small<4, 8>(a, mode, st);
         else launch_small<4, 4>(a, mode, st);
         return true;

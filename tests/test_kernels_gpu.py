@@ -421,7 +421,8 @@ def _attn_ref(q, k_, v, add_mask, dmask, B, h, Sq, Skv):
                                           (2, 4, 128, 36, 0.1), (2, 3, 128, 128, 0.1), (1, 2, 32, 200, 0.0),
                                           (1, 16, 256, 256, 0.1), (2, 2, 49, 128, 0.1), (1, 2, 5, 7, 0.0),
                                           (2, 2, 128, 49, 0.1), (1, 3, 65, 65, 0.1), (1, 2, 300, 300, 0.1), (1, 2, 512, 512, 0.0),
-                                          (2, 2, 200, 130, 0.1), (1, 2, 256, 64, 0.1), (1, 2, 320, 50, 0.0)])
+                                          (2, 2, 200, 130, 0.1), (1, 2, 256, 64, 0.1), (1, 2, 320, 50, 0.0),
+                                          (2, 3, 180, 180, 0.1), (1, 2, 192, 150, 0.0), (1, 2, 150, 192, 0.1)])
 @pytest.mark.parametrize("whole_head", [True, False])
 def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
     k = _k()

@@ -21,11 +21,16 @@ def main():
     ap.add_argument("--p", type=float, default=0.1)
     ap.add_argument("--whole", type=int, default=1)
     ap.add_argument("--c4", action="store_true", help="bert-large geometry: 16 heads, 256 x 256 (tiled kernels)")
+    ap.add_argument("--shape", default=None, help="Sq,Skv,heads: one explicit shape (batch 32)")
     args = ap.parse_args()
     K.attn_set_whole_head(bool(args.whole))
     B, h, H = (32, 16, 1024) if args.c4 else (32, 12, 768)
     torch.manual_seed(0)
-    for Sq, Skv in (((256, 256), (256, 50)) if args.c4 else ((128, 128), (128, 36))):
+    shapes = ((256, 256), (256, 50)) if args.c4 else ((128, 128), (128, 36))
+    if args.shape:
+        sq, skv, h = (int(v) for v in args.shape.split(","))
+        H, shapes = 64 * h, ((sq, skv),)
+    for Sq, Skv in shapes:
         qkv = torch.randn(B * Sq, 3 * H, device="cuda").to(BF16)
         kv = torch.randn(B * Skv, 2 * H, device="cuda").to(BF16) if Skv != Sq else qkv[:, H:]
         q, k, v = qkv[:, :H], kv[:, :H], kv[:, H:2 * H]
