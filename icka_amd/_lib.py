@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("alpha", c_f32), ("beta", c_f32),
         ("epilogue", c_i32),
         ("colsum_out", c_vp), ("colsum_accumulate", c_i32),
-        ("ab_f16", c_i32), ("C3", c_vp), ("ldc3", c_i64),
+        ("ab_f16", c_i32), ("C3", c_vp), ("ldc3", c_i64), ("aux_f16", c_i32),
     ]
 
 
@@ -95,6 +95,7 @@ PROTOTYPES = {
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_set_whole_head": (None, [c_i32]),
     "icka_cls_head_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "icka_cls_head_fwd_h": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_cls_head_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                   c_vp]),
     "icka_cls_head_bwd_slabs": (c_i32, [c_i32]),

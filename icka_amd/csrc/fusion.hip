@@ -297,6 +297,8 @@ __device__ __forceinline__ void cls_st8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
 }
 
+// F16: seq, gated and W are IEEE fp16 (the "mixed16" head: the classifier reads the fp16 twins, 11 significand bits)
+template <bool F16>
 __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict__ gated,
                                                            const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                            float* __restrict__ logits, int M, int H, int C) {
@@ -335,12 +337,24 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const bf16_t* __restr
                 for (int c = 0; c < CLS_MAXC; ++c) {
                     if (c < C) {
                         float w[8];
-                        cls_ld8(sW + (int64_t)c * 2 * H + j * 8, w);
+                        if constexpr (F16) {
+                            const f16x8 wv = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(sW + (int64_t)c * 2 * H + j * 8));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) w[e] = (float)wv[e];
+                        } else {
+                            cls_ld8(sW + (int64_t)c * 2 * H + j * 8, w);
+                        }
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
-                            const bf16x8 xv = as_bf16x8(xr[r][i]);
+                            if constexpr (F16) {
+                                const f16x8 xv = __builtin_bit_cast(f16x8, xr[r][i]);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) acc[r][c] += bf2f(xv[e]) * w[e];
+                                for (int e = 0; e < 8; ++e) acc[r][c] += (float)xv[e] * w[e];
+                            } else {
+                                const bf16x8 xv = as_bf16x8(xr[r][i]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) acc[r][c] += bf2f(xv[e]) * w[e];
+                            }
                         }
                     }
                 }
@@ -458,18 +472,31 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const bf16_t* __restr
 extern "C" int32_t icka_cls_head_bwd_slabs(int32_t M) { return (M + CLS_TB - 1) / CLS_TB; }
 extern "C" int64_t icka_cls_head_slab_floats(int32_t H, int32_t C) { return (int64_t)C * 2 * H + CLS_MAXC; }
 
-extern "C" int icka_cls_head_fwd(const void* seq, const void* gated, const void* W, const float* bias, float* logits,
-                                 int32_t M, int32_t H, int32_t C, void* stream) {
+static int cls_head_fwd_impl(bool f16, const void* seq, const void* gated, const void* W, const float* bias, float* logits,
+                             int32_t M, int32_t H, int32_t C, void* stream) {
     if (!seq || !gated || !W || !logits) return ICKA_E_ARG;
     if (M <= 0 || H <= 0 || H % 8 || C <= 0 || C > CLS_MAXC || (int64_t)C * 2 * H * 2 > 44 * 1024) return ICKA_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(seq) | reinterpret_cast<uintptr_t>(gated) | reinterpret_cast<uintptr_t>(W)) & 15)
         return ICKA_E_ALIGN;
     int grid = (M + 7) / 8;   // 4 waves x 2 rows per pass
     grid = grid > 512 ? 512 : grid;
-    hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(grid), dim3(256), (size_t)C * 2 * H * 2, (hipStream_t)stream,
-                       (const bf16_t*)seq, (const bf16_t*)gated, (const bf16_t*)W, bias, logits, M, H, C);
+    if (f16)
+        hipLaunchKernelGGL(cls_head_fwd_kernel<true>, dim3(grid), dim3(256), (size_t)C * 2 * H * 2, (hipStream_t)stream,
+                           (const bf16_t*)seq, (const bf16_t*)gated, (const bf16_t*)W, bias, logits, M, H, C);
+    else
+        hipLaunchKernelGGL(cls_head_fwd_kernel<false>, dim3(grid), dim3(256), (size_t)C * 2 * H * 2, (hipStream_t)stream,
+                           (const bf16_t*)seq, (const bf16_t*)gated, (const bf16_t*)W, bias, logits, M, H, C);
     ICKA_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int icka_cls_head_fwd(const void* seq, const void* gated, const void* W, const float* bias, float* logits,
+                                 int32_t M, int32_t H, int32_t C, void* stream) {
+    return cls_head_fwd_impl(false, seq, gated, W, bias, logits, M, H, C, stream);
+}
+// "mixed16" form: seq, gated and W are fp16
+extern "C" int icka_cls_head_fwd_h(const void* seq, const void* gated, const void* W, const float* bias, float* logits,
+                                   int32_t M, int32_t H, int32_t C, void* stream) {
+    return cls_head_fwd_impl(true, seq, gated, W, bias, logits, M, H, C, stream);
 }
 
 extern "C" int icka_cls_head_bwd(const void* dl, int64_t ldd, const void* seq, const void* gated, const void* gate,

@@ -45,6 +45,7 @@ struct GemmArgs {
     int f16;           // operands are IEEE fp16 (v_mfma_f32_16x16x32_f16; NT only): the "mixed16" forward GEMMs
     int c_f16;         // main output C is fp16 (c_f32 == 0)
     bf16_t* C3; int64_t ldc3;   // optional bf16 copy of the main output (the weight-gradient operand of an fp16 activation)
+    int aux_f16;       // the epilogue operand aux is fp16 (read through load8_aux / load4_aux)
 };
 
 // k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
@@ -134,6 +135,11 @@ __device__ __forceinline__ void load4(const bf16_t* base, int64_t ld, int m, int
         for (int r = 0; r < 4; ++r) o[r] = r < nvalid ? bf2f(p[r]) : 0.f;
     }
 }
+__device__ __forceinline__ void load4_aux(const bf16_t* base, int64_t ld, int m, int n, int nvalid, int f16, float (&o)[4]) {
+    if (!f16) { load4(base, ld, m, n, nvalid, o); return; }
+    const _Float16* p = reinterpret_cast<const _Float16*>(base) + (int64_t)m * ld + n;
+    for (int r = 0; r < 4; ++r) o[r] = r < nvalid ? (float)p[r] : 0.f;
+}
 __device__ __forceinline__ void store4_bf16(bf16_t* base, int64_t ld, int m, int n, int nvalid, const float (&v)[4]) {
     bf16_t* p = base + (int64_t)m * ld + n;
     if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) {
@@ -162,24 +168,24 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
             for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
             break;
         case ICKA_EPI_DGELU:
-            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            load4_aux(g.aux, g.ldaux, m, n, nvalid, g.aux_f16, a);
             for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(a[r]);
             break;
         case ICKA_EPI_ADD:
-            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            load4_aux(g.aux, g.ldaux, m, n, nvalid, g.aux_f16, a);
             for (int r = 0; r < 4; ++r) v[r] += a[r];
             break;
         case ICKA_EPI_GATE:
             for (int r = 0; r < 4; ++r) v[r] = sigmoid_f(v[r]);
             if (g.C2) store4_bf16(g.C2, g.ldc2, m, n, nvalid, v);
-            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            load4_aux(g.aux, g.ldaux, m, n, nvalid, g.aux_f16, a);
             for (int r = 0; r < 4; ++r) v[r] *= a[r];
             break;
         case ICKA_EPI_TANH:
             for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
             break;
         case ICKA_EPI_ADD_RELU:
-            load4(g.aux, g.ldaux, m, n, nvalid, a);
+            load4_aux(g.aux, g.ldaux, m, n, nvalid, g.aux_f16, a);
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + a[r], 0.f);
             break;
         case ICKA_EPI_RELU:
@@ -434,6 +440,16 @@ __device__ __forceinline__ void load8_bf16(const bf16_t* p, float (&o)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
 }
+// epilogue operand in either 16-bit type (same element size: the pointer arithmetic is shared)
+__device__ __forceinline__ void load8_aux(const bf16_t* p, int f16, float (&o)[8]) {
+    if (f16) {
+        const f16x8 v = __builtin_bit_cast(f16x8, ld_once(reinterpret_cast<const u32x4*>(p)));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    } else {
+        load8_bf16(p, o);
+    }
+}
 __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     bf16x8 o;
 #pragma unroll
@@ -520,12 +536,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
                 break;
             case ICKA_EPI_DGELU:
-                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(a[e]);
                 break;
             case ICKA_EPI_ADD:
-                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += a[e];
                 break;
@@ -533,7 +549,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
                 if (g.C2) store8_bf16(g.C2 + (int64_t)m * g.ldc2 + n, v);
-                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= a[e];
                 break;
@@ -542,7 +558,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
                 break;
             case ICKA_EPI_ADD_RELU:
-                load8_bf16(g.aux + (int64_t)m * g.ldaux + n, a);
+                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + a[e], 0.f);
                 break;
@@ -1423,7 +1439,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.alpha = d->alpha; g.beta = d->beta; g.epi = d->epilogue;
     if (d->c_is_f32 < 0 || d->c_is_f32 > 2) return ICKA_E_ARG;
     g.c_f32 = d->c_is_f32 == 1; g.c_f16 = d->c_is_f32 == 2;
-    g.f16 = d->ab_f16 != 0; g.C3 = (bf16_t*)d->C3; g.ldc3 = d->ldc3;
+    g.f16 = d->ab_f16 != 0; g.C3 = (bf16_t*)d->C3; g.ldc3 = d->ldc3; g.aux_f16 = d->aux_f16 != 0;
     if (g.f16 && d->op != ICKA_GEMM_NT) return ICKA_E_ARG;       // fp16 operands: forward (NT) GEMMs only
     if (g.c_f16 && d->beta != 0.f) return ICKA_E_ARG;              // fp16 outputs are never accumulated into
     if (g.C3 && !g.c_f16) return ICKA_E_ARG;                       // C3 = bf16 twin of an fp16 main output

@@ -141,8 +141,9 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
         _mat(out2, "out2")
     d.C2, d.ldc2 = _ptr(out2), _ld(out2)
     if aux is not None:
-        _mat(aux, "aux")
+        _mat(aux, "aux", F16 if aux.dtype == F16 else BF16)
     d.aux, d.ldaux = _ptr(aux), _ld(aux)
+    d.aux_f16 = int(aux is not None and aux.dtype == F16)
     if bias is not None:
         _dev(bias, "bias")
         if bias.dtype != F32 or bias.numel() != N or not bias.is_contiguous():
@@ -192,16 +193,19 @@ def slab_reduction(partials: torch.Tensor, nslab: int, H: int, outs, accumulate:
 
 
 def cls_head_fwd(seq, gated, W, bias, logits):
-    """logits f32 [M,C] = [seq | gated] . W^T + bias (W bf16 [C, 2H])."""
-    _mat(seq, "seq"); _mat(gated, "gated")
+    """logits f32 [M,C] = [seq | gated] . W^T + bias (W [C, 2H]); seq, gated and W all bf16, or all fp16 (mixed16)."""
+    dt = seq.dtype if seq.dtype == F16 else BF16
+    _mat(seq, "seq", dt); _mat(gated, "gated", dt)
     M, H = seq.shape
     Cn = W.shape[0]
     if not (seq.is_contiguous() and gated.is_contiguous() and W.is_contiguous() and logits.is_contiguous()):
         raise ValueError("cls_head_fwd: contiguous operands")
-    if W.dtype != BF16 or tuple(W.shape) != (Cn, 2 * H) or logits.dtype != F32 or tuple(logits.shape) != (M, Cn):
-        raise ValueError("cls_head_fwd: W bf16 [C,2H], logits f32 [M,C]")
-    check(_lib.load().icka_cls_head_fwd(seq.data_ptr(), gated.data_ptr(), W.data_ptr(), _ptr(bias), logits.data_ptr(),
-                                        M, H, Cn, _stream()), "icka_cls_head_fwd")
+    if W.dtype != dt or tuple(W.shape) != (Cn, 2 * H) or logits.dtype != F32 or tuple(logits.shape) != (M, Cn):
+        raise ValueError("cls_head_fwd: W %s [C,2H], logits f32 [M,C]" % dt)
+    lib = _lib.load()
+    fn = lib.icka_cls_head_fwd_h if dt == F16 else lib.icka_cls_head_fwd
+    check(fn(seq.data_ptr(), gated.data_ptr(), W.data_ptr(), _ptr(bias), logits.data_ptr(), M, H, Cn, _stream()),
+          "icka_cls_head_fwd")
     return logits
 
 

@@ -100,8 +100,8 @@ def set_precision(module: nn.Module, precision: str) -> nn.Module:
     "bf16" (default): bf16 MFMA operands, f32 accumulation / statistics / residual stream -- the product path;
     "mixed16": the FORWARD GEMMs of the encoder layers read IEEE fp16 operands (activations: an fp16 copy that is also
                the residual stream; weights: an fp16 shadow of the masters) on v_mfma_f32_16x16x32_f16 -- 11 significand
-               bits instead of 8, same MFMA rate; q/k/v, the attention kernels, the gated head and the WHOLE backward
-               stay bf16 (no loss scaling needed: no gradient is ever held in fp16).  For deep stacks whose bf16 rounding
+               bits instead of 8, same MFMA rate -- and so do the gate GEMM and the classifier of the gated head; q/k/v, the
+               attention kernels, the region projection and the WHOLE backward stay bf16 (no loss scaling needed: no gradient is ever held in fp16).  For deep stacks whose bf16 rounding
                noise exceeds the 2e-2 logit bar (bert-large, BASELINE config c4).  It is implemented by the fused layer
                Functions (BertEmbeddings, BertLayer, BertCrossAttentionLayer and the models built from them); sub-modules
                called one by one (BertAttention, BertIntermediate, ...) and the hf_style shim keep bf16 operands;
@@ -758,7 +758,14 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         # ---- gate + classifier (:1363-1371)
         if _is_exact(self):
             return X.GatedHeadFn.apply(A.anchor, seq, cross, self, A).view(B, S, self.num_labels)
-        logits = ops.GatedHeadFn.apply(A.anchor, seq, cross, self, A)
+        seq16 = cross16 = None
+        if _is_mixed(self) and self.variant != "gate_cl":
+            # the fp16 twins of the two streams (left by the last encoder / cross layer; made from the bf16 tensors when a
+            # dropout or fan-out node sits in between) feed the gate GEMM and the classifier
+            d16 = _dims(cfg, B, S, 0, self.training, mixed=True)
+            seq16 = ops._fwd_twin(A, seq, seqf, d16)
+            cross16 = ops._fwd_twin(A, cross, crossf, d16)
+        logits = ops.GatedHeadFn.apply(A.anchor, seq, cross, self, A, seq16, cross16)
         return logits.view(B, S, self.num_labels)
 
     def forward(self, input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_mean=None,

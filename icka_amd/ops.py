@@ -505,20 +505,37 @@ class GatedHeadFn(torch.autograd.Function):
     reduction from two buffers / two weight matrices, and so does the classifier GEMM."""
 
     @staticmethod
-    def forward(ctx, anchor, seq, cross, head, A: ParamArena):
+    def forward(ctx, anchor, seq, cross, head, A: ParamArena, seq16=None, cross16=None):
+        """seq16 / cross16 (mixed16): the fp16 twins of seq / cross.  The gate GEMM then reads fp16 operands and writes the
+        gated product in fp16 (+ the bf16 copy the backward reads), and the classifier reads fp16 inputs and weights."""
         M, H = seq.shape
         C = head.classifier.weight.shape[0]
         gate = torch.empty(M, H, dtype=BF16, device=seq.device)
         gated = torch.empty_like(gate)
-        K.gemm(K.GEMM_NT, seq, A.w(head.Gate_text.weight), gated, A2=cross, B2=A.w(head.Gate_image.weight),
-               bias=head.Gate_text.bias, bias2=head.Gate_image.bias, epilogue=K.EPI_GATE, aux=cross, out2=gate)
-        Wc = A.w(head.classifier.weight)
-        logits = torch.empty(M, C, dtype=F32, device=seq.device)
+        h16 = seq16 is not None and cross16 is not None
         ctx.skinny = C <= 16 and H % 8 == 0 and 2 * H // 8 <= 256 and C * 2 * H * 2 <= 44 * 1024
-        if ctx.skinny:   # HBM-bound kernels for the 13-wide output (see icka_cls_head_fwd)
-            K.cls_head_fwd(seq, gated, Wc, head.classifier.bias, logits)
+        logits = torch.empty(M, C, dtype=F32, device=seq.device)
+        if h16:
+            if A.shadow16 is None:
+                A.enable_fp16_shadow()
+                A.sync(force=True)
+            gated16 = torch.empty(M, H, dtype=F16, device=seq.device)
+            K.gemm(K.GEMM_NT, seq16, A.w16(head.Gate_text.weight), gated16, A2=cross16, B2=A.w16(head.Gate_image.weight),
+                   bias=head.Gate_text.bias, bias2=head.Gate_image.bias, epilogue=K.EPI_GATE, aux=cross16, out2=gate,
+                   out3=gated)
+            Wc = A.w16(head.classifier.weight)
+            if ctx.skinny:
+                K.cls_head_fwd(seq16, gated16, Wc, head.classifier.bias, logits)
+            else:
+                K.gemm(K.GEMM_NT, seq16, Wc[:, :H], logits, A2=gated16, B2=Wc[:, H:], bias=head.classifier.bias)
         else:
-            K.gemm(K.GEMM_NT, seq, Wc[:, :H], logits, A2=gated, B2=Wc[:, H:], bias=head.classifier.bias)
+            K.gemm(K.GEMM_NT, seq, A.w(head.Gate_text.weight), gated, A2=cross, B2=A.w(head.Gate_image.weight),
+                   bias=head.Gate_text.bias, bias2=head.Gate_image.bias, epilogue=K.EPI_GATE, aux=cross, out2=gate)
+            Wc = A.w(head.classifier.weight)
+            if ctx.skinny:   # HBM-bound kernels for the 13-wide output (see icka_cls_head_fwd)
+                K.cls_head_fwd(seq, gated, Wc, head.classifier.bias, logits)
+            else:
+                K.gemm(K.GEMM_NT, seq, Wc[:, :H], logits, A2=gated, B2=Wc[:, H:], bias=head.classifier.bias)
         ctx.head, ctx.A = head, A
         ctx.save_for_backward(seq, cross, gate, gated)
         return logits
@@ -580,7 +597,7 @@ class GatedHeadFn(torch.autograd.Function):
         K.gemm(K.GEMM_NN, du, A.w(head.Gate_text.weight), dseq, epilogue=K.EPI_ADD, aux=dseq_c)
         K.gemm(K.GEMM_NN, du, A.w(head.Gate_image.weight), dcross, epilogue=K.EPI_ADD, aux=dcross_d)
         A.flush_final()
-        return None, dseq, dcross, None, None
+        return None, dseq, dcross, None, None, None, None
 
 
 class SampleGateFn(torch.autograd.Function):

@@ -70,6 +70,7 @@ typedef struct icka_gemm_desc {
      * be 0) and C3, if not NULL, receives a bf16 copy of it (the operand the bf16 weight-gradient GEMM reads later). */
     int32_t ab_f16;
     void* C3; int64_t ldc3;
+    int32_t aux_f16;       /* the epilogue operand `aux` is fp16 instead of bf16 (mixed16 gate: sigmoid(.) * cross_fp16) */
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that
@@ -269,6 +270,10 @@ int icka_gate_bwd(const void* dout, int64_t lddout, const void* g, const void* c
  * Needs 2H/8 <= 256 (H <= 1024). */
 int icka_cls_head_fwd(const void* seq, const void* gated, const void* W, const float* bias, float* logits, int32_t M,
                       int32_t H, int32_t C, void* stream);
+/* "mixed16" form of icka_cls_head_fwd: seq, gated and W are IEEE fp16 (the fp16 twins of the encoder outputs, the fp16
+ * gate product of icka_gemm and the fp16 weight shadow). */
+int icka_cls_head_fwd_h(const void* seq, const void* gated, const void* W, const float* bias, float* logits, int32_t M,
+                        int32_t H, int32_t C, void* stream);
 int icka_cls_head_bwd(const void* dl, int64_t ldd, const void* seq, const void* gated, const void* gate,
                       const void* cross, const void* W, void* dseq, void* du, void* dcross, float* partials, int32_t M,
                       int32_t H, int32_t C, void* stream);

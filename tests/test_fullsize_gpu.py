@@ -25,7 +25,7 @@ LOGIT_TOL_FP32 = 1e-3
 # 13,312 logits (the value moves with the kernel variant: it is rounding noise), ABOVE north_star's 2e-2.  The per-layer
 # hidden-state error against the fp32 mode grows as sqrt(depth) (tools/depth_error.py), every 16-bit GEMM operand carries
 # 2^-9 relative rounding (tools/rounding_attribution.py: all forward GEMMs contribute about equally).  The remedy is the
-# "mixed16" mode (fp16 forward operands, 2^-12): 8.8e-3 on this configuration, asserted at 2e-2 below; bench.py's c4 preset
+# "mixed16" mode (fp16 forward operands, 2^-12): 3.8e-3 on this configuration, asserted at 2e-2 below; bench.py's c4 preset
 # runs it.  The pure-bf16 leg is kept with a bar of 3e-2 so that the gap stays measured and visible.
 C4_BF16_LOGIT_BAR = 3e-2
 
@@ -113,7 +113,7 @@ def _both_modes(tag, cfgkw, B, S, R, seed, grad_bf16, grad_fp32, fp8=False, logi
     # mixed16 (fp16 forward operands in the encoder layers, bf16 backward): must meet north_star's 2e-2 at EVERY depth
     mx = icka_amd.set_precision(copy.deepcopy(model).cuda(), "mixed16")
     errx, _ = _compare(tag + " mixed16" + ("+fp8 cross" if fp8 else ""), mx, P, ref, rloss, batch, LOGIT_TOL_BF16, grad_bf16)
-    assert errx < 0.75 * err, "mixed16 logits (%.3e) are not clearly closer to the reference than bf16 (%.3e)" % (errx, err)
+    assert errx < 0.5 * err, "mixed16 logits (%.3e) are not clearly closer to the reference than bf16 (%.3e)" % (errx, err)
     del mx
     torch.cuda.empty_cache()
     m32 = icka_amd.set_precision(model.cuda(), "fp32")
