@@ -121,3 +121,45 @@ def test_graphed_step_with_reference_training_loop():
     assert K._NONCE_PTR is None                 # kernels no longer point at memory the GraphedStep owned
     with pytest.raises(RuntimeError):
         gs()
+
+
+def test_mixed16_graphed_training_loop_matches_eager_and_refreshes_both_shadows():
+    """mixed16 under a captured step: the replayed forward reads the fp16 AND bf16 weight shadows of the weights the
+    optimizer just wrote (through ``.data``-style in-place updates as well), and the loss sequence equals the eager one."""
+    import copy
+    import icka_amd
+    from icka_amd.graph import GraphedStep
+    base, args, labels = _model()
+    seqs = []
+    for graphed in (False, True):
+        model = icka_amd.set_precision(copy.deepcopy(base), "mixed16")
+
+        def step():
+            loss = model(*args, labels=labels)
+            loss.backward()
+            return loss
+
+        run = GraphedStep(model, step) if graphed else step
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for i in range(4):
+            if not graphed:
+                model.zero_grad()
+            loss = run()
+            losses.append(loss.item())
+            opt.step()
+            if i == 1:      # an update that leaves no trace in any version counter
+                with torch.no_grad():
+                    model.classifier.weight.data.mul_(0.5)
+            model.zero_grad()
+        A = model._icka_arena
+        torch.cuda.synchronize()
+        A.sync()
+        w = model.bert.encoder.layer[0].output.dense.weight
+        assert torch.equal(A.w16(w), w.detach().to(torch.float16)) and torch.equal(A.w(w), w.detach().to(torch.bfloat16))
+        seqs.append(losses)
+        if graphed:
+            run.close()
+    assert seqs[0][-1] < seqs[0][0]
+    for a, b in zip(*seqs):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(a)), seqs
