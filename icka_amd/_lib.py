@@ -102,6 +102,8 @@ PROTOTYPES = {
     "icka_cls_head_slab_floats": (c_i64, [c_i32, c_i32]),
     "icka_conv_stem_patches": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "icka_conv_im2col3x3": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "icka_conv3x3_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32,
+                                   c_vp, c_vp]),
     "icka_conv_subsample": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "icka_conv_maxpool3x3s2": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "icka_conv_features_out": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -46,6 +46,11 @@ struct GemmArgs {
     int c_f16;         // main output C is fp16 (c_f32 == 0)
     bf16_t* C3; int64_t ldc3;   // optional bf16 copy of the main output (the weight-gradient operand of an fp16 activation)
     int aux_f16;       // the epilogue operand aux is fp16 (read through load8_aux / load4_aux)
+    // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
+    // output pixel m and the reduction index is k = tap * cvC + c -- the loader waves compute the patch addresses, no
+    // patch matrix exists.  cvZero: at least 128 B of zeros for the taps that fall off the image / rows past cvRows.
+    int cvH, cvW, cvC, cvS, cvHo, cvWo, cvRows;
+    const bf16_t* cvZero;
 };
 
 // k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
@@ -789,7 +794,7 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -829,9 +834,40 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         const int k1t = g.K1 > 0 ? g.K1 / BK : -1;
         const bf16_t* pa[4];
         const bf16_t* pb[4];
-        dma_init<A_KM>(pa, g.A, g.lda, m0, lw, lane);
+        // CONV: the A tile is gathered from the NHWC activation.  Per piece (8 tile rows) this lane serves one output pixel:
+        // the pointer to its centre input pixel (+ this lane's 16-byte chunk) and a 9-bit mask of the taps that lie inside
+        // the image; a k-tile is 64 channels of ONE tap (cvC % 64 == 0), so its source is centre + a wave-uniform offset,
+        // or the zero page.
+        const bf16_t* ctr[4];
+        uint32_t vmask[4] = {0u, 0u, 0u, 0u};
+        const bf16_t* zsrc = nullptr;
+        int cv_tap = 0, cv_cb = 0;
+        if constexpr (CONV) {
+            static_assert(!A_KM && !B_KM, "implicit convolution: NT only");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 8 * (lw + 4 * j) + (lane >> 3);
+                const int lc = (lane & 7) ^ ((row >> 1) & 7);
+                const int m = m0 + row;
+                const int mm = m < g.cvRows ? m : 0;
+                const int hw = g.cvHo * g.cvWo;
+                const int b = mm / hw, r = mm - b * hw, oy = r / g.cvWo, ox = r - oy * g.cvWo;
+                const int y0 = oy * g.cvS, x0 = ox * g.cvS;
+                ctr[j] = g.A + ((int64_t)(b * g.cvH + y0) * g.cvW + x0) * g.cvC + 8 * lc;
+                uint32_t vm = 0u;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int y = y0 + t / 3 - 1, x = x0 + t % 3 - 1;
+                    vm |= (m < g.cvRows && y >= 0 && y < g.cvH && x >= 0 && x < g.cvW) ? (1u << t) : 0u;
+                }
+                vmask[j] = vm;
+                if (j == 0) zsrc = g.cvZero + 8 * (lane & 7);
+            }
+        } else {
+            dma_init<A_KM>(pa, g.A, g.lda, m0, lw, lane);
+        }
         dma_init<B_KM, BNT>(pb, g.B, g.ldb, n0, lw, lane);
-        int64_t sa = A_KM ? (int64_t)BK * g.lda : BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+        int64_t sa = CONV ? 0 : (A_KM ? (int64_t)BK * g.lda : BK), sb = B_KM ? (int64_t)BK * g.ldb : BK;
 #define ICKA_WS_STAGE(KT, BUF)                                          \
     do {                                                                \
         if ((KT) == k1t) {                                              \
@@ -839,6 +875,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
             dma_init<B_KM, BNT>(pb, g.B2, g.ldb2, n0, lw, lane);        \
             sa = A_KM ? (int64_t)BK * g.lda2 : BK;                      \
             sb = B_KM ? (int64_t)BK * g.ldb2 : BK;                      \
+        }                                                               \
+        if constexpr (CONV) {   /* k-tiles are staged in order: (tap, channel block) advance as counters */ \
+            const int64_t off_ = (int64_t)((cv_tap / 3 - 1) * g.cvW + (cv_tap % 3 - 1)) * g.cvC + cv_cb * 64; \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)            \
+                pa[j_] = ((vmask[j_] >> cv_tap) & 1u) ? ctr[j_] + off_ : zsrc; \
+            if (++cv_cb == g.cvC / 64) { cv_cb = 0; ++cv_tap; }         \
         }                                                               \
         if (ABL != 2) {                                                 \
             dma_issue(pa, sa, lds0 + (BUF) + lw * 1024);                \
@@ -1089,11 +1131,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16>(g, smem, blockIdx.x, gridDim.x);
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1491,6 +1533,40 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
         case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
         default: return launch<true, true>(g, aligned, st);
     }
+}
+
+// 3x3 / pad 1 convolution (stride 1 or 2) of an NHWC bf16 activation as an implicit GEMM on the warp-specialised kernel:
+//   y[m, co] = epilogue( sum_{tap, c} x[pixel(m) + tap][c] * w[co][tap * C + c] + bias[co] (+ aux[m, co]) )
+// m = output pixel (b, oy, ox) row-major, rows [rows_valid, rows_padded) of y are written from zero patches.
+// Replaces icka_conv_im2col3x3 + icka_gemm: the [rows, 9 C] patch matrix (9x the activation) is never written or read.
+extern "C" int icka_conv3x3_gemm(const void* x, const void* w, const float* bias, const void* aux, int64_t ldaux, void* y,
+                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t stride,
+                                 int64_t rows_padded, int32_t epilogue, const void* zeros, void* stream) {
+    if (!x || !w || !y || !zeros) return ICKA_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 || Cout <= 0 || Cout % 64 || (stride != 1 && stride != 2))
+        return ICKA_E_SHAPE;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int64_t rows = (int64_t)B * Ho * Wo;
+    if (rows_padded < rows || rows_padded % BM || rows_padded > 0x7fffffff) return ICKA_E_SHAPE;
+    if (epilogue != ICKA_EPI_NONE && epilogue != ICKA_EPI_RELU && epilogue != ICKA_EPI_ADD_RELU && epilogue != ICKA_EPI_ADD)
+        return ICKA_E_ARG;
+    if ((epilogue == ICKA_EPI_ADD_RELU || epilogue == ICKA_EPI_ADD) && !aux) return ICKA_E_ARG;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al(x) || !al(w) || !al(y) || !al(zeros) || (aux && (!al(aux) || ldaux % 8)) || (bias && !al(bias))) return ICKA_E_ALIGN;
+    GemmArgs g{};
+    g.M = (int)rows_padded; g.N = Cout; g.K = 9 * C; g.K1 = 0;
+    g.A = (const bf16_t*)x; g.lda = C; g.B = (const bf16_t*)w; g.ldb = 9 * (int64_t)C;
+    g.C = y; g.ldc = Cout; g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.bias = bias;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = epilogue; g.c_f32 = 0; g.a_vec = g.b_vec = 1; g.ksplit = 1; g.direct = g_direct;
+    g.cvH = H; g.cvW = W; g.cvC = C; g.cvS = stride; g.cvHo = Ho; g.cvWo = Wo; g.cvRows = (int)rows;
+    g.cvZero = (const bf16_t*)zeros;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout % 128 == 0)
+        hipLaunchKernelGGL((gemm_ws_kernel<false, false, 3, 0, 128, false, true>), dim3((g.M / BM) * (Cout / 128)), dim3(512), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_ws_kernel<false, false, 3, 0, 64, false, true>), dim3((g.M / BM) * (Cout / 64)), dim3(512), 0, st, g);
+    ICKA_CHECK_LAUNCH();
+    return 0;
 }
 
 template <bool A_KM, bool B_KM, int NBUF>

@@ -78,6 +78,8 @@ class ResNet(nn.Module):
                 m.bias.data.zero_()
         self._folded = None
         self._folded_key = None
+        # 3x3 convolutions as implicit GEMMs (icka_conv3x3_gemm); False = patch matrix (icka_conv_im2col3x3) + GEMM
+        self.implicit_conv = True
         # load_state_dict always invalidates the folded weights (version counters also move, but be explicit)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refold())
 
@@ -147,6 +149,12 @@ class ResNet(nn.Module):
         self._folded, self._folded_key = plan, key
         return plan
 
+    def _zero_page(self, dev):
+        z = getattr(self, "_zeros", None)
+        if z is None or z.device != dev:
+            z = self._zeros = torch.zeros(256, dtype=BF16, device=dev)
+        return z
+
     # ------------------------------------------------------------------------------------------------ forward
     def features(self, x: torch.Tensor) -> Tuple[torch.Tensor, int, int, int]:
         """x f32 [B,3,H,W] on a ROCm device -> (last feature map as NHWC bf16 rows [rows_padded, 2048], B, Hf, Wf)."""
@@ -183,10 +191,18 @@ class ResNet(nn.Module):
             t1 = gemm(cur, e["c1"], K.EPI_RELU)
             Hn, Wn = (Hc + 2 - 3) // s + 1, (Wc + 2 - 3) // s + 1
             rows_out = _pad128(B * Hn * Wn)
-            pm = torch.empty(rows_out, 9 * e["p"], dtype=BF16, device=dev)
-            K.check(lib.icka_conv_im2col3x3(t1.data_ptr(), pm.data_ptr(), B, Hc, Wc, e["p"], s, rows_out, st()),
-                    "icka_conv_im2col3x3")
-            t2 = gemm(pm, e["c2"], K.EPI_RELU)
+            if self.implicit_conv:
+                # conv2 + bn2 + relu as an implicit GEMM: the loader waves gather the 3x3 patches from t1 (no patch matrix)
+                w2, b2 = e["c2"]
+                t2 = torch.empty(rows_out, e["p"], dtype=BF16, device=dev)
+                K.check(lib.icka_conv3x3_gemm(t1.data_ptr(), w2.data_ptr(), b2.data_ptr(), None, 0, t2.data_ptr(), B, Hc, Wc,
+                                              e["p"], e["p"], s, rows_out, K.EPI_RELU, self._zero_page(dev).data_ptr(), st()),
+                        "icka_conv3x3_gemm")
+            else:
+                pm = torch.empty(rows_out, 9 * e["p"], dtype=BF16, device=dev)
+                K.check(lib.icka_conv_im2col3x3(t1.data_ptr(), pm.data_ptr(), B, Hc, Wc, e["p"], s, rows_out, st()),
+                        "icka_conv_im2col3x3")
+                t2 = gemm(pm, e["c2"], K.EPI_RELU)
             if e["down"] is not None:
                 xs = cur
                 if s != 1:

@@ -384,6 +384,13 @@ int icka_conv_stem_patches(const float* image, void* patches, int32_t B, int32_t
                            void* stream);
 int icka_conv_im2col3x3(const void* src, void* patches, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
                         int64_t rows_padded, void* stream);
+/* The 3x3 / pad 1 convolution itself (stride 1 or 2) as an IMPLICIT GEMM: y bf16 [rows_padded, Cout] = epilogue(patches(x) .
+ * w^T + bias (+ aux)), x NHWC bf16 [B,H,W,C] (C % 64 == 0), w bf16 [Cout, 9*C] with k = (ky*3+kx)*C + c (Cout % 64 == 0),
+ * epilogue ICKA_EPI_NONE / RELU / ADD / ADD_RELU (aux bf16 [rows_padded, ldaux]), zeros = at least 128 B of zero bytes.
+ * Same result as icka_conv_im2col3x3 + icka_gemm without the 9x patch matrix (resnet/resnet.py:63-64 conv2 + bn2 + relu). */
+int icka_conv3x3_gemm(const void* x, const void* w, const float* bias, const void* aux, int64_t ldaux, void* y, int32_t B,
+                      int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t stride, int64_t rows_padded, int32_t epilogue,
+                      const void* zeros, void* stream);
 int icka_conv_subsample(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
                         int64_t rows_padded, void* stream);
 int icka_conv_maxpool3x3s2(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int64_t rows_padded,

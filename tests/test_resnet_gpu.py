@@ -64,3 +64,39 @@ def test_resnet_refuses_unsupported_use():
     net.train()
     with pytest.raises(RuntimeError):
         enc(torch.zeros(1, 3, 224, 224, device="cuda"))
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout,stride", [(2, 56, 56, 64, 64, 1), (3, 28, 28, 128, 128, 2), (1, 14, 14, 256, 256, 1),
+                                                 (2, 7, 7, 512, 512, 1), (1, 15, 9, 64, 128, 2), (5, 8, 8, 128, 64, 1)])
+def test_implicit_conv3x3_equals_patch_matrix_gemm(B, H, W, C, Cout, stride):
+    """icka_conv3x3_gemm (the loader waves gather the 3x3 patches) against icka_conv_im2col3x3 + icka_gemm and against
+    torch's conv2d: borders, stride 2, odd image sizes, row padding, both tile widths, bias + ReLU / residual epilogues."""
+    from icka_amd import kernels as K
+    lib = K._lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = (torch.randn(B, H, W, C, generator=g) * 0.5).to(torch.bfloat16).cuda()          # NHWC
+    w = (torch.randn(Cout, 3, 3, C, generator=g) * 0.05).to(torch.bfloat16).cuda()      # k = (ky*3+kx)*C + c
+    bias = torch.randn(Cout, generator=g).cuda()
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    rows = B * Ho * Wo
+    rp = (rows + 127) // 128 * 128
+    zeros = torch.zeros(256, dtype=torch.bfloat16, device="cuda")
+    aux = (torch.randn(rp, Cout, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    st = K._stream
+    for epi, a in ((K.EPI_RELU, None), (K.EPI_ADD_RELU, aux), (K.EPI_NONE, None)):
+        y = torch.full((rp, Cout), 7.0, dtype=torch.bfloat16, device="cuda")
+        K.check(lib.icka_conv3x3_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None if a is None else a.data_ptr(),
+                                      0 if a is None else a.stride(0), y.data_ptr(), B, H, W, C, Cout, stride, rp, epi,
+                                      zeros.data_ptr(), st()), "icka_conv3x3_gemm")
+        pm = torch.empty(rp, 9 * C, dtype=torch.bfloat16, device="cuda")
+        K.check(lib.icka_conv_im2col3x3(x.data_ptr(), pm.data_ptr(), B, H, W, C, stride, rp, st()), "im2col")
+        y2 = torch.empty(rp, Cout, dtype=torch.bfloat16, device="cuda")
+        K.gemm(K.GEMM_NT, pm, w.view(Cout, 9 * C), y2, bias=bias, epilogue=epi, aux=a)
+        assert torch.equal(y, y2), (epi, (y.float() - y2.float()).abs().max().item())
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=stride,
+                                         padding=1).permute(0, 2, 3, 1).reshape(rows, Cout)
+        if a is not None:
+            ref = ref + a[:rows].float()
+        if epi != K.EPI_NONE:
+            ref = ref.clamp_min(0)
+        assert _rel(y[:rows].float(), ref) < 1e-2
