@@ -11,7 +11,11 @@
 //                          128x128 or 128x96 output tiles, LDS-staged or direct (f32) epilogue
 //   gemm_ws2_kernel        same with a ring of 2 and two co-resident blocks per CU (short-K, many-tile grids)
 //   gemm_ws_group_kernel   up to 4 problems of one layout in one launch (128x128 tiles)
+//   gemm_w3_kernel         12 waves (8 compute + 4 loader), 256x192 tiles (wide short-K outputs: qkv, ffn-up, d-ffn-down) or
+//                          256x128 tiles (N = 1024 / 768 at M = 8192: one round of 192..256 tiles instead of two)
 //   gemm_big_group_kernel  256x128 tiles for the grouped weight gradients + column-sum / slab-reduction blocks
+// Variants of the NT kernels: F16 (IEEE fp16 operands on v_mfma_f32_16x16x32_f16, fp16 / bf16-copy outputs: the "mixed16"
+// forward GEMMs) and CONV (gemm_ws_kernel only: the A tile is gathered from an NHWC activation = implicit 3x3 convolution).
 // LDS images are XOR-swizzled per layout (off_kc / off_km), the swizzle applied to the DMA source address.
 #include "common.h"
 #include <cstdio>
