@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=100.0,
+    ap.add_argument("--bucket-mb", type=float, default=50.0,
                     help="minimum gradient bucket size in MB of fp32 gradients (the embedding tables are always a bucket of "
                          "their own): every bucket is a fork/join of the captured graph, see DESIGN.md section 6")
     ap.add_argument("--comm-f32", action="store_true", help="fp32 gradient buckets on the wire (default at N > 1: bf16)")

@@ -61,6 +61,17 @@ __global__ void cast_to_f16_kernel(const void* __restrict__ src, int kind, _Floa
         dst[i] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
     }
 }
+// 8 elements per thread and iteration (one 16-byte load, two 16-byte stores) when both pointers are 16-byte aligned: the
+// data-parallel reducer casts 119 M gradients back per step (the scalar form below moves 2 + 4 bytes per instruction)
+__global__ void cast_b2f_vec_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t nch = n >> 3;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(src + c * 8));
+        *reinterpret_cast<f32x4*>(dst + c * 8) = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+        *reinterpret_cast<f32x4*>(dst + c * 8 + 4) = f32x4{bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7])};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nch << 3) + threadIdx.x] = bf2f(src[(nch << 3) + threadIdx.x]);
+}
 __global__ void cast_b2f_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = bf2f(src[i]);
@@ -396,7 +407,11 @@ extern "C" int icka_cast_to_f16(const void* src, int32_t src_is_f32, void* dst, 
 extern "C" int icka_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
     if (!src || !dst) return ICKA_E_ARG;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+    if (al16(src) && al16(dst))
+        hipLaunchKernelGGL(cast_b2f_vec_kernel, dim3(grid_for((n + 7) / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)src, dst, n);
+    else
+        hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
     ICKA_CHECK_LAUNCH();
     return 0;
 }
