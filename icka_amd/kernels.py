@@ -669,6 +669,20 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def zero_rows_(t: torch.Tensor, row0: int) -> None:
+    """Clear rows [row0, end) of a contiguous 16-bit [rows, cols] matrix (the padding rows of a row-padded operand) with the
+    library's fill kernel."""
+    _dev(t, "t")
+    if t.dim() != 2 or not t.is_contiguous() or t.element_size() != 2:
+        raise TypeError("zero_rows_: contiguous 16-bit [rows, cols] matrix")
+    n16 = (t.shape[0] - row0) * t.shape[1]
+    if n16 <= 0:
+        return
+    if (row0 * t.shape[1]) % 2 or n16 % 2:
+        raise ValueError("zero_rows_: the cleared range must be a whole number of 32-bit words")
+    check(_lib.load().icka_zero_f32(t.data_ptr() + 2 * row0 * t.shape[1], n16 // 2, _stream()), "icka_zero_f32")
+
+
 def scale_by_ratio(x, y, num=None, den=None):
     """y = x * num[0] / max(den[0], 1) with device scalars (None = 1)."""
     check(_lib.load().icka_scale_by_ratio(x.data_ptr(), y.data_ptr(), _ptr(num), _ptr(den), x.numel(), _stream()),

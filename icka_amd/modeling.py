@@ -639,7 +639,12 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     # ---- region tokens + projection (:1348-1350)
     v = visual_embeds_att
     R, layout = _region_layout(v)
-    tokens = torch.empty(B * R, 2048, dtype=BF16, device=dev)
+    # region-token rows are padded to a multiple of 128 (zero rows) so that the region projection, the cross-attention K/V
+    # projection and their gradients stay on the aligned GEMM kernels for every region count (the reference's own layout
+    # has 49 regions: 32 x 49 = 1568 rows); the attention kernels address keys as b*R + r and never see the padding
+    rows_p = (B * R + 127) // 128 * 128
+    tokens = torch.empty(rows_p, 2048, dtype=BF16, device=dev)
+    K.zero_rows_(tokens, B * R)
     K.regions_to_tokens(v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v, tokens, B, R,
                         2048, layout)
     vis = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE)

@@ -152,6 +152,8 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         return dx, None
     dq = _empty(x, M, H)
     dkv = _empty(x, kv_src.shape[0], 2 * H)
+    if kv_src.shape[0] > d.B * Skv:     # row-padded key/value source (region tokens): the attention writes real rows only
+        K.zero_rows_(dkv, d.B * Skv)
     K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
                d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
     _wgrad(A, dq, x, A.g(sa.query.weight), A.grad_beta(sa.query.weight), bias=sa.query.bias)
