@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
+ABI_VERSION = 2   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
 GEMM_NT, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -205,6 +206,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.icka_abi_version() != ABI_VERSION:
+        raise IckaLibraryError("%s was built for C-ABI version %d, this package binds version %d: rebuild it "
+                               "(make -C icka_amd/csrc)" % (path, lib.icka_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

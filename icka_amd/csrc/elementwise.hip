@@ -365,7 +365,7 @@ __global__ void scalar_ratio_kernel(float* out, const float* num, const float* d
 
 const uint32_t* g_icka_nonce = nullptr;
 
-extern "C" int icka_abi_version(void) { return 1; }
+extern "C" int icka_abi_version(void) { return ICKA_ABI_VERSION; }
 extern "C" int icka_set_dropout_nonce(const uint32_t* device_words) {
     g_icka_nonce = device_words;
     return 0;
