@@ -27,19 +27,19 @@ def mb(x):
 bf, f4 = 2, 4
 LAYERS, XL = 12, 1            # BERT layers + cross layer (the cross layer's q / kv projections are listed separately)
 G = [
-    ("qkv (NT 4096x2304x768)", "gemm_w3_kernel<false>", LAYERS, M * H * bf, 3 * H * H * bf, 0, M * 3 * H * bf),
-    ("ffn-up + GELU (NT 4096x3072x768)", "gemm_w3_kernel<false>", LAYERS + XL, M * H * bf, I * H * bf, 0, 2 * M * I * bf),
-    ("d(ffn-down) + GELU' (NN 4096x3072x768)", "gemm_w3_kernel<true>", LAYERS + XL, M * H * bf, I * H * bf, M * I * bf,
+    ("qkv (NT 4096x2304x768)", "gemm_w3_kernel<false, false, 192>", LAYERS, M * H * bf, 3 * H * H * bf, 0, M * 3 * H * bf),
+    ("ffn-up + GELU (NT 4096x3072x768)", "gemm_w3_kernel<false, false, 192>", LAYERS + XL, M * H * bf, I * H * bf, 0, 2 * M * I * bf),
+    ("d(ffn-down) + GELU' (NN 4096x3072x768)", "gemm_w3_kernel<true, false, 192>", LAYERS + XL, M * H * bf, I * H * bf, M * I * bf,
      M * I * bf),
-    ("out-proj (NT 4096x768x768, f32 out)", "gemm_ws_kernel<false, false, 3, 0, 96>", LAYERS + XL, M * H * bf, H * H * bf, 0,
+    ("out-proj (NT 4096x768x768, f32 out)", "gemm_ws_kernel<false, false, 3, 0, 96, false, false>", LAYERS + XL, M * H * bf, H * H * bf, 0,
      M * H * f4),
-    ("ffn-down (NT 4096x768x3072, f32 out)", "gemm_ws_kernel<false, false, 3, 0, 96>", LAYERS + XL, M * I * bf, I * H * bf, 0,
+    ("ffn-down (NT 4096x768x3072, f32 out)", "gemm_ws_kernel<false, false, 3, 0, 96, false, false>", LAYERS + XL, M * I * bf, I * H * bf, 0,
      M * H * f4),
-    ("d(ffn-up) + fan-in (NN 4096x768x3072)", "gemm_ws_kernel<false, true, 3, 0, 96>", LAYERS + XL, M * I * bf, I * H * bf,
+    ("d(ffn-up) + fan-in (NN 4096x768x3072)", "gemm_ws_kernel<false, true, 3, 0, 96, false, false>", LAYERS + XL, M * I * bf, I * H * bf,
      M * H * bf, M * H * bf),
-    ("d(qkv) + fan-in (NN 4096x768x2304)", "gemm_ws_kernel<false, true, 3, 0, 96>", LAYERS, M * 3 * H * bf, 3 * H * H * bf,
+    ("d(qkv) + fan-in (NN 4096x768x2304)", "gemm_ws_kernel<false, true, 3, 0, 96, false, false>", LAYERS, M * 3 * H * bf, 3 * H * H * bf,
      M * H * bf, M * H * bf),
-    ("d(out-proj) (NN 4096x768x768)", "gemm_ws_kernel<false, true, 3, 0, 96>", LAYERS + XL, M * H * bf, H * H * bf, 0,
+    ("d(out-proj) (NN 4096x768x768)", "gemm_ws_kernel<false, true, 3, 0, 96, false, false>", LAYERS + XL, M * H * bf, H * H * bf, 0,
      M * H * bf),
 ]
 
