@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
-ABI_VERSION = 3   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
+ABI_VERSION = 2   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
 GEMM_NT, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -34,15 +34,6 @@ class GemmDesc(C.Structure):
         ("epilogue", c_i32),
         ("colsum_out", c_vp), ("colsum_accumulate", c_i32),
         ("ab_f16", c_i32), ("C3", c_vp), ("ldc3", c_i64), ("aux_f16", c_i32),
-    ]
-
-
-class LnEpilogue(C.Structure):
-    """Mirror of ``icka_ln_epilogue`` (include/icka_hip.h): the fused LayerNorm epilogue of icka_gemm_ln."""
-    _fields_ = [
-        ("residual", c_vp), ("ld_residual", c_i64), ("residual_kind", c_i32), ("twin_f16", c_i32),
-        ("gamma", c_vp), ("beta", c_vp), ("y", c_vp), ("ldy", c_i64), ("y_twin", c_vp), ("xhat", c_vp), ("rstd", c_vp),
-        ("eps", c_f32), ("p_drop", c_f32), ("seed", C.c_uint64), ("workspace", c_vp), ("workspace_bytes", c_i64),
     ]
 
 
@@ -70,10 +61,6 @@ PROTOTYPES = {
     "icka_abi_version": (c_i32, []),
     "icka_build_arch": (C.c_char_p, []),
     "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
-    "icka_gemm_ln": (c_i32, [C.POINTER(GemmDesc), C.POINTER(LnEpilogue), c_vp]),
-    "icka_gemm_ln_supported": (c_i32, [c_i32, c_i32, c_i32]),
-    "icka_gemm_ln_set_debug": (c_i32, [c_i32]),
-    "icka_gemm_ln_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "icka_gemm_grouped": (c_i32, [C.POINTER(GemmDesc), c_i32, c_vp]),
     "icka_gemm_grouped_ex": (c_i32, [C.POINTER(GemmDesc), c_i32, C.POINTER(SlabReduction), c_i32, c_vp]),
     "icka_gemm_set_ring": (c_i32, [c_i32]),

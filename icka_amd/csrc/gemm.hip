@@ -26,23 +26,6 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, either layout
 
-// Fused LayerNorm epilogue (icka_gemm_ln): the GEMM's 128-row stripe of blocks finishes
-//   y = LayerNorm(dropout(A.B^T + bias) + residual)
-// in its epilogue; the N / tile-width blocks of a stripe exchange per-row (sum, M2) through `stats` and a counter.
-struct LnEpi {
-    const void* res; int res_kind; int64_t ldr;   // residual input: 0 = bf16, 1 = f32, 2 = fp16
-    const float* gamma; const float* beta;
-    bf16_t* y; int64_t ldy;                       // bf16 output (operand of the next GEMM)
-    void* yf; int yf_f16;                         // twin of y [M, N] contiguous: f32 or fp16 (may be null)
-    bf16_t* xhat; float* rstd;                    // saved for backward (may be null)
-    float eps;
-    DropCfg drop;                                 // hidden dropout on the dense output (index = m * N + n, as ln_fwd_kernel)
-    float* stats;                                 // [M / 128][128][N / tile width][2] f32
-    unsigned* cnt;                                // [M / 128][2]: arrivals, departures (self-resetting) ; then 1 error word
-    unsigned* err;
-    int dbg;                                      // diagnostic (icka_gemm_ln_set_debug): 1 = skip the exchange (timing only)
-};
-
 struct GemmArgs {
     int M, N, K, K1;
     const bf16_t* A;  int64_t lda;
@@ -72,7 +55,6 @@ struct GemmArgs {
     // patch matrix exists.  cvZero: at least 128 B of zeros for the taps that fall off the image / rows past cvRows.
     int cvH, cvW, cvC, cvS, cvHo, cvWo, cvRows;
     const bf16_t* cvZero;
-    LnEpi ln;          // gemm_ws_kernel<..., LN = true> only
 };
 
 // k-contiguous tile image [128 rows][64 k]: 128-B rows, 16-B chunk index XORed with (row>>1)&7 so that the 16 rows
@@ -619,167 +601,6 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Fused LayerNorm epilogue of the 128 x BNT-tile kernel (BNT = 96: N = 768, 128: N = 1024).  The f32 C tile is staged in LDS
-// (off_c image); 4 threads finish one tile row (BNT / 4 columns each, kept in registers across the exchange):
-//   1. v = acc + bias, dropout, + residual; the block's per-row (sum, M2 about the block mean) go to stats[stripe][row][cb]
-//      as agent-scope stores, then one arrival on the stripe's counter;
-//   2. wait until all N / BNT blocks of the stripe have arrived (they are neighbours in dispatch order on ONE XCD --
-//      tile_origin -- and a block only ever waits for blocks dispatched within 8 * nbn ids of it, so the wait cannot
-//      deadlock whatever else occupies CUs); merge the blocks' statistics in FIXED order (Chan's formula: deterministic,
-//      and every block of the stripe derives bit-identical mean / rstd);
-//   3. y = gamma * xhat + beta -> bf16 y, twin (f32 / fp16), xhat, rstd.
-// The last block to leave a stripe clears its two counters, so the workspace is reusable by the next launch on the stream.
-__device__ __forceinline__ void load8_any(const void* base, int kind, int64_t off, float (&o)[8]) {
-    if (kind == 1) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off + 4);
-        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-    } else {
-        load8_aux(reinterpret_cast<const bf16_t*>(base) + off, kind == 2, o);
-    }
-}
-template <int NB, int BNT>
-__device__ __forceinline__ void ln_merge(const unsigned long long* srow, int nbn, int N, float& mean, float& M2) {
-    unsigned long long raw[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) raw[b] = __hip_atomic_load(srow + (b < nbn ? b : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float tot = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) tot += b < nbn ? __uint_as_float((unsigned)raw[b]) : 0.f;
-    mean = tot / (float)N;
-    M2 = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const float d = __uint_as_float((unsigned)raw[b]) * (1.f / (float)BNT) - mean;
-        M2 += b < nbn ? __uint_as_float((unsigned)(raw[b] >> 32)) + (float)BNT * d * d : 0.f;
-    }
-}
-template <int BNT>
-__device__ __forceinline__ void epilogue_ln(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
-    constexpr int CPT = BNT / 4, NG = CPT / 8;     // columns / 8-column groups per thread: 24 / 3 or 32 / 4
-    constexpr int MAXB = 16;                       // blocks per stripe (host-checked)
-    const LnEpi& L = g.ln;
-    if (L.dbg == 2) return;
-    const DropCfg drop = drop_resolve(L.drop);
-    const int row = tid >> 2, q = tid & 3;
-    const int m = m0 + row;
-    const int nbn = g.N / BNT, stripe = m0 / BM, cb = n0 / BNT;
-    float v[NG][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int c8 = NG * q + gi, n = n0 + 8 * c8;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + off_c(row, 2 * c8 + 1));
-        v[gi][0] = lo[0]; v[gi][1] = lo[1]; v[gi][2] = lo[2]; v[gi][3] = lo[3];
-        v[gi][4] = hi[0]; v[gi][5] = hi[1]; v[gi][6] = hi[2]; v[gi][7] = hi[3];
-        if (g.bias) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[gi][e] += b0[e]; v[gi][4 + e] += b1[e]; }
-        }
-        if (drop.thr) {
-            const uint32_t base = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[gi][e] *= drop_mul(drop, base + e);
-        }
-        if (L.res && L.dbg != 3) {
-            float r[8];
-            load8_any(L.res, L.res_kind, (int64_t)m * L.ldr + n, r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[gi][e] += r[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += v[gi][e];
-    }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    const float mean_b = sum * (1.f / (float)BNT);
-    float m2 = 0.f;
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[gi][e] - mean_b; m2 += d * d; }
-    m2 += __shfl_xor(m2, 1, 64);
-    m2 += __shfl_xor(m2, 2, 64);
-    // (LayerNorm parameters are requested before the exchange so that their latency hides under the wait)
-    f32x4 gm[NG][2], bt[NG][2];
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int n = n0 + 8 * (NG * q + gi);
-        gm[gi][0] = *reinterpret_cast<const f32x4*>(L.gamma + n); gm[gi][1] = *reinterpret_cast<const f32x4*>(L.gamma + n + 4);
-        bt[gi][0] = *reinterpret_cast<const f32x4*>(L.beta + n); bt[gi][1] = *reinterpret_cast<const f32x4*>(L.beta + n + 4);
-    }
-    unsigned long long* srow = reinterpret_cast<unsigned long long*>(L.stats) + ((int64_t)stripe * BM + row) * nbn;
-    if (q == 0) {
-        const unsigned long long bits = (unsigned long long)__float_as_uint(sum) | ((unsigned long long)__float_as_uint(m2) << 32);
-        __hip_atomic_store(srow + cb, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's statistics have reached the coherent level
-    __syncthreads();
-    unsigned* cnt = L.cnt + 2 * stripe;
-    if (tid == 0 && L.dbg != 1) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 24)) {   // (~seconds: a lost stripe-mate.  Report instead of hanging the device.)
-                __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    // all of the stripe's partials are requested back to back (branch-free: one wait for the lot, not one round trip each)
-    float mean, M2;
-    if (L.dbg == 1) { mean = mean_b; M2 = m2 * (float)nbn; }
-    else if (nbn <= 8) ln_merge<8, BNT>(srow, nbn, g.N, mean, M2);
-    else ln_merge<MAXB, BNT>(srow, nbn, g.N, mean, M2);
-    const float rstd = 1.f / sqrtf(M2 / (float)g.N + L.eps);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                 // every thread of the block has read the stripe's statistics
-    if (L.rstd && cb == 0 && q == 0) L.rstd[m] = rstd;
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int n = n0 + 8 * (NG * q + gi);
-        const f32x4 g0 = gm[gi][0], g1 = gm[gi][1], b0 = bt[gi][0], b1 = bt[gi][1];
-        float xh[8], o[8];
-        if (L.dbg == 4 && mean != 12345.f) continue;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            xh[e] = (v[gi][e] - mean) * rstd;
-            o[e] = (e < 4 ? g0[e] : g1[e - 4]) * xh[e] + (e < 4 ? b0[e] : b1[e - 4]);
-        }
-        {
-            bf16x8 ob;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ob[e] = f2bf(o[e]);
-            *reinterpret_cast<u32x4*>(L.y + (int64_t)m * L.ldy + n) = as_u32x4(ob);
-        }
-        if (L.yf) {
-            if (L.yf_f16) {
-                f16x8 oh;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) oh[e] = f2h(o[e]);
-                *reinterpret_cast<u32x4*>(reinterpret_cast<_Float16*>(L.yf) + (int64_t)m * g.N + n) = __builtin_bit_cast(u32x4, oh);
-            } else {
-                float* p = reinterpret_cast<float*>(L.yf) + (int64_t)m * g.N + n;
-                *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
-            }
-        }
-        if (L.xhat) store8_bf16(L.xhat + (int64_t)m * g.N + n, xh);   // (non-temporal: read again only in backward)
-    }
-    if (tid == 0 && L.dbg != 1) {
-        const unsigned old = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)nbn - 1u) {   // last block out: every stripe-mate is past its wait and its reads
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 template <bool A_KM, bool B_KM, int NBUF, int ABL>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -977,8 +798,7 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false,
-          bool LN = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1249,7 +1069,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     // from the accumulators to HBM: a lane owns 4 consecutive columns of one row (16 B) and the 4 lane groups of an
     // MFMA tile cover 64 contiguous bytes per row; the stores of adjacent tiles merge in L2.  This skips two block barriers and
     // 128 KB of LDS traffic of the staged epilogue below, and the loader waves retire at once.
-    if (!LN && g_direct_epilogue(g)) {
+    if (g_direct_epilogue(g)) {
 #ifdef ICKA_GEMM_STAMP
         if (g.stamp && lane == 0 && wave == 0) {
             unsigned long long* o = g.stamp + (size_t)bid * 16 + 11;
@@ -1304,8 +1124,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         }
     }
     __syncthreads();
-    if constexpr (LN) epilogue_ln<BNT>(g, smem, m0, n0, tid);
-    else epilogue_rows<32, BNT / 8>(g, smem, m0, n0, tid);
+    epilogue_rows<32, BNT / 8>(g, smem, m0, n0, tid);
 #ifdef ICKA_GEMM_STAMP
     if (g.stamp && lane == 0 && wave == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1321,14 +1140,6 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
     gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV>(g, smem, blockIdx.x, gridDim.x);
-}
-
-// NT GEMM with the fused LayerNorm epilogue (epilogue_ln): BertSelfOutput / BertOutput in one launch
-template <int BNT, bool F16>
-__global__ __launch_bounds__(512) void gemm_ln_kernel(const GemmArgs gp) {
-    const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[3 * 2 * TILE_BYTES];
-    gemm_ws_body<false, false, 3, 0, 2, BNT, F16, false, true>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1726,67 +1537,6 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
         case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
         default: return launch<true, true>(g, aligned, st);
     }
-}
-
-// y = LayerNorm(dropout(A . B^T + bias) + residual) in ONE launch (see epilogue_ln).  Supported: NT, M % 128 == 0,
-// K % 64 == 0, N % 96 == 0 or N % 128 == 0 with at most 16 column tiles, and a grid of at most one block per CU (256): the
-// stripe-mates then run concurrently and the wait is only their skew.  Larger grids: use icka_gemm + icka_ln_fwd.
-static int ln_tile(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0 || M % BM || K % BK) return 0;
-    const int bnt = N % 96 == 0 ? 96 : (N % 128 == 0 ? 128 : 0);
-    if (!bnt) return 0;
-    const int nbn = N / bnt;
-    if (nbn > 16 || (M / BM) * nbn > 256) return 0;
-    return bnt;
-}
-static int g_ln_dbg = 0;
-extern "C" int icka_gemm_ln_set_debug(int mode) { g_ln_dbg = mode; return 0; }
-extern "C" int icka_gemm_ln_supported(int32_t M, int32_t N, int32_t K) { return ln_tile(M, N, K) != 0; }
-extern "C" int64_t icka_gemm_ln_workspace_bytes(int32_t M, int32_t N) {
-    if (M <= 0 || N <= 0) return 0;
-    const int64_t stripes = (M + BM - 1) / BM;
-    // header (the same place for every problem size: launches of different shapes share one workspace and rely on the
-    // counters being zero between launches): counters of up to 256 stripes, error word at byte 2048; then the statistics
-    return 4096 + stripes * BM * 16 * 8;
-}
-extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const icka_ln_epilogue* ln, void* stream) {
-    if (!d || !ln || !d->A || !d->B || !ln->y || !ln->gamma || !ln->beta || !ln->workspace) return ICKA_E_ARG;
-    if (d->op != ICKA_GEMM_NT || d->K1 != 0 || d->epilogue != ICKA_EPI_NONE || d->beta != 0.f || d->colsum_out || d->bias2)
-        return ICKA_E_ARG;
-    const int bnt = ln_tile(d->M, d->N, d->K);
-    if (!bnt) return ICKA_E_SHAPE;
-    if (ln->workspace_bytes < icka_gemm_ln_workspace_bytes(d->M, d->N)) return ICKA_E_ARG;
-    if (ln->residual_kind < 0 || ln->residual_kind > 2 || ln->p_drop < 0.f || ln->p_drop >= 1.f) return ICKA_E_ARG;
-    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (!vec_ok(d->A, d->lda) || !vec_ok(d->B, d->ldb) || !al(ln->y) || ln->ldy % 8 || !al(ln->y_twin) || !al(ln->xhat) ||
-        !al(ln->gamma) || !al(ln->beta) || !al(d->bias) || !al(ln->workspace) ||
-        (ln->residual && (!al(ln->residual) || ln->ld_residual % (ln->residual_kind == 1 ? 4 : 8))))
-        return ICKA_E_ALIGN;
-    GemmArgs g{};
-    g.M = d->M; g.N = d->N; g.K = d->K; g.K1 = 0;
-    g.A = (const bf16_t*)d->A; g.lda = d->lda; g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
-    g.bias = d->bias; g.alpha = d->alpha; g.beta = 0.f; g.epi = ICKA_EPI_NONE;
-    g.f16 = d->ab_f16 != 0; g.a_vec = g.b_vec = 1; g.ksplit = 1; g.stamp = nullptr;
-    LnEpi& L = g.ln;
-    L.res = ln->residual; L.res_kind = ln->residual_kind; L.ldr = ln->ld_residual;
-    L.gamma = ln->gamma; L.beta = ln->beta; L.y = (bf16_t*)ln->y; L.ldy = ln->ldy;
-    L.yf = ln->y_twin; L.yf_f16 = ln->twin_f16 != 0; L.xhat = (bf16_t*)ln->xhat; L.rstd = ln->rstd; L.eps = ln->eps;
-    L.drop = make_drop(ln->p_drop, ln->seed);
-    L.dbg = g_ln_dbg;
-    L.cnt = reinterpret_cast<unsigned*>(ln->workspace);
-    L.err = L.cnt + 512;
-    L.stats = reinterpret_cast<float*>(reinterpret_cast<char*>(ln->workspace) + 4096);
-    hipStream_t st = (hipStream_t)stream;
-    const int nb = (d->M / BM) * (d->N / bnt);
-    if (bnt == 96) {
-        if (g.f16) hipLaunchKernelGGL((gemm_ln_kernel<96, true>), dim3(nb), dim3(512), 0, st, g);
-        else hipLaunchKernelGGL((gemm_ln_kernel<96, false>), dim3(nb), dim3(512), 0, st, g);
-    } else {
-        if (g.f16) hipLaunchKernelGGL((gemm_ln_kernel<128, true>), dim3(nb), dim3(512), 0, st, g);
-        else hipLaunchKernelGGL((gemm_ln_kernel<128, false>), dim3(nb), dim3(512), 0, st, g);
-    }
-    ICKA_CHECK_LAUNCH();
-    return 0;
 }
 
 // 3x3 / pad 1 convolution (stride 1 or 2) of an NHWC bf16 activation as an implicit GEMM on the warp-specialised kernel:

@@ -7,7 +7,6 @@ on a ROCm device; there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
-import os
 import math
 from typing import Optional
 
@@ -70,8 +69,6 @@ def profile_gemm(enable: bool, reps: int = 5):
         for kind, payload, n, _keep in rec:
             if kind == 0:
                 check(lib.icka_gemm(C.byref(payload), _stream()), "icka_gemm")
-            elif kind == 2:
-                check(lib.icka_gemm_ln(C.byref(payload[0]), C.byref(payload[1]), _stream()), "icka_gemm_ln")
             else:
                 check(lib.icka_gemm_grouped(payload, n, _stream()), "icka_gemm_grouped")
 
@@ -175,70 +172,6 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> 
         _PROF.append((0, d, 1, [d]))
     check(lib.icka_gemm(C.byref(d), _stream()), "icka_gemm")
     return out
-
-
-FUSE_LN = os.environ.get("ICKA_FUSE_LN", "1") != "0"   # dense + LayerNorm in one launch where icka_gemm_ln covers the shape
-_LN_WS = {}   # device index -> zeroed workspace of the fused GEMM + LayerNorm launches (one compute stream per device)
-
-
-def gemm_ln_supported(M: int, N: int, K: int) -> bool:
-    """True if gemm_ln covers [M, K] x [N, K]^T (one 128-row tile per CU); else call gemm + ln_fwd."""
-    return bool(_lib.load().icka_gemm_ln_supported(M, N, K))
-
-
-def _ln_workspace(dev: torch.device, M: int, N: int) -> torch.Tensor:
-    need = _lib.load().icka_gemm_ln_workspace_bytes(M, N)
-    ws = _LN_WS.get(dev.index)
-    if ws is None or ws.numel() < need:
-        # sized for the largest supported problem (256 tiles -> M <= 32768 / column tiles) so that it is allocated ONCE,
-        # before any graph capture; zeroed once, the counters reset themselves afterwards
-        ws = torch.zeros(max(need, _lib.load().icka_gemm_ln_workspace_bytes(32768, 96)), dtype=torch.uint8, device=dev)
-        _LN_WS[dev.index] = ws
-    return ws
-
-
-def gemm_ln(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor],
-            gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, *, y_f32=None, y_f16=None, xhat=None, rstd=None,
-            eps: float = 1e-12, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
-    """y = LayerNorm(dropout(A . W^T + bias) + residual) in one launch (icka_gemm_ln; same outputs and dropout mask as
-    gemm(GEMM_NT) into an f32 buffer + ln_fwd).  A / W bf16 or both fp16; residual bf16 / f32 / fp16."""
-    lib = _lib.load()
-    d = gemm_desc(GEMM_NT, A, W, y, bias=bias)   # (y stands in for the dense output, which never reaches memory)
-    M, N = d.M, d.N
-    if y_f32 is not None and y_f16 is not None:
-        raise ValueError("one twin copy: y_f32 or y_f16")
-    twin = y_f16 if y_f16 is not None else y_f32
-    if twin is not None and (twin.dtype != (F16 if y_f16 is not None else F32) or not twin.is_contiguous()
-                             or tuple(twin.shape) != (M, N)):
-        raise ValueError("twin output must be contiguous [M,N] f32 (y_f32) / fp16 (y_f16)")
-    if residual is not None:
-        _mat(residual, "residual", residual.dtype if residual.dtype in (BF16, F32, F16) else BF16)
-        if tuple(residual.shape) != (M, N):
-            raise ValueError("residual must be [%d,%d]" % (M, N))
-    for t, nm, dt, shp in ((xhat, "xhat", BF16, (M, N)), (rstd, "rstd", F32, (M,)), (gamma, "gamma", F32, (N,)),
-                           (beta, "beta", F32, (N,))):
-        if t is not None and (t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous() or not t.is_cuda):
-            raise ValueError("%s must be a contiguous device %s tensor of shape %s" % (nm, dt, shp))
-    ws = _ln_workspace(A.device, M, N)
-    e = _lib.LnEpilogue()
-    e.residual, e.ld_residual = _ptr(residual), _ld(residual)
-    e.residual_kind = 0 if residual is None else _kind(residual)
-    e.twin_f16 = int(y_f16 is not None)
-    e.gamma, e.beta, e.y, e.ldy = gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), y.stride(0)
-    e.y_twin, e.xhat, e.rstd = _ptr(twin), _ptr(xhat), _ptr(rstd)
-    e.eps, e.p_drop, e.seed = eps, p_drop, seed
-    e.workspace, e.workspace_bytes = ws.data_ptr(), ws.numel()
-    if _PROF is not None:
-        d._keep = (A, W, y, bias, residual, gamma, beta, twin, xhat, rstd)
-        _PROF.append((2, (d, e), 1, [d]))
-    check(lib.icka_gemm_ln(C.byref(d), C.byref(e), _stream()), "icka_gemm_ln")
-    return y
-
-
-def gemm_ln_error(dev=None) -> int:
-    """Diagnostic: 1 if a fused launch on this device ever gave up waiting for a stripe-mate (never expected)."""
-    ws = _LN_WS.get(torch.cuda.current_device() if dev is None else torch.device(dev).index)
-    return 0 if ws is None else int(ws[2048:2052].view(torch.int32).item())
 
 
 def slab_reduction(partials: torch.Tensor, nslab: int, H: int, outs, accumulate: bool, slab_stride: int = 0,

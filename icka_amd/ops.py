@@ -175,26 +175,18 @@ def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool, h16=None):
     the twin of the output is fp16.  Returns (y bf16, y twin, saved)."""
     M = h.shape[0]
     H = mod.dense.weight.shape[0]
-    y = _empty(h, M, H)
-    yf = _empty(h, M, H, dtype=F16 if d.h16 else F32)
-    xhat = _empty(h, M, H) if save else None
-    rstd = _empty(h, M, dtype=F32) if save else None
-    seed_h = A.next_seed() if d.p_hidden > 0 else 0
-    twin = {"y_f16": yf} if d.h16 else {"y_f32": yf}
-    if K.FUSE_LN and K.gemm_ln_supported(M, H, h.shape[1]):
-        # one launch: the stripe's GEMM blocks exchange row statistics and normalise in their epilogue (the f32 dense
-        # output never reaches memory; same dropout mask / saved tensors as the two-launch form below)
-        a, w = (h16, A.w16(mod.dense.weight)) if h16 is not None else (h, A.w(mod.dense.weight))
-        K.gemm_ln(a, w, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, xhat=xhat, rstd=rstd,
-                  eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **twin)
-        return y, yf, ((xhat, rstd, seed_h) if save else None)
     o = _empty(h, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra 16-bit rounding)
     if h16 is not None:
         K.gemm(K.GEMM_NT, h16, A.w16(mod.dense.weight), o)
     else:
         K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
+    y = _empty(h, M, H)
+    yf = _empty(h, M, H, dtype=F16 if d.h16 else F32)
+    xhat = _empty(h, M, H) if save else None
+    rstd = _empty(h, M, dtype=F32) if save else None
+    seed_h = A.next_seed() if d.p_hidden > 0 else 0
     K.ln_fwd(o, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, xhat=xhat, rstd=rstd,
-             eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **twin)
+             eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **({"y_f16": yf} if d.h16 else {"y_f32": yf}))
     return y, yf, ((xhat, rstd, seed_h) if save else None)
 
 

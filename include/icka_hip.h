@@ -24,9 +24,8 @@ extern "C" {
 
 /* library / ABI version, and the code-object architecture it was built for ("gfx950") */
 /* 2: round 2 -- icka_gemm_desc grew (ab_f16, C3, ldc3, aux_f16), c_is_f32 may be 2 (fp16 output); new entry points
- * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm.
- * 3: icka_gemm_ln (+ icka_ln_epilogue, icka_gemm_ln_supported, icka_gemm_ln_workspace_bytes). */
-#define ICKA_ABI_VERSION 3
+ * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm. */
+#define ICKA_ABI_VERSION 2
 int icka_abi_version(void);
 const char* icka_build_arch(void);
 
@@ -77,46 +76,6 @@ typedef struct icka_gemm_desc {
     int32_t aux_f16;       /* the epilogue operand `aux` is fp16 instead of bf16 (mixed16 gate: sigmoid(.) * cross_fp16) */
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
-
-/* Dense + dropout + residual + LayerNorm in ONE launch -- BertSelfOutput.forward / BertOutput.forward
- * (Cross_Modal_Interaction_Module.py:561-565, :532-536; a_transformers/modeling_bert.py BertSelfOutput / BertOutput):
- *     y = LayerNorm(dropout(A . B^T + bias) + residual) * gamma + beta
- * The N / 96 (or N / 128) blocks that hold one 128-row stripe of the output exchange per-row (sum, M2) partials through
- * `workspace` and merge them in a fixed order (deterministic; same statistics as the two-pass icka_ln_fwd up to f32
- * rounding).  d: op NT, epilogue NONE, beta 0, no K1 / bias2 / colsum; d->C / ldc / c_is_f32 are ignored (the dense output
- * never reaches memory); d->ab_f16 selects fp16 operands.  Outputs as icka_ln_fwd_h: y bf16 [M, ldy], y_twin [M, N]
- * contiguous f32 (twin_f16 = 0) or fp16 (1) or NULL, xhat bf16 [M, N] / rstd f32 [M] for icka_ln_bwd or NULL.
- * Dropout element index = m * N + n and the same counter hash as icka_ln_fwd: icka_ln_bwd regenerates the mask from seed.
- * workspace: icka_gemm_ln_workspace_bytes(M, N) bytes, 16-byte aligned, ZEROED ONCE by the caller before the first use and
- * then owned by the library (counters reset themselves; a nonzero int32 at byte 2048 = a launch gave up waiting, never
- * expected); launches that share a workspace must be ordered on one stream.
- * Shapes: icka_gemm_ln_supported(M, N, K) -- M % 128 == 0, K % 64 == 0, N % 96 == 0 or N % 128 == 0, at most 16 column
- * tiles and at most 256 tiles in all (one per CU: the stripe's blocks run concurrently); else ICKA_E_SHAPE -> call icka_gemm
- * + icka_ln_fwd instead. */
-typedef struct icka_ln_epilogue {
-    const void* residual;      /* [M, ld_residual] or NULL */
-    int64_t ld_residual;
-    int32_t residual_kind;     /* 0 = bf16, 1 = f32, 2 = fp16 */
-    int32_t twin_f16;
-    const float* gamma;
-    const float* beta;
-    void* y;
-    int64_t ldy;
-    void* y_twin;
-    void* xhat;
-    float* rstd;
-    float eps;
-    float p_drop;
-    uint64_t seed;
-    void* workspace;
-    int64_t workspace_bytes;
-} icka_ln_epilogue;
-int icka_gemm_ln(const icka_gemm_desc* d, const icka_ln_epilogue* ln, void* stream);
-int icka_gemm_ln_supported(int32_t M, int32_t N, int32_t K);
-int64_t icka_gemm_ln_workspace_bytes(int32_t M, int32_t N);
-/* diagnostic: 1 = skip the statistics exchange (each block normalises with its own columns' statistics: WRONG results,
- * prices the exchange in tools/gemm_ln_bench.py); 0 = normal */
-int icka_gemm_ln_set_debug(int mode);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that
  * several partially-filling grids (the weight-gradient GEMMs of a layer) fill the chip together. */
 int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream);

@@ -417,51 +417,6 @@ def _attn_ref(q, k_, v, add_mask, dmask, B, h, Sq, Skv):
     return o.permute(0, 2, 1, 3).reshape(B * Sq, h * 64), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("M,N,Kd,p,res_dt,f16", [(128, 768, 64, 0.0, BF16, False), (4096, 768, 768, 0.1, F32, False),
-                                                  (4096, 768, 3072, 0.1, F32, False), (2048, 1024, 1024, 0.1, F32, False),
-                                                  (4096, 768, 3072, 0.1, torch.float16, True),
-                                                  (1024, 1536, 192, 0.0, None, False), (256, 96, 128, 0.1, BF16, False)])
-def test_gemm_ln_fused(M, N, Kd, p, res_dt, f16):
-    """icka_gemm_ln (dense + dropout + residual + LayerNorm in one launch, row statistics exchanged between the blocks of
-    a stripe) against the two-launch form icka_gemm (f32 out) + icka_ln_fwd on the same operands and dropout seed."""
-    k = _k()
-    assert k.gemm_ln_supported(M, N, Kd)
-    odt = torch.float16 if f16 else BF16
-    A = (torch.randn(M, Kd, device="cuda") * 0.5).to(odt)
-    W = (torch.randn(N, Kd, device="cuda") * (1.0 / Kd ** 0.5)).to(odt)
-    bias, gamma, beta = rnd(N, seed=3, dtype=F32), rnd(N, seed=4, dtype=F32) + 1.0, rnd(N, seed=5, dtype=F32)
-    res = None if res_dt is None else (torch.randn(M, N, device="cuda") * 0.7 + 0.3).to(res_dt)
-    seed = 0x0bad_cafe_1234
-    twin_dt = torch.float16 if f16 else F32
-    tk = "y_f16" if f16 else "y_f32"
-    o = torch.empty(M, N, dtype=F32, device="cuda")
-    k.gemm(k.GEMM_NT, A, W, o)
-    y0 = torch.empty(M, N, dtype=BF16, device="cuda"); t0 = torch.empty(M, N, dtype=twin_dt, device="cuda")
-    xh0 = torch.empty_like(y0); r0 = torch.empty(M, dtype=F32, device="cuda")
-    k.ln_fwd(o, bias, res, gamma, beta, y0, xhat=xh0, rstd=r0, eps=1e-12, p_drop=p, seed=seed, **{tk: t0})
-    outs = []
-    for rep in range(3):   # repeated launches: the workspace counters re-arm themselves; results are bitwise stable
-        y1 = torch.full((M, N), float("nan"), dtype=BF16, device="cuda"); t1 = torch.full((M, N), float("nan"), dtype=twin_dt, device="cuda")
-        xh1 = torch.full_like(y1, float("nan")); r1 = torch.full((M,), float("nan"), dtype=F32, device="cuda")
-        k.gemm_ln(A, W, bias, res, gamma, beta, y1, xhat=xh1, rstd=r1, eps=1e-12, p_drop=p, seed=seed, **{tk: t1})
-        outs.append((y1, t1, xh1, r1))
-    torch.cuda.synchronize()
-    assert k.gemm_ln_error() == 0
-    y1, t1, xh1, r1 = outs[0]
-    for y2, t2, xh2, r2 in outs[1:]:
-        assert torch.equal(y1, y2) and torch.equal(t1, t2) and torch.equal(xh1, xh2) and torch.equal(r1, r2)
-    assert torch.isfinite(t1.float()).all() and torch.isfinite(xh1.float()).all()
-    # statistics: merged block partials vs the two-pass row kernel -- f32 rounding only
-    assert ((r1 - r0).abs() / r0.abs()).max().item() < 1e-5
-    assert (t1.float() - t0.float()).abs().max().item() < (2e-2 if f16 else 1e-4) * max(1.0, t0.float().abs().max().item())
-    # bf16 outputs: same values up to a flipped rounding of the last bit on a few elements
-    d = (y1.float() - y0.float()).abs()
-    assert (d > 0).float().mean().item() < 1e-2 and d.max().item() <= 0.01 * max(1.0, y0.float().abs().max().item()) + 1e-6
-    dx = (xh1.float() - xh0.float()).abs()
-    assert (dx > 0).float().mean().item() < 1e-2 and dx.max().item() < 0.05
-    assert torch.equal(t1.to(BF16), y1) or f16
-
-
 @pytest.mark.parametrize("B,h,Sq,Skv,p", [(2, 2, 64, 64, 0.0), (2, 12, 128, 128, 0.0), (3, 2, 100, 49, 0.0),
                                           (2, 4, 128, 36, 0.1), (2, 3, 128, 128, 0.1), (1, 2, 32, 200, 0.0),
                                           (1, 16, 256, 256, 0.1), (2, 2, 49, 128, 0.1), (1, 2, 5, 7, 0.0),
