@@ -321,6 +321,174 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Flag-in-data hand-off ("LL" form): h_t is published as 8-byte words {2 hidden units bf16, u32 step tag}, written with
+// ONE agent-scope 8-byte store each, and the consumers poll the data words themselves until every tag reads `step`.
+// Against the ticket form above this removes, per time step, the producer's store drain + ticket add and the consumer's
+// separate poll + L1 invalidate: one store -> load hop instead of four dependent round trips.  Words alternate between two
+// buffers by step parity: a block can publish step t+1 only after it has read every block's step t, and nobody overwrites
+// parity p before all of step t+1 (which needs every block's reads of step t done) has been published.  The buffer is
+// zeroed by the host before each launch, tags are step + 1.
+// The reduction over H is split over the 4 waves (wave w: columns [w H/4, (w+1) H/4) of W_hh for ALL four gates), so a
+// wave polls only its quarter of h_t (24 KB of words at B = 32, H = 768) and the block reads h once, not once per gate.
+constexpr int LSTM_LL_MAXH = 1024, LSTM_LL_ROWS = 16 * MAX_RT;
+__device__ unsigned long long g_lstm_ll[2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2)];   // [parity][dir][b][H / 2]
+
+__device__ __forceinline__ u32x4 ll_load16(const unsigned long long* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int NRT, int KQ>   // KQ = W_hh fragments per gate and wave = H / 128
+__global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsigned int* err) {
+    __shared__ float s_g[4][4][NRT * 16][17];   // [wave][gate][b][unit]
+    __shared__ __attribute__((aligned(16))) bf16_t s_h[NRT * 16][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
+    const int i15 = lane & 15, g4 = lane >> 4;
+    const int kq0 = wave * (H >> 2);
+    bf16x8 wf[4][KQ];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bf16_t* wrow = a.whh + ((int64_t)d * 4 * H + (int64_t)q * H + u0 + i15) * H + kq0 + 8 * g4;
+#pragma unroll
+        for (int u = 0; u < KQ; ++u) wf[q][u] = frag16(wrow + 32 * u, true);
+    }
+    float creg[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) creg[i] = 0.f;
+    for (int step = 0; step < S; ++step) {
+        const int tt = d == 0 ? step : S - 1 - step;
+        float gxr[NRT][4];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            const float* gx = a.gx + ((int64_t)(b < a.B ? b : 0) * S + tt) * a.ldg + (int64_t)d * 4 * H + u0 + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gxr[i][q] = gx[q * H];
+        }
+        f32x4 acc[NRT][4];
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            // h_{t-1}: words of step - 1 (tag = step) in buffer (step - 1) & 1
+            const unsigned long long* base = g_lstm_ll + ((int64_t)(((step - 1) & 1) * 2 + d) * LSTM_LL_ROWS) * (LSTM_LL_MAXH / 2) +
+                                             ((kq0 + 8 * g4) >> 1);
+            const uint32_t want = (uint32_t)step;
+            bf16x8 hf[NRT][KQ];
+            int polls = 0;
+            {   // cheap poll first: the last word (row B-1, units 14..15) of each producer block of this wave's quarter -- a
+                // hint only (words become visible in any order); the full load below checks every tag
+                const int nsrc = H >> 6;   // (H / 4) / 16 producer blocks
+                const unsigned long long* sp = base - ((8 * g4) >> 1) + (int64_t)(a.B - 1) * (LSTM_LL_MAXH / 2) + 8 * (lane < nsrc ? lane : 0) + 7;
+                while (true) {
+                    const unsigned long long v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_ballot_w64((uint32_t)(v >> 32) != want) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1 << 20)) break;   // (the full check below reports it)
+                }
+            }
+            bool pending = true;
+            while (pending) {
+                u32x4 raw[NRT][KQ][2];
+#pragma unroll
+                for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                    for (int u = 0; u < KQ; ++u) {
+                        const unsigned long long* p = base + (int64_t)(16 * r + i15) * (LSTM_LL_MAXH / 2) + 16 * u;
+                        raw[r][u][0] = ll_load16(p);
+                        raw[r][u][1] = ll_load16(p + 2);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (the loads are asm outputs the compiler knows nothing about: tie every register to a volatile asm that
+                //  follows the wait, so that no use is scheduled ahead of it)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                    for (int u = 0; u < KQ; ++u) {
+                        asm volatile("" : "+v"(raw[r][u][0]));
+                        asm volatile("" : "+v"(raw[r][u][1]));
+                    }
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const bool live = 16 * r + i15 < a.B;
+#pragma unroll
+                    for (int u = 0; u < KQ; ++u) {
+                        ok = ok && (!live || (raw[r][u][0][1] == want && raw[r][u][0][3] == want && raw[r][u][1][1] == want &&
+                                              raw[r][u][1][3] == want));
+                        const u32x4 dw = {raw[r][u][0][0], raw[r][u][0][2], raw[r][u][1][0], raw[r][u][1][2]};
+                        hf[r][u] = live ? as_bf16x8(dw) : as_bf16x8(u32x4{0u, 0u, 0u, 0u});
+                    }
+                }
+                pending = __builtin_amdgcn_ballot_w64(!ok) != 0ull;
+                if (pending) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1 << 20)) {
+                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pending = false;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KQ; ++u)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r][q] = mfma16(wf[q][u], hf[r][u], acc[r][q]);
+        }
+        __syncthreads();   // s_g / s_h of the previous step fully consumed
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_g[wave][q][16 * r + i15][4 * g4 + e] = acc[r][q][e];
+        __syncthreads();
+        float gi_[NRT], gf_[NRT], gg_[NRT], go_[NRT], hp_[NRT];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            float z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] = gxr[i][q] + ((s_g[0][q][b][u] + s_g[1][q][b][u]) + (s_g[2][q][b][u] + s_g[3][q][b][u]));
+            gi_[i] = sigmoid_f(z[0]); gf_[i] = sigmoid_f(z[1]); gg_[i] = tanhf(z[2]); go_[i] = sigmoid_f(z[3]);
+            const float c = gf_[i] * creg[i] + gi_[i] * gg_[i];
+            hp_[i] = step == 0 ? 0.f : bf2f(s_h[b][u]);   // h_{t-1} of this (b, u): the same thread wrote it last step
+            creg[i] = c;
+            s_h[b][u] = f2bf(go_[i] * tanhf(c));
+        }
+        __syncthreads();
+        // publish h_t first: 2 units + tag per 8-byte word, write-through
+        if (step + 1 < S) {
+            unsigned long long* out = g_lstm_ll + ((int64_t)((step & 1) * 2 + d) * LSTM_LL_ROWS) * (LSTM_LL_MAXH / 2) + (u0 >> 1);
+            for (int p = tid; p < NRT * 16 * 8; p += 256) {
+                const int b = p >> 3, j = p & 7;
+                if (b < a.B) {
+                    const uint32_t dw = *reinterpret_cast<const uint32_t*>(&s_h[b][2 * j]);
+                    __hip_atomic_store(out + (int64_t)b * (LSTM_LL_MAXH / 2) + j, (unsigned long long)dw | ((unsigned long long)(step + 1) << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ... then everything nobody waits for: y, the saved cell state / activations / h_{t-1}
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int p = tid + 256 * i, b = p >> 4, u = p & 15;
+            if (b >= a.B) continue;
+            const int64_t row = (int64_t)b * S + tt;
+            a.y[row * 2 * H + (int64_t)d * H + u0 + u] = s_h[b][u];
+            if (a.hprev) a.hprev[row * 2 * H + (int64_t)d * H + u0 + u] = f2bf(hp_[i]);
+            a.c_all[(row * 2 + d) * H + u0 + u] = creg[i];
+            bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + u;
+            act[0] = f2bf(gi_[i]); act[H] = f2bf(gf_[i]); act[2 * H] = f2bf(gg_[i]); act[3 * H] = f2bf(go_[i]);
+        }
+    }
+}
+
 template <int NRT, int KS>
 __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs a, const LstmPersist ps) {
     __shared__ float s_p[4][NRT * 16][17];
@@ -410,6 +578,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
 }
 
 int g_lstm_persistent = 1;   // icka_lstm_set_persistent
+int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
+static unsigned long long* lstm_ll_words() {
+    static unsigned long long* p = nullptr;
+    if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_ll)) != hipSuccess) p = nullptr;
+    return p;
+}
 __device__ unsigned int g_lstm_sync[4];   // [0..1] tickets, [2] error word
 static unsigned int* lstm_sync_words() {   // address looked up once (not a stream operation: safe under graph capture)
     static unsigned int* p = nullptr;
@@ -502,6 +676,28 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
+    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 128 == 0 && (H / 16) * 2 <= 256) {
+        // flag-in-data hand-off: zero the word buffers (tags of an earlier launch), then one launch for all S steps
+        unsigned int* base = lstm_sync_words();
+        unsigned long long* ll = lstm_ll_words();
+        if (!base || !ll) return ICKA_E_ARG;
+        hipStream_t st = (hipStream_t)stream;
+        if (hipMemsetAsync(ll, 0, sizeof(unsigned long long) * 2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2), st) != hipSuccess) return ICKA_E_ARG;
+        const dim3 grid(H / 16, 2);
+#define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, base + 2)
+        switch (H / 128) {
+            case 2: if (nrt == 1) ICKA_LL_FWD(1, 2); else ICKA_LL_FWD(2, 2); break;
+            case 4: if (nrt == 1) ICKA_LL_FWD(1, 4); else ICKA_LL_FWD(2, 4); break;
+            case 6: if (nrt == 1) ICKA_LL_FWD(1, 6); else ICKA_LL_FWD(2, 6); break;
+            case 8: if (nrt == 1) ICKA_LL_FWD(1, 8); else ICKA_LL_FWD(2, 8); break;
+            default:   // H = 128, 384, 640, 896: not instantiated, fall through to the ticket form below
+                goto ticket_form;
+        }
+#undef ICKA_LL_FWD
+        ICKA_CHECK_LAUNCH();
+        return 0;
+    }
+ticket_form:
     if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= 256) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
@@ -586,6 +782,11 @@ extern "C" int icka_linear_small_m(const void* x, int64_t ldx, const void* W, co
     return 0;
 }
 
+extern "C" int icka_lstm_set_handoff(int32_t mode) {
+    if (mode != 0 && mode != 1) return ICKA_E_ARG;
+    g_lstm_handoff = mode;
+    return 0;
+}
 extern "C" int icka_lstm_set_persistent(int32_t on) {
     g_lstm_persistent = on ? 1 : 0;
     return 0;

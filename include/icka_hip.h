@@ -365,6 +365,9 @@ int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const flo
  * steps; 0: one launch per time step.  icka_lstm_barrier_error() returns 1 if a barrier wait ever gave up (bounded
  * spin: the kernel then finishes with invalid data instead of hanging), -1 if the query itself failed. */
 int icka_lstm_set_persistent(int32_t on);
+/* hand-off between the blocks of a persistent launch: 1 (default) = flag-in-data 8-byte words polled by the consumers (H % 256
+ * == 0 shapes; others use the ticket form), 0 = step tickets + L1 invalidate.  Same results either way. */
+int icka_lstm_set_handoff(int32_t mode);
 int icka_lstm_barrier_error(void);
 /* y bf16 [M <= 64, N] = act(x . W^T + bias) for a handful of rows (BertPooler.forward :675-681: tanh(dense(h[:, 0])),
  * 32 rows at c2): x bf16 rows with stride ldx, W bf16 [N,K], K % 128 == 0; act 0 = none, 1 = tanh. */
