@@ -8,14 +8,18 @@ pytestmark = pytest.mark.gpu
 TAGGER_GRAD_BAR = 1.6e-2   # 2x the 7.8e-3 measured on MI355X (printed by the test)
 
 
-@pytest.mark.parametrize("persistent", [1, 0])
-@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64), (32, 24, 1024), (7, 12, 1024)])
+@pytest.mark.parametrize("persistent", [1, 2, 0])
+@pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64), (32, 24, 1024), (7, 12, 1024),
+                                   (20, 33, 512)])
 def test_bilstm_forward_backward_against_aten(B, S, H, persistent, request):
     from icka_amd import _lib
     from icka_amd.lstm import BiLSTM
     lib = _lib.load()
-    lib.icka_lstm_set_persistent(persistent)       # one persistent launch with grid barriers / one launch per step
-    request.addfinalizer(lambda: lib.icka_lstm_set_persistent(1))
+    # 1: one persistent launch, forward hand-off by tagged data words (H % 256 == 0) / 2: the same with step tickets in
+    # both directions / 0: one launch per step
+    lib.icka_lstm_set_persistent(int(persistent > 0))
+    lib.icka_lstm_set_handoff(int(persistent == 1))
+    request.addfinalizer(lambda: (lib.icka_lstm_set_persistent(1), lib.icka_lstm_set_handoff(1)))
     torch.manual_seed(B * 100 + S)
     ref = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
     mine = BiLSTM(H, H)
