@@ -112,6 +112,7 @@ PROTOTYPES = {
     "icka_lstm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_lstm_set_persistent": (c_i32, [c_i32]),
     "icka_lstm_set_handoff": (c_i32, [c_i32]),
+    "icka_lstm_set_batch_split": (c_i32, [c_i32]),
     "icka_lstm_barrier_error": (c_i32, []),
     "icka_linear_small_m": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "icka_transpose_bf16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

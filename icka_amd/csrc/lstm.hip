@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
     const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
     const int i15 = lane & 15, g4 = lane >> 4;
     const int kq0 = wave * (H >> 2);
+    const int bofs = 16 * blockIdx.z;   // batch rows are independent recurrences: grid.z may split them into tiles of 16
     bf16x8 wf[4][KQ];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
             const int p = tid + 256 * i, b = p >> 4, u = p & 15;
-            const float* gx = a.gx + ((int64_t)(b < a.B ? b : 0) * S + tt) * a.ldg + (int64_t)d * 4 * H + u0 + u;
+            const float* gx = a.gx + ((int64_t)(b + bofs < a.B ? b + bofs : 0) * S + tt) * a.ldg + (int64_t)d * 4 * H + u0 + u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) gxr[i][q] = gx[q * H];
         }
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
             {   // cheap poll first: the last word (row B-1, units 14..15) of each producer block of this wave's quarter -- a
                 // hint only (words become visible in any order); the full load below checks every tag
                 const int nsrc = H >> 6;   // (H / 4) / 16 producer blocks
-                const unsigned long long* sp = base - ((8 * g4) >> 1) + (int64_t)(a.B - 1) * (LSTM_LL_MAXH / 2) + 8 * (lane < nsrc ? lane : 0) + 7;
+                const int blast = (a.B < bofs + 16 * NRT ? a.B : bofs + 16 * NRT) - 1;
+                const unsigned long long* sp = base - ((8 * g4) >> 1) + (int64_t)blast * (LSTM_LL_MAXH / 2) + 8 * (lane < nsrc ? lane : 0) + 7;
                 while (true) {
                     const unsigned long long v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_ballot_w64((uint32_t)(v >> 32) != want) == 0ull) break;
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
                 for (int r = 0; r < NRT; ++r)
 #pragma unroll
                     for (int u = 0; u < KQ; ++u) {
-                        const unsigned long long* p = base + (int64_t)(16 * r + i15) * (LSTM_LL_MAXH / 2) + 16 * u;
+                        const unsigned long long* p = base + (int64_t)(bofs + 16 * r + i15) * (LSTM_LL_MAXH / 2) + 16 * u;
                         raw[r][u][0] = ll_load16(p);
                         raw[r][u][1] = ll_load16(p + 2);
                     }
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
                 bool ok = true;
 #pragma unroll
                 for (int r = 0; r < NRT; ++r) {
-                    const bool live = 16 * r + i15 < a.B;
+                    const bool live = bofs + 16 * r + i15 < a.B;
 #pragma unroll
                     for (int u = 0; u < KQ; ++u) {
                         ok = ok && (!live || (raw[r][u][0][1] == want && raw[r][u][0][3] == want && raw[r][u][1][1] == want &&
@@ -467,9 +469,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
             unsigned long long* out = g_lstm_ll + ((int64_t)((step & 1) * 2 + d) * LSTM_LL_ROWS) * (LSTM_LL_MAXH / 2) + (u0 >> 1);
             for (int p = tid; p < NRT * 16 * 8; p += 256) {
                 const int b = p >> 3, j = p & 7;
-                if (b < a.B) {
+                if (b + bofs < a.B) {
                     const uint32_t dw = *reinterpret_cast<const uint32_t*>(&s_h[b][2 * j]);
-                    __hip_atomic_store(out + (int64_t)b * (LSTM_LL_MAXH / 2) + j, (unsigned long long)dw | ((unsigned long long)(step + 1) << 32),
+                    __hip_atomic_store(out + (int64_t)(b + bofs) * (LSTM_LL_MAXH / 2) + j, (unsigned long long)dw | ((unsigned long long)(step + 1) << 32),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -478,8 +480,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
             const int p = tid + 256 * i, b = p >> 4, u = p & 15;
-            if (b >= a.B) continue;
-            const int64_t row = (int64_t)b * S + tt;
+            if (b + bofs >= a.B) continue;
+            const int64_t row = (int64_t)(b + bofs) * S + tt;
             a.y[row * 2 * H + (int64_t)d * H + u0 + u] = s_h[b][u];
             if (a.hprev) a.hprev[row * 2 * H + (int64_t)d * H + u0 + u] = f2bf(hp_[i]);
             a.c_all[(row * 2 + d) * H + u0 + u] = creg[i];
@@ -579,12 +581,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
 
 int g_lstm_persistent = 1;   // icka_lstm_set_persistent
 int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
+int g_lstm_bsplit = 1;       // icka_lstm_set_batch_split: batch tiles of 16 rows as separate blocks of the persistent launches
 static unsigned long long* lstm_ll_words() {
     static unsigned long long* p = nullptr;
     if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_ll)) != hipSuccess) p = nullptr;
     return p;
 }
-__device__ unsigned int g_lstm_sync[4];   // [0..1] tickets, [2] error word
+__device__ unsigned int g_lstm_sync[8];   // [0..1] tickets per direction (2..3 spare), [4] error word
 static unsigned int* lstm_sync_words() {   // address looked up once (not a stream operation: safe under graph capture)
     static unsigned int* p = nullptr;
     if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_sync)) != hipSuccess) p = nullptr;
@@ -683,13 +686,17 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
         if (!base || !ll) return ICKA_E_ARG;
         hipStream_t st = (hipStream_t)stream;
         if (hipMemsetAsync(ll, 0, sizeof(unsigned long long) * 2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2), st) != hipSuccess) return ICKA_E_ARG;
-        const dim3 grid(H / 16, 2);
-#define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, base + 2)
+        // batch rows are independent recurrences: two tiles of 16 rows run as separate blocks (grid.z) where all of them
+        // are co-resident -- half the words to poll and half the MFMAs per block and step
+        const bool split = g_lstm_bsplit && nrt == 2 && (H / 16) * 2 * 2 <= 256;
+        const dim3 grid(H / 16, 2, split ? 2 : 1);
+        const int nr = split ? 1 : nrt;
+#define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, base + 4)
         switch (H / 128) {
-            case 2: if (nrt == 1) ICKA_LL_FWD(1, 2); else ICKA_LL_FWD(2, 2); break;
-            case 4: if (nrt == 1) ICKA_LL_FWD(1, 4); else ICKA_LL_FWD(2, 4); break;
-            case 6: if (nrt == 1) ICKA_LL_FWD(1, 6); else ICKA_LL_FWD(2, 6); break;
-            case 8: if (nrt == 1) ICKA_LL_FWD(1, 8); else ICKA_LL_FWD(2, 8); break;
+            case 2: if (nr == 1) ICKA_LL_FWD(1, 2); else ICKA_LL_FWD(2, 2); break;
+            case 4: if (nr == 1) ICKA_LL_FWD(1, 4); else ICKA_LL_FWD(2, 4); break;
+            case 6: if (nr == 1) ICKA_LL_FWD(1, 6); else ICKA_LL_FWD(2, 6); break;
+            case 8: if (nr == 1) ICKA_LL_FWD(1, 8); else ICKA_LL_FWD(2, 8); break;
             default:   // H = 128, 384, 640, 896: not instantiated, fall through to the ticket form below
                 goto ticket_form;
         }
@@ -702,8 +709,8 @@ ticket_form:
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         if (!base) return ICKA_E_ARG;
-        ps.tickets = base; ps.err = base + 2;
-        if (hipMemsetAsync(base, 0, 2 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
+        ps.tickets = base; ps.err = base + 4;
+        if (hipMemsetAsync(base, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
         // KS = resident W_hh fragments per wave (32 hidden units each): 24 up to H = 768, 32 up to H = 1024
         if (H > 768) {
             if (nrt == 1) hipLaunchKernelGGL((lstm_fwd_persistent_kernel<1, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
@@ -738,8 +745,10 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         if (!base) return ICKA_E_ARG;
-        ps.tickets = base; ps.err = base + 2;
-        if (hipMemsetAsync(base, 0, 2 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
+        ps.tickets = base; ps.err = base + 4;
+        if (hipMemsetAsync(base, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
+        // (batch tiles as separate blocks, as in the forward launch, are slower here: 9.3 vs 8.9 us per step at H = 768 --
+        //  every block reads all of dgates_t through L2 either way, twice the blocks only add contention)
         if (H > 768) {
             if (nrt == 1) hipLaunchKernelGGL((lstm_bwd_persistent_kernel<1, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
             else hipLaunchKernelGGL((lstm_bwd_persistent_kernel<2, 32>), dim3(H / 16, 2), dim3(256), 0, (hipStream_t)stream, a, ps);
@@ -782,6 +791,10 @@ extern "C" int icka_linear_small_m(const void* x, int64_t ldx, const void* W, co
     return 0;
 }
 
+extern "C" int icka_lstm_set_batch_split(int32_t on) {
+    g_lstm_bsplit = on ? 1 : 0;
+    return 0;
+}
 extern "C" int icka_lstm_set_handoff(int32_t mode) {
     if (mode != 0 && mode != 1) return ICKA_E_ARG;
     g_lstm_handoff = mode;
@@ -793,7 +806,7 @@ extern "C" int icka_lstm_set_persistent(int32_t on) {
 }
 /* 1 if a grid barrier of the persistent recurrence ever gave up waiting (results of that call are invalid). */
 extern "C" int icka_lstm_barrier_error(void) {
-    unsigned int v[4] = {0, 0, 0, 0};
+    unsigned int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_lstm_sync), sizeof(v)) != hipSuccess) return -1;
-    return (int)v[2];
+    return (int)v[4];
 }

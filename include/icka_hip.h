@@ -368,6 +368,9 @@ int icka_lstm_set_persistent(int32_t on);
 /* hand-off between the blocks of a persistent launch: 1 (default) = flag-in-data 8-byte words polled by the consumers (H % 256
  * == 0 shapes; others use the ticket form), 0 = step tickets + L1 invalidate.  Same results either way. */
 int icka_lstm_set_handoff(int32_t mode);
+/* 1 (default): in the forward launch with the tagged-word hand-off a batch of 17..32 rows runs as two independent tiles of
+ * 16 rows (separate blocks); 0: one block per 16 hidden units holds all rows.  Same results. */
+int icka_lstm_set_batch_split(int32_t on);
 int icka_lstm_barrier_error(void);
 /* y bf16 [M <= 64, N] = act(x . W^T + bias) for a handful of rows (BertPooler.forward :675-681: tanh(dense(h[:, 0])),
  * 32 rows at c2): x bf16 rows with stride ldx, W bf16 [N,K], K % 128 == 0; act 0 = none, 1 = tanh. */

@@ -44,12 +44,12 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1e3 / args.reps
 
 
-for mode in (1, 0) if hasattr(lib, "icka_lstm_set_handoff") else (None,):
-    if mode is not None:
-        lib.icka_lstm_set_handoff(mode)
+for mode, split in ((1, 1), (1, 0), (0, 1), (0, 0)):
+    lib.icka_lstm_set_handoff(mode)
+    lib.icka_lstm_set_batch_split(split)
     tf = timed(lambda: K.lstm_fwd(gx, whh, y, c_all, act, hprev, B, S, H))
     ysum = y.float().abs().sum().item()
     tb = timed(lambda: K.lstm_bwd(dy, whh_t, act, c_all, dgates, dcc, B, S, H))
     gsum = dgates.float().abs().sum().item()
-    print("B %d S %d H %d handoff %s | fwd %.1f us (%.2f us/step) | bwd %.1f us (%.2f us/step) | checksums %.6e %.6e"
-          % (B, S, H, mode, tf, tf / S, tb, tb / S, ysum, gsum), flush=True)
+    print("B %d S %d H %d handoff %s split %d | fwd %.1f us (%.2f us/step) | bwd %.1f us (%.2f us/step) | checksums %.6e %.6e"
+          % (B, S, H, mode, split, tf, tf / S, tb, tb / S, ysum, gsum), flush=True)
