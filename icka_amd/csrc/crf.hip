@@ -257,10 +257,10 @@ __device__ __forceinline__ float lse_shfl(float x, const float (&col)[CM]) {
     return m + __logf(s);
 }
 
-__global__ __launch_bounds__(64) void crf_llh_small_kernel(const CrfArgs a) {
+// log-domain recursions (every step: 16 shuffles + 16 exp + log on the dependent chain): the fallback of the scaled
+// linear-domain kernels below for parameters / emissions whose spread underflows f32
+__device__ __noinline__ void crf_llh_small_log(const CrfArgs& a, const MaskBits& mb) {
     const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
-    int len;
-    const MaskBits mb = load_mask(a, b, j, &len);
     float Tc[CM];
 #pragma unroll
     for (int i = 0; i < CM; ++i) Tc[i] = (j < C && i < C) ? a.trans[i * C + j] : -INFINITY;
@@ -282,11 +282,8 @@ __global__ __launch_bounds__(64) void crf_llh_small_kernel(const CrfArgs a) {
     if (j == 0) a.llh[b] = num - z;
 }
 
-__global__ __launch_bounds__(64) void crf_grad_small_kernel(const CrfArgs a) {
-    __shared__ float s_al[CRF_MAX_SC];   // alpha[t][j] after step t
+__device__ __noinline__ void crf_grad_small_log(const CrfArgs& a, const MaskBits& mb, int len, float* s_al) {
     const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
-    int len;
-    const MaskBits mb = load_mask(a, b, j, &len);
     const bool act_lane = j < C;
     float Tc[CM], Tr[CM], dT[CM];   // column j (into tag j), row j (out of tag j), gradient column j
 #pragma unroll
@@ -355,6 +352,245 @@ __global__ __launch_bounds__(64) void crf_grad_small_kernel(const CrfArgs a) {
         for (int i = 0; i < CM; ++i)
             if (i < C) atomicAdd(a.dtrans + i * C + j, g * dT[i]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Scaled linear-domain forward-backward (C <= 16): the same quantities as the log-domain recursions with NO transcendental
+// on the dependent chain -- a_t[j] = (sum_i a_{t-1}[i] E[i][j]) x_t[j] / c_t with E = exp(trans - max trans),
+// x_t = exp(e_t - max_j e_t) (computed one step ahead, off the chain) and c_t = sum_i a_{t-1}[i] (the normaliser lags one
+// step, so its DPP row sum + reciprocal run beside the dot product), so a step is 16 lane reads + FMAs and a multiply; log Z = sum_t (log c_t + max_j e_t + max trans) + ... accumulates
+// beside the chain.  Backward: bhat_{t-1}[i] = sum_j E[i][j] x_t[j] bhat_t[j] / c_t, marginal_t = a_t . bhat_t,
+// pair marginals a_{t-1}[i] E[i][j] x_t[j] bhat_t[j] / c_t.  If a normaliser underflows (spreads beyond ~e^80, e.g.
+// -1e4 "forbidden" transitions into every reachable tag) or a marginal is not finite the sample is redone by the
+// log-domain body above: same results either way up to f32 rounding.
+// 16-lane row reductions on the DPP path (row_ror: no LDS crossbar, ~4 VALU ops): every lane of the row gets the result
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum16(float v) {
+    v += dpp_f<0x128>(v);   // row_ror:8
+    v += dpp_f<0x124>(v);   // row_ror:4
+    v += dpp_f<0x122>(v);   // row_ror:2
+    v += dpp_f<0x121>(v);   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, dpp_f<0x128>(v));
+    v = fmaxf(v, dpp_f<0x124>(v));
+    v = fmaxf(v, dpp_f<0x122>(v));
+    v = fmaxf(v, dpp_f<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ float lane_val(float x, int i) {   // value of lane i (compile-time i) as a scalar operand
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
+}
+// sum_i (value of lane i) * col[i]
+__device__ __forceinline__ float dot_shfl(float x, const float (&col)[CM]) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CM; i += 4) {
+        s0 = fmaf(lane_val(x, i), col[i], s0);
+        s1 = fmaf(lane_val(x, i + 1), col[i + 1], s1);
+        s2 = fmaf(lane_val(x, i + 2), col[i + 2], s2);
+        s3 = fmaf(lane_val(x, i + 3), col[i + 3], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+constexpr float CRF_TINY = 1e-30f;
+constexpr int CRF_LIN_SC = 4096;   // S * C of the scaled form: x_t and a_t tiles of 16 KiB each
+
+struct CrfLin {
+    float logz;      // log partition function
+    float zend;      // sum_j a_last[j] exp(end[j] - mEnd)
+    float mEnd;
+    float a_last;    // this lane's (semi-normalised) alpha after the last step
+};
+// Stage the sample: emissions -> LDS in one coalesced sweep (the recursions then never wait for HBM or scratch: a per-step
+// global load -- or a dynamically indexed mask word, which lives in scratch -- is a whole step of latency), then per
+// position (lanes over t) x_t[j] = exp(e_t[j] - max_j e_t[j]) in place, the step-on flags and the clamped gold tags.
+// Returns sum over the ON steps t >= 1 of (max_j e_t[j] + mT) + max_j e_0[j]: the static part of log Z.
+__device__ __forceinline__ float crf_stage(const CrfArgs& a, float mT, float* s_x, unsigned char* s_on, unsigned char* s_tag) {
+    const int b = blockIdx.x, lane = threadIdx.x, C = a.C, S = a.S;
+    const float* eb = a.e + (int64_t)b * S * a.ld_s;
+    for (int idx = lane; idx < S * C; idx += 64) {
+        const int t = idx / C, j = idx - t * C;
+        s_x[idx] = eb[(int64_t)t * a.ld_s + j];
+    }
+    __syncthreads();
+    const int64_t* tg = a.tags + (int64_t)b * S;
+    float lzs = 0.f;
+    for (int t = lane; t < S; t += 64) {
+        float m = -INFINITY;
+        for (int j = 0; j < C; ++j) m = fmaxf(m, s_x[t * C + j]);
+        for (int j = 0; j < C; ++j) s_x[t * C + j] = __expf(s_x[t * C + j] - m);
+        const bool on = t == 0 || a.mask == nullptr || a.mask[(int64_t)b * S + t] != 0;
+        s_on[t] = on ? 1 : 0;
+        if (on) lzs += t == 0 ? m : m + mT;
+        if (s_tag) s_tag[t] = (unsigned char)tag_at(tg, t, C);
+    }
+    __syncthreads();
+    return wave_sum(lzs);
+}
+// Forward over the staged x.  s_al (may be null): a_t[j] for every t; s_c (may be null): the normaliser used AT on-step t
+// (= sum of the alpha state before it).  Returns false if a normaliser left the safe range (wave-uniform).
+__device__ __forceinline__ bool crf_forward_lin(const CrfArgs& a, const float (&Ec)[CM], float lz_static, const float* s_x,
+                                                const unsigned char* s_on, float* s_al, float* s_c, CrfLin& out) {
+    const int j = threadIdx.x, C = a.C, S = a.S;
+    const bool act_lane = j < C;
+    bool ok = true;
+    const float sv = act_lane ? a.start[j] : -INFINITY;
+    const float mS = max16(sv);
+    float al = act_lane ? __expf(sv - mS) * s_x[j] : 0.f;   // a_0 (its sum divides the NEXT step)
+    float lz = mS + lz_static;
+    if (s_al && act_lane) s_al[j] = al;
+    float xn = (act_lane && S > 1) ? s_x[C + j] : 0.f;
+    int onn = S > 1 ? s_on[1] : 0;
+    for (int t = 1; t < S; ++t) {
+        const float x = xn;
+        const int on = onn;
+        if (t + 1 < S) { xn = act_lane ? s_x[(t + 1) * C + j] : 0.f; onn = s_on[t + 1]; }
+        if (on) {
+            // a_t = (a_{t-1} . E) x_t / sum(a_{t-1}): the row sum + reciprocal run beside the 16-term dot product
+            const float sm = sum16(al);
+            ok = ok && sm > CRF_TINY && sm < 1e30f;
+            al = dot_shfl(al, Ec) * (x * (1.f / sm));
+            lz += __logf(sm);
+            if (s_c && j == 0) s_c[t] = sm;
+        }
+        if (s_al && act_lane) s_al[t * C + j] = al;
+    }
+    const float ev = act_lane ? a.end[j] : -INFINITY;
+    out.mEnd = max16(ev);
+    const float w = act_lane ? al * __expf(ev - out.mEnd) : 0.f;
+    out.zend = sum16(w);
+    ok = ok && out.zend > CRF_TINY && out.zend < 1e30f;
+    out.logz = lz + out.mEnd + __logf(out.zend);
+    out.a_last = al;
+    // (lanes 16..63 carry zeros / NaNs of their own empty rows: only the first 16 lanes vote)
+    ok = ok && isfinite(out.logz);
+    return (__builtin_amdgcn_ballot_w64(!ok) & 0xffffull) == 0ull;
+}
+__device__ __forceinline__ float crf_load_E(const CrfArgs& a, int j, float (&Ec)[CM], float (&Er)[CM], bool rows) {
+    const int C = a.C;
+    float m = -INFINITY;
+    for (int k = j; k < C * C; k += 64) m = fmaxf(m, a.trans[k]);
+    m = wave_max(m);
+#pragma unroll
+    for (int i = 0; i < CM; ++i) {
+        Ec[i] = (j < C && i < C) ? __expf(a.trans[i * C + j] - m) : 0.f;
+        if (rows) Er[i] = (j < C && i < C) ? __expf(a.trans[j * C + i] - m) : 0.f;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(64) void crf_llh_small_kernel(const CrfArgs a) {
+    __shared__ float s_x[CRF_LIN_SC];
+    __shared__ unsigned char s_on[64 * MAXW];
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (a.S * a.C <= CRF_LIN_SC) {
+        float Ec[CM], Er[CM];
+        const float mT = crf_load_E(a, j, Ec, Er, false);
+        const float lzs = crf_stage(a, mT, s_x, s_on, nullptr);
+        CrfLin f;
+        if (crf_forward_lin(a, Ec, lzs, s_x, s_on, nullptr, nullptr, f)) {
+            const float num = gold_score(a, b, j);
+            if (j == 0) a.llh[b] = num - f.logz;
+            return;
+        }
+    }
+    int len;
+    const MaskBits mb = load_mask(a, b, j, &len);
+    crf_llh_small_log(a, mb);
+}
+
+__global__ __launch_bounds__(64) void crf_grad_small_kernel(const CrfArgs a) {
+    __shared__ float s_buf[CRF_MAX_SC];   // scaled form: a_t[j] | x_t[j] (S * C <= 4096 each); log form: alpha[t][j]
+    __shared__ float s_c[64 * MAXW];
+    __shared__ unsigned char s_tag[64 * MAXW], s_on[64 * MAXW];
+    const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
+    const bool act_lane = j < C;
+    bool ok = S * C <= CRF_LIN_SC;
+    if (ok) {
+        float* s_al = s_buf;
+        float* s_x = s_buf + CRF_LIN_SC;
+        float Ec[CM], Er[CM];
+        const float mT = crf_load_E(a, j, Ec, Er, true);
+        const float lzs = crf_stage(a, mT, s_x, s_on, s_tag);
+        CrfLin f;
+        ok = crf_forward_lin(a, Ec, lzs, s_x, s_on, s_al, s_c, f);
+        __syncthreads();
+        if (ok) {
+            // x_t[j] / S_{t-1} for every on-step, all rows at once (lanes over t): no division on the backward chain
+            int cnt = 0;
+            for (int t = j; t < S; t += 64) {
+                cnt += (a.mask == nullptr || a.mask[(int64_t)b * S + t] != 0) ? 1 : 0;
+                if (t >= 1 && s_on[t]) {
+                    const float r = 1.f / s_c[t];
+                    for (int k = 0; k < C; ++k) s_x[t * C + k] *= r;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            const int last = cnt > 0 ? cnt - 1 : 0;
+            __syncthreads();
+            const float g = a.gllh[b];
+            float* deb = a.de + (int64_t)b * S * a.ld_ds;
+            float dT[CM];
+#pragma unroll
+            for (int i = 0; i < CM; ++i) dT[i] = 0.f;
+            // bhat after the last step: exp(end - mEnd) / zend  (marginal_last = a_last . bhat)
+            float bh = act_lane ? __expf(a.end[j] - f.mEnd) / f.zend : 0.f;
+            float dend = act_lane ? -(f.a_last * bh) : 0.f;
+            float dstart = 0.f;
+            // operands of the step, fetched from LDS one step ahead
+            int on_n = s_on[S - 1], y_n = s_tag[S - 1], yp_n = S > 1 ? s_tag[S - 2] : 0;
+            float al_n = act_lane ? s_al[(S - 1) * C + j] : 0.f, ap_n = (act_lane && S > 1) ? s_al[(S - 2) * C + j] : 0.f;
+            float xc_n = act_lane ? s_x[(S - 1) * C + j] : 0.f;
+            for (int t = S - 1; t >= 0; --t) {
+                const int on = on_n, y = y_n, yp = yp_n;
+                const float alt = al_n, ap = ap_n, xc = xc_n;
+                if (t > 0) {
+                    on_n = s_on[t - 1]; y_n = yp; yp_n = t > 1 ? s_tag[t - 2] : 0;
+                    al_n = ap; ap_n = (act_lane && t > 1) ? s_al[(t - 2) * C + j] : 0.f;
+                    xc_n = act_lane ? s_x[(t - 1) * C + j] : 0.f;
+                }
+                if (!on) {
+                    if (act_lane) deb[(int64_t)t * a.ld_ds + j] = 0.f;
+                    continue;
+                }
+                const float marg = alt * bh;
+                ok = ok && isfinite(marg);
+                if (act_lane) deb[(int64_t)t * a.ld_ds + j] = g * ((j == y ? 1.f : 0.f) - marg);
+                if (t == 0) { dstart = (j == y ? 1.f : 0.f) - marg; break; }
+                // u[j] = x_t[j] bhat_t[j] / S_{t-1};  pair marginal (i, j) = a_{t-1}[i] E[i][j] u[j]
+                const float u = xc * bh;
+#pragma unroll
+                for (int i = 0; i < CM; ++i) dT[i] = fmaf(-lane_val(ap, i) * Ec[i], u, dT[i]);
+                if (j == y) {   // gold transition (literal previous position)
+#pragma unroll
+                    for (int i = 0; i < CM; ++i) dT[i] += (i == yp) ? 1.f : 0.f;
+                }
+                bh = act_lane ? dot_shfl(u, Er) : 0.f;   // bhat_{t-1}[j] = sum_k E[j][k] u[k]
+            }
+            ok = (__builtin_amdgcn_ballot_w64(!ok) & 0xffffull) == 0ull;
+            if (ok) {
+                if (act_lane) {
+                    if (j == s_tag[last]) dend += 1.f;
+                    atomicAdd(a.dstart + j, g * dstart);
+                    atomicAdd(a.dend + j, g * dend);
+#pragma unroll
+                    for (int i = 0; i < CM; ++i)
+                        if (i < C) atomicAdd(a.dtrans + i * C + j, g * dT[i]);
+                }
+                return;
+            }
+        }
+        __syncthreads();
+    }
+    int len;
+    const MaskBits mb = load_mask(a, b, j, &len);
+    crf_grad_small_log(a, mb, len, s_buf);
 }
 
 __global__ __launch_bounds__(64) void crf_decode_small_kernel(const CrfArgs a) {

@@ -55,6 +55,50 @@ def test_crf_llh_grad_decode_against_oracle(B, S, Cn, reduction):
     assert [len(p) for p in paths] == lens.tolist()
 
 
+@pytest.mark.parametrize("scale,forbid", [(2.0, True), (40.0, False), (60.0, True)])
+def test_crf_extreme_scores_against_oracle(scale, forbid):
+    """-1e4 "forbidden" transitions (BIO constraints) and emission spreads up to e^+-200: the scaled linear-domain recursion
+    either stays in range or hands the sample to the log-domain body -- both must match the oracle."""
+    from icka_amd.crf import CRF
+    from oracle import crf_oracle as O
+    B, S, Cn = 6, 64, 13
+    e, tags, mask, lens = _case(B, S, Cn, seed=77)
+    e = e * (scale / 2.0)
+    torch.manual_seed(int(scale) * 2 + int(forbid))   # (the CRF parameters are drawn at construction)
+    crf = CRF(Cn, batch_first=True).cuda()
+    with torch.no_grad():
+        if forbid:
+            g = torch.Generator().manual_seed(5)
+            blocked = torch.rand(Cn, Cn, generator=g) < 0.3
+            blocked[torch.arange(Cn), torch.arange(Cn)] = False
+            crf.transitions[blocked.cuda()] = -1e4
+            crf.start_transitions[::3] = -1e4
+            # keep the gold paths feasible (finite log-likelihood): route them over allowed transitions only
+            ok_next = (~blocked)
+            tags[:, 0] = 1
+            for b in range(B):
+                for t in range(1, S):
+                    cand = torch.nonzero(ok_next[tags[b, t - 1]]).flatten()
+                    tags[b, t] = cand[(b + t) % len(cand)]
+            tags = torch.where(mask, tags, torch.zeros_like(tags))
+    # the oracle in float64: at |scores| ~ 7e3 an f32 log-domain recursion (the oracle's own, and the kernels' fallback body)
+    # carries ~1e-3 of rounding in the marginals (f32 oracle: marginals of 1.0002)
+    P = [p.detach().cpu().double().clone().requires_grad_(True) for p in (crf.start_transitions, crf.end_transitions, crf.transitions)]
+    eg = e.cuda().requires_grad_(True)
+    out = crf(eg, tags.cuda(), mask=mask.cuda().byte(), reduction="none")
+    er = e.double().clone().requires_grad_(True)
+    ref = O.crf_llh(er, tags, mask, *P)
+    assert torch.isfinite(out).all() and torch.isfinite(ref).all()
+    assert torch.allclose(out.detach().cpu().double(), ref.detach(), rtol=3e-5, atol=2e-3 * max(1.0, scale / 10)), (out, ref)
+    (-out.sum()).backward()
+    (-ref.sum()).backward()
+    assert torch.isfinite(eg.grad).all()
+    bar = 2e-3 if scale < 40 else 4e-3
+    assert (eg.grad.cpu().double() - er.grad).abs().max().item() < bar
+    for mine, theirs in zip((crf.start_transitions, crf.end_transitions, crf.transitions), P):
+        assert (mine.grad.cpu().double() - theirs.grad).abs().max().item() < bar * (theirs.grad.abs().max().item() + 1.0), (mine.grad, theirs.grad)
+
+
 def test_crf_decode_matches_brute_force_and_sequence_first_layout():
     from icka_amd.crf import CRF
     from oracle import crf_oracle as O
