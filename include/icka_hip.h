@@ -24,8 +24,9 @@ extern "C" {
 
 /* library / ABI version, and the code-object architecture it was built for ("gfx950") */
 /* 2: round 2 -- icka_gemm_desc grew (ab_f16, C3, ldc3, aux_f16), c_is_f32 may be 2 (fp16 output); new entry points
- * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm. */
-#define ICKA_ABI_VERSION 2
+ * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm.
+ * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split (additive). */
+#define ICKA_ABI_VERSION 3
 int icka_abi_version(void);
 const char* icka_build_arch(void);
 
