@@ -39,6 +39,9 @@ __device__ __forceinline__ bf16x8 frag16(const bf16_t* row, bool ok) {
 }
 
 constexpr int MAX_RT = 4;   // batch row tiles of 16 (B <= 64 per launch)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, f2bf(lo)) | ((uint32_t)__builtin_bit_cast(unsigned short, f2bf(hi)) << 16);
+}
 
 // ---------------------------------------------------------------------------------------------------- forward step
 template <int NRT, int UB>
@@ -579,9 +582,157 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward recurrence, reduce-scatter form with the flag-in-data hand-off.  dh_t = dy_t + dgates_{t+1} . W_hh needs ALL 4H
+// gate columns of step t+1 in every block if the blocks exchange dgates (the ticket kernel above: 192 KB per block and step,
+// and as tagged words twice that through L2-bypassing loads -- measured 14.6 vs 8.9 us per step).  Here the PRODUCER
+// multiplies: the block that owns units U computes its own 64 gate columns of dgates_t and at once their contribution
+//     P = dgates_t[:, G(U)] . W_hh[G(U), :]      (16 rows x H, K = 64: 2 MFMA k-steps per 16-column tile)
+// to dh_{t-1} of EVERY unit, and sends each 16-column tile of P to the block that owns those units as {2 x bf16, tag} words;
+// a consumer sums the H / 16 partial tiles addressed to it (12 x 16-byte loads per thread at H = 768).  Every word is written
+// once and read once (no broadcast), batch tiles of 16 rows are independent blocks, and a step is one store -> load hop.
+// Word buffer: [parity][dir][dest block][src block][32 rows][8 words]; tags S - step, parity by step (same argument as the
+// forward kernel: a block reaches step t-1 only after every block has produced step t, i.e. consumed step t+1).
+template <int NT>   // 16-column tiles of P per wave = sources summed per wave = H / 64
+__global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsigned long long* llr, unsigned int* err) {
+    __shared__ float s_p[4][16][17];
+    __shared__ __attribute__((aligned(16))) bf16_t s_dg[4][16][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, blk = blockIdx.x, u0 = blk * 16, H = a.H, S = a.S;
+    const int nblk = gridDim.x, bofs = 16 * blockIdx.z;
+    const int i15 = lane & 15, g4 = lane >> 4;
+    // W_hh^T rows n (all H of them, this wave's NT tiles), columns = this block's 64 gate columns in the order k = 16 q + uu
+    bf16x8 wf[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = 16 * (wave * NT + j) + i15;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+            wf[j][f] = frag16(a.whh + ((int64_t)d * H + n) * 4 * H + (int64_t)(2 * f + (g4 >> 1)) * H + u0 + 8 * (g4 & 1), true);
+    }
+    const int64_t region = (int64_t)nblk * nblk * 256;   // words per (parity, direction)
+    const int cb = tid >> 4, cu = tid & 15;               // this thread's (row, unit) of the cell update
+    const bool crow = bofs + cb < a.B;
+    const int br = lane >> 2, wp = lane & 3;              // this lane's (row, 4-unit group) of the partial tiles
+    const bool lrow = bofs + br < a.B;
+    float carry = 0.f;
+    for (int step = S - 1; step >= 0; --step) {
+        const int tt = d == 0 ? step : S - 1 - step;
+        const int tp = d == 0 ? tt - 1 : tt + 1;
+        const bool first = step == 0;
+        const int64_t row = (int64_t)(crow ? bofs + cb : 0) * S + tt;
+        const float dyr = bf2f(a.dy[row * 2 * H + (int64_t)d * H + u0 + cu]);
+        float actr[4];
+        {
+            const bf16_t* act = a.act + (row * 2 + d) * 4 * H + u0 + cu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) actr[q] = bf2f(act[q * H]);
+        }
+        const float cr = a.c_all[(row * 2 + d) * H + u0 + cu];
+        const float cpr = first ? 0.f : a.c_all[(((int64_t)(crow ? bofs + cb : 0) * S + tp) * 2 + d) * H + u0 + cu];
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        if (step < S - 1) {
+            // partial tiles of step + 1 addressed to this block: tag S - 1 - step, buffer (step + 1) & 1; wave w sums the
+            // sources w NT .. w NT + NT - 1
+            const uint32_t want = (uint32_t)(S - 1 - step);
+            const unsigned long long* base = llr + ((int64_t)(((step + 1) & 1) * 2 + d)) * region +
+                                             (((int64_t)blk * nblk + wave * NT) * 32 + bofs + br) * 8 + 2 * wp;
+            int polls = 0;
+            bool pending = true;
+            while (pending) {
+                u32x4 raw[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) raw[k] = ll_load16(base + (int64_t)k * 256);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < NT; ++k) asm volatile("" : "+v"(raw[k]));
+                bool ok = true;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    ok = ok && (!lrow || (raw[k][1] == want && raw[k][3] == want));
+                    part[0] += __uint_as_float(raw[k][0] << 16);
+                    part[1] += __uint_as_float(raw[k][0] & 0xffff0000u);
+                    part[2] += __uint_as_float(raw[k][2] << 16);
+                    part[3] += __uint_as_float(raw[k][2] & 0xffff0000u);
+                }
+                pending = __builtin_amdgcn_ballot_w64(!ok) != 0ull;
+                if (pending) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1 << 17)) {   // (~0.2 s: a lost word.  Report instead of hanging the device.)
+                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pending = false;
+                    }
+                }
+            }
+            if (!lrow) { part[0] = part[1] = part[2] = part[3] = 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_p[wave][br][4 * wp + e] = part[e];
+        __syncthreads();
+        if (crow) {
+            const float dh = dyr + ((s_p[0][cb][cu] + s_p[1][cb][cu]) + (s_p[2][cb][cu] + s_p[3][cb][cu]));
+            const float gi = actr[0], gf = actr[1], gg = actr[2], go = actr[3];
+            const float tc = tanhf(cr);
+            const float dc = dh * go * (1.f - tc * tc) + carry;
+            carry = dc * gf;
+            s_dg[0][cb][cu] = f2bf(dc * gg * gi * (1.f - gi));
+            s_dg[1][cb][cu] = f2bf(dc * cpr * gf * (1.f - gf));
+            s_dg[2][cb][cu] = f2bf(dc * gi * (1.f - gg * gg));
+            s_dg[3][cb][cu] = f2bf(dh * tc * go * (1.f - go));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_dg[q][cb][cu] = f2bf(0.f);
+        }
+        __syncthreads();
+        if (step > 0) {
+            // P tiles of this step: 2 MFMA k-steps each, sent as tagged words to the owners of the columns
+            const bf16x8 g0 = as_bf16x8(*reinterpret_cast<const u32x4*>(&s_dg[g4 >> 1][i15][8 * (g4 & 1)]));
+            const bf16x8 g1 = as_bf16x8(*reinterpret_cast<const u32x4*>(&s_dg[2 + (g4 >> 1)][i15][8 * (g4 & 1)]));
+            unsigned long long* out = llr + ((int64_t)((step & 1) * 2 + d)) * region +
+                                      (((int64_t)(wave * NT) * nblk + blk) * 32 + bofs + i15) * 8 + 2 * g4;
+            const unsigned long long tag = (unsigned long long)(S - step) << 32;
+            const bool live = bofs + i15 < a.B;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mfma16(wf[j][0], g0, acc);
+                acc = mfma16(wf[j][1], g1, acc);
+                if (live) {
+                    const unsigned long long w0 = (unsigned long long)pack_bf16x2(acc[0], acc[1]) | tag;
+                    const unsigned long long w1 = (unsigned long long)pack_bf16x2(acc[2], acc[3]) | tag;
+                    unsigned long long* o = out + (int64_t)j * nblk * 256;
+                    __hip_atomic_store(o, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // the plain copy of dgates_t (operand of the weight / input gradient GEMMs after the loop): one 8-byte piece per thread
+        {
+            const int gate = tid >> 6, rem = tid & 63, b = rem >> 2, partq = rem & 3;
+            if (bofs + b < a.B)
+                *reinterpret_cast<unsigned long long*>(a.dgates + ((int64_t)(bofs + b) * S + tt) * a.ldg + (int64_t)d * 4 * H +
+                                                       (int64_t)gate * H + u0 + 4 * partq) =
+                    *reinterpret_cast<const unsigned long long*>(&s_dg[gate][b][4 * partq]);
+        }
+    }
+}
+
 int g_lstm_persistent = 1;   // icka_lstm_set_persistent
 int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
 int g_lstm_bsplit = 1;       // icka_lstm_set_batch_split: batch tiles of 16 rows as separate blocks of the persistent launches
+static unsigned long long* lstm_rs_words() {   // [2 parity][2 dir][64 dest][64 src][32 rows][8 words]: 33.5 MB, allocated once
+    static unsigned long long* p = nullptr;
+    static bool tried = false;
+    if (!p && !tried) {
+        tried = true;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)cs;
+        if (hipMalloc((void**)&p, sizeof(unsigned long long) * 4 * 64 * 64 * 256) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+    }
+    return p;
+}
 static unsigned long long* lstm_ll_words() {
     static unsigned long long* p = nullptr;
     if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_ll)) != hipSuccess) p = nullptr;
@@ -741,6 +892,25 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
     a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
+    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= 256) {
+        // reduce-scatter form with tagged words (lstm_bwd_rs_kernel); the word buffer is allocated once (largest shape)
+        unsigned int* base = lstm_sync_words();
+        unsigned long long* llr = lstm_rs_words();
+        if (base && llr) {
+            hipStream_t st = (hipStream_t)stream;
+            const int nblk = H / 16;
+            if (hipMemsetAsync(llr, 0, sizeof(unsigned long long) * 4 * nblk * nblk * 256, st) != hipSuccess) return ICKA_E_ARG;
+            const dim3 grid(nblk, 2, nrt);
+            switch (H / 256) {
+                case 1: hipLaunchKernelGGL((lstm_bwd_rs_kernel<4>), grid, dim3(256), 0, st, a, llr, base + 4); break;
+                case 2: hipLaunchKernelGGL((lstm_bwd_rs_kernel<8>), grid, dim3(256), 0, st, a, llr, base + 4); break;
+                case 3: hipLaunchKernelGGL((lstm_bwd_rs_kernel<12>), grid, dim3(256), 0, st, a, llr, base + 4); break;
+                default: hipLaunchKernelGGL((lstm_bwd_rs_kernel<16>), grid, dim3(256), 0, st, a, llr, base + 4); break;
+            }
+            ICKA_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= 256) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
