@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
             const bf16x8 g1 = as_bf16x8(*reinterpret_cast<const u32x4*>(&s_dg[2 + (g4 >> 1)][i15][8 * (g4 & 1)]));
             unsigned long long* out = llr + ((int64_t)((step & 1) * 2 + d)) * region +
                                       (((int64_t)(wave * NT) * nblk + blk) * 32 + bofs + i15) * 8 + 2 * g4;
-            const unsigned long long tag = (unsigned long long)(S - step) << 32;
+            const uint32_t tagw = (uint32_t)(S - step);
             const bool live = bofs + i15 < a.B;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -700,11 +700,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
                 acc = mfma16(wf[j][0], g0, acc);
                 acc = mfma16(wf[j][1], g1, acc);
                 if (live) {
-                    const unsigned long long w0 = (unsigned long long)pack_bf16x2(acc[0], acc[1]) | tag;
-                    const unsigned long long w1 = (unsigned long long)pack_bf16x2(acc[2], acc[3]) | tag;
+                    // two tagged words in ONE 16-byte write-through store (each 8-byte word validates itself, so it does
+                    // not matter whether the 16 bytes become visible together)
+                    const u32x4 w = {pack_bf16x2(acc[0], acc[1]), tagw, pack_bf16x2(acc[2], acc[3]), tagw};
                     unsigned long long* o = out + (int64_t)j * nblk * 256;
-                    __hip_atomic_store(o, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(o + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(o), "v"(w) : "memory");
                 }
             }
         }
