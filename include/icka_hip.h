@@ -367,7 +367,8 @@ int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const flo
  * spin: the kernel then finishes with invalid data instead of hanging), -1 if the query itself failed. */
 int icka_lstm_set_persistent(int32_t on);
 /* hand-off between the blocks of a persistent launch: 1 (default) = flag-in-data 8-byte words polled by the consumers (H % 256
- * == 0 shapes; others use the ticket form), 0 = step tickets + L1 invalidate.  Same results either way. */
+ * == 0 shapes; others use the ticket form) -- forward broadcasts h_t, backward reduce-scatters bf16 partial products of
+ * dgates_t . W_hh --, 0 = step tickets + L1 invalidate.  Same forward results; backward gradients agree to bf16 rounding. */
 int icka_lstm_set_handoff(int32_t mode);
 /* 1 (default): in the forward launch with the tagged-word hand-off a batch of 17..32 rows runs as two independent tiles of
  * 16 rows (separate blocks); 0: one block per 16 hidden units holds all rows.  Same results. */
