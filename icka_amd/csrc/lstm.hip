@@ -722,14 +722,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
 int g_lstm_persistent = 1;   // icka_lstm_set_persistent
 int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
 int g_lstm_bsplit = 1;       // icka_lstm_set_batch_split: batch tiles of 16 rows as separate blocks of the persistent launches
-static unsigned long long* lstm_rs_words() {   // [2 parity][2 dir][64 dest][64 src][32 rows][8 words]: 33.5 MB, allocated once
+static unsigned long long* lstm_rs_words(hipStream_t st) {   // [2 parity][2 dir][64 dest][64 src][32 rows][8 words]: 33.5 MB, allocated once
     static unsigned long long* p = nullptr;
-    static bool tried = false;
-    if (!p && !tried) {
-        tried = true;
+    static bool failed = false;
+    if (!p && !failed) {
+        // never allocate while the stream is being captured into a graph (hipMalloc would invalidate the capture): the
+        // caller then uses the ticket form for this launch; the first eager launch allocates
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        (void)cs;
-        if (hipMalloc((void**)&p, sizeof(unsigned long long) * 4 * 64 * 64 * 256) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+        if (hipMalloc((void**)&p, sizeof(unsigned long long) * 4 * 64 * 64 * 256) != hipSuccess) { p = nullptr; failed = true; (void)hipGetLastError(); }
     }
     return p;
 }
@@ -895,7 +896,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= 256) {
         // reduce-scatter form with tagged words (lstm_bwd_rs_kernel); the word buffer is allocated once (largest shape)
         unsigned int* base = lstm_sync_words();
-        unsigned long long* llr = lstm_rs_words();
+        unsigned long long* llr = lstm_rs_words((hipStream_t)stream);
         if (base && llr) {
             hipStream_t st = (hipStream_t)stream;
             const int nblk = H / 16;
