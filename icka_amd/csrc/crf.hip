@@ -595,30 +595,52 @@ __global__ __launch_bounds__(64) void crf_grad_small_kernel(const CrfArgs a) {
 
 __global__ __launch_bounds__(64) void crf_decode_small_kernel(const CrfArgs a) {
     __shared__ unsigned char s_bp[CRF_MAX_SC];
+    __shared__ float s_e[CRF_LIN_SC];
+    __shared__ unsigned char s_on[64 * MAXW];
     __shared__ float s_fin[64];
     const int b = blockIdx.x, j = threadIdx.x, C = a.C, S = a.S;
-    int len;
-    const MaskBits mb = load_mask(a, b, j, &len);
     const bool act_lane = j < C;
     float Tc[CM];
 #pragma unroll
     for (int i = 0; i < CM; ++i) Tc[i] = (act_lane && i < C) ? a.trans[i * C + j] : -INFINITY;
     const float* eb = a.e + (int64_t)b * S * a.ld_s;
-    float score = act_lane ? a.start[j] + eb[j] : -INFINITY;
-    float en = (act_lane && S > 1) ? eb[a.ld_s + j] : 0.f;
+    // stage emissions and step flags in LDS (as the likelihood kernels: no HBM / scratch access on the S-step chain);
+    // larger S * C keep the per-step global loads
+    const bool staged = S * C <= CRF_LIN_SC;
+    int len = 0;
+    for (int t = j; t < S; t += 64) {
+        const bool raw = a.mask == nullptr || a.mask[(int64_t)b * S + t] != 0;
+        len += raw ? 1 : 0;
+        s_on[t] = (t == 0 || raw) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+    if (staged)
+        for (int idx = j; idx < S * C; idx += 64) {
+            const int t = idx / C, k = idx - t * C;
+            s_e[idx] = eb[(int64_t)t * a.ld_s + k];
+        }
+    __syncthreads();
+    float score = act_lane ? a.start[j] + (staged ? s_e[j] : eb[j]) : -INFINITY;
+    float en = (act_lane && S > 1) ? (staged ? s_e[C + j] : eb[a.ld_s + j]) : 0.f;
+    int onn = S > 1 ? s_on[1] : 0;
     for (int t = 1; t < S; ++t) {
         const float et = en;
-        if (t + 1 < S) en = act_lane ? eb[(int64_t)(t + 1) * a.ld_s + j] : 0.f;
+        const int on = onn;
+        if (t + 1 < S) {
+            en = act_lane ? (staged ? s_e[(t + 1) * C + j] : eb[(int64_t)(t + 1) * a.ld_s + j]) : 0.f;
+            onn = s_on[t + 1];
+        }
         float m = -INFINITY;
         int am = 0;
 #pragma unroll
         for (int i = 0; i < CM; ++i) {
-            const float v = __shfl(score, i, 64) + Tc[i];
+            const float v = lane_val(score, i) + Tc[i];
             if (v > m) { m = v; am = i; }
         }
         if (act_lane) {
             s_bp[t * C + j] = (unsigned char)am;
-            if (mb.on(t)) score = m + et;
+            if (on) score = m + et;
         }
     }
     s_fin[j] = act_lane ? score + a.end[j] : -INFINITY;
