@@ -43,16 +43,30 @@ __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// wave-level reductions (64 lanes)
+// wave-level reductions (64 lanes; call from wave-uniform code: every lane takes part and gets the result).
+// Rows of 16 lanes reduce on the DPP path (row_ror: 4 VALU ops, every lane of a row holds the row's result), the four rows
+// combine through lane reads.  (__shfl_xor compiles to ds_bpermute_b32 here: six dependent LDS-crossbar round trips of
+// ~100 cycles each sat between the load and the store phase of every LayerNorm row.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_f32(float v, int lane) {   // value of a (compile-time) lane as a scalar operand
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_row<0x128>(v);   // row_ror:8
+    v += dpp_row<0x124>(v);   // row_ror:4
+    v += dpp_row<0x122>(v);   // row_ror:2
+    v += dpp_row<0x121>(v);   // row_ror:1
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_row<0x128>(v));
+    v = fmaxf(v, dpp_row<0x124>(v));
+    v = fmaxf(v, dpp_row<0x122>(v));
+    v = fmaxf(v, dpp_row<0x121>(v));
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
