@@ -719,6 +719,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
     }
 }
 
+// The persistent launches wait on each other's blocks: every block of the grid must be resident at once, i.e. the grid may
+// not exceed the CUs of THIS device (256 on a whole MI355X, fewer in a partitioned mode); larger grids take one launch per step.
+static int lstm_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else { n = 1; (void)hipGetLastError(); }
+    }
+    return n;
+}
 int g_lstm_persistent = 1;   // icka_lstm_set_persistent
 int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
 int g_lstm_bsplit = 1;       // icka_lstm_set_batch_split: batch tiles of 16 rows as separate blocks of the persistent launches
@@ -831,7 +842,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
-    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 128 == 0 && (H / 16) * 2 <= 256) {
+    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 128 == 0 && (H / 16) * 2 <= lstm_cus()) {
         // flag-in-data hand-off: zero the word buffers (tags of an earlier launch), then one launch for all S steps
         unsigned int* base = lstm_sync_words();
         unsigned long long* ll = lstm_ll_words();
@@ -840,7 +851,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
         if (hipMemsetAsync(ll, 0, sizeof(unsigned long long) * 2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2), st) != hipSuccess) return ICKA_E_ARG;
         // batch rows are independent recurrences: two tiles of 16 rows run as separate blocks (grid.z) where all of them
         // are co-resident -- half the words to poll and half the MFMAs per block and step
-        const bool split = g_lstm_bsplit && nrt == 2 && (H / 16) * 2 * 2 <= 256;
+        const bool split = g_lstm_bsplit && nrt == 2 && (H / 16) * 2 * 2 <= lstm_cus();
         const dim3 grid(H / 16, 2, split ? 2 : 1);
         const int nr = split ? 1 : nrt;
 #define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, base + 4)
@@ -857,7 +868,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
         return 0;
     }
 ticket_form:
-    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= 256) {
+    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         if (!base) return ICKA_E_ARG;
@@ -893,7 +904,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
     a.B = B; a.S = S; a.H = H;
     const int nrt = (B + 15) / 16;
-    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= 256) {
+    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= lstm_cus()) {
         // reduce-scatter form with tagged words (lstm_bwd_rs_kernel); the word buffer is allocated once (largest shape)
         unsigned int* base = lstm_sync_words();
         unsigned long long* llr = lstm_rs_words((hipStream_t)stream);
@@ -912,7 +923,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
             return 0;
         }
     }
-    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= 256) {
+    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         if (!base) return ICKA_E_ARG;
