@@ -156,6 +156,7 @@ PROTOTYPES = {
     "icka_set_dropout_nonce": (c_i32, [c_vp]),
     "icka_bump_dropout_nonce": (c_i32, [c_vp, c_vp]),
     "icka_dropout_mask": (c_i32, [c_vp, c_i64, c_f32, c_u64, c_vp]),
+    "icka_attn_dropout_mask": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_u64, c_vp]),
     # ---- fp32 "exact" mode (csrc/exact.hip)
     "icka_x_gemm": (c_i32, [C.POINTER(XGemmDesc), c_vp]),
     "icka_x_ln_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64,

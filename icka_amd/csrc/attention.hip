@@ -131,14 +131,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_) {
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
+            float dm4[4];
+            drop_mul_key4(a.drop, idx_row, (uint32_t)(kv0 + 16 * kt + 4 * g), dm4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __expf(s[kt][r] - m_new);
                 psum += p;
-                const int key = kv0 + 16 * kt + 4 * g + r;
-                s[kt][r] = p * drop_mul(a.drop, idx_row + (uint32_t)key);
+                s[kt][r] = p * dm4[r];
             }
+        }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
@@ -220,11 +222,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_) {
                 s = mfma16(frag_row(sK, 16 * kt, ks, lane), qf[ks], s);
                 dp = mfma16(frag_row(sV, 16 * kt, ks, lane), dof[ks], dp);
             }
+            float dm4[4];
+            drop_mul_key4(a.drop, idx_row, (uint32_t)(kv0 + 16 * kt + 4 * g), dm4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kv0 + 16 * kt + 4 * g + r;
                 const float p = key < a.Skv ? __expf(s[r] * a.scale + mb[key] - lse_q) : 0.f;
-                dl_q += p * dp[r] * drop_mul(a.drop, idx_row + (uint32_t)key);
+                dl_q += p * dp[r] * dm4[r];
             }
         }
     }
@@ -250,12 +254,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_) {
                 s = mfma16(frag_row(sK, 16 * kt, ks, lane), qf[ks], s);
                 dp = mfma16(frag_row(sV, 16 * kt, ks, lane), dof[ks], dp);
             }
+            float dm4[4];
+            drop_mul_key4(a.drop, idx_row, (uint32_t)(kv0 + 16 * kt + 4 * g), dm4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kv0 + 16 * kt + 4 * g + r;
                 const float p = key < a.Skv ? __expf(s[r] * a.scale + mb[key] - lse_q) : 0.f;
-                const float dm = drop_mul(a.drop, idx_row + (uint32_t)key);
-                ds[kt][r] = p * (dp[r] * dm - dl_q) * a.scale;
+                ds[kt][r] = p * (dp[r] * dm4[r] - dl_q) * a.scale;
             }
         }
         bf16x8 dsf[2];
@@ -328,12 +333,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_keep_kernel(const AttnArgs
                 s = mfma16(frag_row(sK + t * TILE_B, 16 * kt, ks, lane), qf[ks], s);
                 dp = mfma16(frag_row(sV, 16 * kt, ks, lane), dof[ks], dp);
             }
-            float pv[4];
+            float pv[4], dm4[4];
+            drop_mul_key4(a.drop, idx_row, (uint32_t)(kv0 + 16 * kt + 4 * g), dm4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kv0 + 16 * kt + 4 * g + r;
                 const float p = key < a.Skv ? __expf(s[r] * a.scale + mb[key] - lse_q) : 0.f;
-                const float d = dp[r] * drop_mul(a.drop, idx_row + (uint32_t)key);
+                const float d = dp[r] * dm4[r];
                 pv[r] = p;
                 dpr[t][kt][r] = d;
                 dl_q += p * d;
@@ -431,8 +437,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_) {
             for (int r = 0; r < 4; ++r) {
                 const int ql = 16 * qt + 4 * g + r;
                 const float p = kok ? __expf(s[r] * a.scale + mk - s_lse[ql]) : 0.f;
-                const uint32_t idx = (idx_bh + (uint32_t)(q0 + ql)) * (uint32_t)a.Skv + (uint32_t)key;
-                const float dm = drop_mul(a.drop, idx);
+                const float dm = a.drop.thr ? drop_mul_key(a.drop, (idx_bh + (uint32_t)(q0 + ql)) * (uint32_t)a.Skv, (uint32_t)key) : a.drop.scale;
                 pd[qt][r] = p * dm;
                 ds[qt][r] = p * (dp[r] * dm - s_dl[ql]) * a.scale;
             }
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
     for (int qi = 0; qi < QT; ++qi) {
         const int q = q0 + 16 * (QT * wave + qi) + i15;
         const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
-        const uint32_t hx = (idx_row + 4u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;   // + (16kt + r) * C0 per element
+        const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;   // + (8 kt + r / 2) * C0 per PAIR of keys
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -578,13 +583,17 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float psum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT; ++kt) {
+            float dm4[4];
+            drop_pair_x<DROP>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0, dm4[0], dm4[1]);
+            drop_pair_x<DROP>(a.drop, hx + (uint32_t)(8 * kt + 1) * ICKA_HASH_C0, dm4[2], dm4[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __expf(s[qi][kt][r] - mx);
                 psum += pv;
-                s[qi][kt][r] = pv * drop_mul_x<DROP>(a.drop, hx + (uint32_t)(16 * kt + r) * ICKA_HASH_C0);
+                s[qi][kt][r] = pv * dm4[r];
             }
+        }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         inv[qi] = (FP8 ? 1.f / FP8_P_SCALE : 1.f) / psum;
@@ -721,13 +730,15 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
         for (int qi = 0; qi < QT; ++qi) {
             const int q = 16 * (QT * wave + qi) + i15;
             const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
-            const uint32_t hx = (idx_row + 4u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
+            const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
+            const uint32_t t16 = a.drop.thr >> 16;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int bit = (qi * KT + kt) * 4 + r;
-                    const uint32_t keep = icka_hash_tail(hx + (uint32_t)(16 * kt + r) * ICKA_HASH_C0, a.drop.s1) >= a.drop.thr ? 1u : 0u;
+                for (int rp = 0; rp < 2; ++rp) {   // one hash per pair of keys
+                    const int bit = (qi * KT + kt) * 4 + 2 * rp;
+                    const uint32_t h = icka_hash_tail(hx + (uint32_t)(8 * kt + rp) * ICKA_HASH_C0, a.drop.s1);
+                    const uint32_t keep = ((h & 0xffffu) >= t16 ? 1u : 0u) | ((h >> 16) >= t16 ? 2u : 0u);
                     dbits[bit >> 5] |= keep << (bit & 31);
                 }
         }
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
         const bf16x8 do0 = frag_row(sDO, 16 * (QT * wave + qi), 0, lane), do1 = frag_row(sDO, 16 * (QT * wave + qi), 1, lane);
         const float lse_q = s_lse[q];
         const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
-        const uint32_t hx = (idx_row + 4u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
+        const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;   // pair index base (see drop_pair)
         // P and dropout-masked dP of this query row block.  Large heads keep P bf16-packed (dS is rounded to bf16 for its
         // MFMA anyway; dP - delta, where the cancellation is, stays f32): 32 registers fewer at the 512-register cap
         f32x4 pr[MASK_LDS ? 1 : KT], dpm[KT];
@@ -760,10 +771,15 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
             f32x4 mkv;
             if constexpr (MASK_LDS) mkv = *reinterpret_cast<const f32x4*>(s_mask + 16 * kt + 4 * g);
             else mkv = mk[kt];
-            const uint32_t hk = hx + (uint32_t)(16 * kt) * ICKA_HASH_C0;
+            const uint32_t hk = hx + (uint32_t)(8 * kt) * ICKA_HASH_C0;
             // large heads run at the 512-register cap: keep hipcc from overlapping the key tiles of a row block (it hoists
             // the fragment reads, MFMAs and hashes of later tiles above the softmax of this one: +250 live registers)
             if constexpr (MASK_LDS) __builtin_amdgcn_sched_barrier(0);
+            float dm4[4];
+            if constexpr (!DROP_BITS) {
+                drop_pair_x<DROP>(a.drop, hk, dm4[0], dm4[1]);
+                drop_pair_x<DROP>(a.drop, hk + ICKA_HASH_C0, dm4[2], dm4[3]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __expf(sc[r] * a.scale + mkv[r] - lse_q);   // mask -inf (key >= Skv) -> exactly 0
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
                     const int bit = (qi * KT + kt) * 4 + r;
                     dm = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? a.drop.scale : 0.f;
                 } else {
-                    dm = drop_mul_x<DROP>(a.drop, hk + (uint32_t)r * ICKA_HASH_C0);
+                    dm = dm4[r];
                 }
                 const float dv = dp[r] * dm;
                 pvv[r] = pv;

@@ -133,6 +133,36 @@ __device__ __forceinline__ float drop_mul_x(const DropCfg& d, uint32_t x) {
     return icka_hash_tail(x, d.s1) >= d.thr ? d.scale : 0.f;
 }
 
+// Attention-probability dropout draws TWO decisions from one 32-bit hash (the whole-head attention kernels are VALU-bound
+// and a third of their backward was hashing): element (row, key) of a probability matrix whose rows start at flat index
+// idx_row = row * Skv uses hash(idx_row + key / 2) -- the low 16 bits for even keys, the high 16 bits for odd keys -- against
+// thr >> 16 (p = 0.1: 6553 / 65536).  Every site that touches an attention mask (forward, both backward layouts, the tiled
+// kernels, the fp32-mode softmax, icka_attn_dropout_mask) goes through these two functions.
+__device__ __forceinline__ void drop_pair(const DropCfg& d, uint32_t pidx, float& m_even, float& m_odd) {
+    const uint32_t h = icka_hash(d.s0, d.s1, pidx), t = d.thr >> 16;
+    m_even = (h & 0xffffu) >= t ? d.scale : 0.f;
+    m_odd = (h >> 16) >= t ? d.scale : 0.f;
+}
+// x = pidx * ICKA_HASH_C0 + s0 already formed by the caller
+template <bool DROP>
+__device__ __forceinline__ void drop_pair_x(const DropCfg& d, uint32_t x, float& m_even, float& m_odd) {
+    if (!DROP) { m_even = m_odd = 1.f; return; }
+    const uint32_t h = icka_hash_tail(x, d.s1), t = d.thr >> 16;
+    m_even = (h & 0xffffu) >= t ? d.scale : 0.f;
+    m_odd = (h >> 16) >= t ? d.scale : 0.f;
+}
+__device__ __forceinline__ float drop_mul_key(const DropCfg& d, uint32_t idx_row, uint32_t key) {
+    float e, o;
+    drop_pair(d, idx_row + (key >> 1), e, o);
+    return (key & 1u) ? o : e;
+}
+// the four in-lane keys kb .. kb + 3 (kb % 4 == 0) of an MFMA accumulator
+__device__ __forceinline__ void drop_mul_key4(const DropCfg& d, uint32_t idx_row, uint32_t kb, float (&m)[4]) {
+    if (d.thr == 0u) { m[0] = m[1] = m[2] = m[3] = d.scale; return; }
+    drop_pair(d, idx_row + (kb >> 1), m[0], m[1]);
+    drop_pair(d, idx_row + (kb >> 1) + 1u, m[2], m[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // erf-GELU (Cross_Modal_Interaction_Module.py:31-37) and its derivative.
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 grid of the outputs): one v_rcp, one v_exp

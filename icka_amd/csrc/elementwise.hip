@@ -118,6 +118,16 @@ __global__ void dropout_mask_kernel(float* out, int64_t n, DropCfg d_) {
         out[i] = drop_mul(d, (uint32_t)i);
 }
 
+// the multiplier (0 or 1/(1-p)) every attention kernel applies to element (row, key) of a probability matrix [rows, Skv]
+__global__ void attn_dropout_mask_kernel(float* out, int64_t rows, int Skv, DropCfg d_) {
+    const DropCfg d = drop_resolve(d_);
+    const int64_t n = rows * Skv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / Skv;
+        out[i] = d.thr ? drop_mul_key(d, (uint32_t)row * (uint32_t)Skv, (uint32_t)(i - row * Skv)) : d.scale;
+    }
+}
+
 // layout 1: src f32 [B, C, R] -> dst bf16 [B, R, C]; one block per (b, 64-channel strip), transposed through LDS
 __global__ __launch_bounds__(256) void regions_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B,
                                                         int R, int C) {
@@ -445,6 +455,14 @@ extern "C" int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t s
     if (!out) return ICKA_E_ARG;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       make_drop(p_drop, seed));
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_attn_dropout_mask(float* out, int64_t rows, int32_t Skv, float p_drop, uint64_t seed, void* stream) {
+    if (!out) return ICKA_E_ARG;
+    if (rows <= 0 || Skv <= 0) return 0;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(grid_for(rows * Skv)), dim3(256), 0, (hipStream_t)stream, out, rows, Skv,
                        make_drop(p_drop, seed));
     ICKA_CHECK_LAUNCH();
     return 0;

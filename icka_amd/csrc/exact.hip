@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void xsoftmax_fwd_kernel(float* __restrict__ P
     for (int j = lane; j < Skv; j += 64) {
         const float v = expf(p[j] * scale + mk[j] - mx) / se;
         p[j] = v;
-        if (Pd) Pd[(int64_t)row * Skv + j] = v * drop_mul(d, (uint32_t)row * (uint32_t)Skv + (uint32_t)j);
+        if (Pd) Pd[(int64_t)row * Skv + j] = v * (d.thr ? drop_mul_key(d, (uint32_t)row * (uint32_t)Skv, (uint32_t)j) : d.scale);
     }
 }
 // in place on dPd:  dP = dPd * mask ;  dS = P * (dP - sum_j dP*P) * scale
@@ -318,10 +318,10 @@ __global__ __launch_bounds__(256) void xsoftmax_bwd_kernel(const float* __restri
     float* g = dS + (int64_t)row * Skv;
     float dot = 0.f;
     for (int j = lane; j < Skv; j += 64)
-        dot += g[j] * drop_mul(d, (uint32_t)row * (uint32_t)Skv + (uint32_t)j) * p[j];
+        dot += g[j] * (d.thr ? drop_mul_key(d, (uint32_t)row * (uint32_t)Skv, (uint32_t)j) : d.scale) * p[j];
     dot = wave_sum(dot);
     for (int j = lane; j < Skv; j += 64) {
-        const float dp = g[j] * drop_mul(d, (uint32_t)row * (uint32_t)Skv + (uint32_t)j);
+        const float dp = g[j] * (d.thr ? drop_mul_key(d, (uint32_t)row * (uint32_t)Skv, (uint32_t)j) : d.scale);
         g[j] = p[j] * (dp - dot) * scale;
     }
 }

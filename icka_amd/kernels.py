@@ -607,6 +607,14 @@ def dropout_mask(n: int, p_drop: float, seed: int, device) -> torch.Tensor:
     return out
 
 
+def attn_dropout_mask(rows: int, Skv: int, p_drop: float, seed: int, device) -> torch.Tensor:
+    """The keep-multiplier [rows, Skv] the attention kernels apply to the probabilities (two decisions per hash: NOT
+    dropout_mask of the flat index); rows = (batch * heads + head) * Sq + query."""
+    out = torch.empty(rows, Skv, dtype=F32, device=device)
+    check(_lib.load().icka_attn_dropout_mask(out.data_ptr(), rows, Skv, p_drop, seed, _stream()), "icka_attn_dropout_mask")
+    return out
+
+
 def regions_to_tokens(src: torch.Tensor, dst: torch.Tensor, B: int, R: int, Cc: int, layout: int) -> torch.Tensor:
     _dev(src, "src")
     if src.dtype != F32 or not src.is_contiguous():

@@ -25,7 +25,7 @@ extern "C" {
 /* library / ABI version, and the code-object architecture it was built for ("gfx950") */
 /* 2: round 2 -- icka_gemm_desc grew (ab_f16, C3, ldc3, aux_f16), c_is_f32 may be 2 (fp16 output); new entry points
  * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm.
- * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split (additive). */
+ * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive). */
 #define ICKA_ABI_VERSION 3
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -416,6 +416,11 @@ int icka_set_dropout_nonce(const uint32_t* device_words);
 int icka_bump_dropout_nonce(uint32_t* device_words, void* stream);
 /* Debug/test helper: materialise the dropout keep-multiplier (0 or 1/(1-p)) for element indices [0,n) as f32. */
 int icka_dropout_mask(float* out, int64_t n, float p_drop, uint64_t seed, void* stream);
+/* The same for the attention-probability dropout of icka_attn_fwd / icka_attn_bwd (and the fp32-mode softmax): the multiplier
+ * of element (row, key) of a [rows, Skv] probability matrix, rows = (batch * heads + head) * Sq + query.  These sites draw two
+ * decisions from one 32-bit hash -- hash(row * Skv + key / 2), low 16 bits for even keys, high 16 bits for odd keys -- so
+ * their mask is NOT icka_dropout_mask of the flat index. */
+int icka_attn_dropout_mask(float* out, int64_t rows, int32_t Skv, float p_drop, uint64_t seed, void* stream);
 
 /* ===============================================================================================================
  * fp32 "exact" mode (icka_amd.set_precision(model, "fp32")): the same path in f32 storage and f32 arithmetic, for

@@ -440,7 +440,7 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
     k.additive_mask(m01, Skv, add_mask)
     assert torch.equal(add_mask, (1.0 - m01.float()) * -10000.0)
     seed = 0xabcdef12345
-    dmask = k.dropout_mask(B * h * Sq * Skv, p, seed, "cuda").view(B, h, Sq, Skv)
+    dmask = k.attn_dropout_mask(B * h * Sq, Skv, p, seed, "cuda").view(B, h, Sq, Skv)
     out = torch.empty(B * Sq, H, dtype=BF16, device="cuda")
     lse = torch.empty(B, h, Sq, dtype=F32, device="cuda")
     k.attn_fwd(q, kk, v, add_mask, out, lse, B, h, Sq, Skv, p_drop=p, seed=seed)
@@ -583,7 +583,7 @@ def test_attention_fp8_forward(B, h, Sq, Skv, p):
     q, kk, v = rnd(B * Sq, H, seed=1), rnd(B * Skv, H, seed=2), rnd(B * Skv, H, seed=3)
     add_mask = torch.zeros(B, Skv, dtype=F32, device="cuda")
     seed = 99
-    dmask = k.dropout_mask(B * h * Sq * Skv, p, seed, "cuda").view(B, h, Sq, Skv)
+    dmask = k.attn_dropout_mask(B * h * Sq, Skv, p, seed, "cuda").view(B, h, Sq, Skv)
     o8 = torch.empty(B * Sq, H, dtype=BF16, device="cuda"); o16 = torch.empty_like(o8)
     l8 = torch.empty(B, h, Sq, dtype=F32, device="cuda"); l16 = torch.empty_like(l8)
     k.attn_fwd(q, kk, v, add_mask, o8, l8, B, h, Sq, Skv, p_drop=p, seed=seed, fp8=True)
