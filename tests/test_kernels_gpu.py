@@ -417,6 +417,24 @@ def _attn_ref(q, k_, v, add_mask, dmask, B, h, Sq, Skv):
     return o.permute(0, 2, 1, 3).reshape(B * Sq, h * 64), torch.logsumexp(s, -1)
 
 
+def test_attn_dropout_mask_matches_the_numpy_restatement():
+    """icka_attn_dropout_mask (= what every attention kernel applies) against the numpy restatement of the hash in
+    tests/test_dropout_hash_cpu.py: two decisions per 32-bit hash, hash(row * Skv + key / 2), even key -> low half."""
+    import numpy as np
+    from test_dropout_hash_cpu import keep_pair
+    from icka_amd import _lib
+    k = _k()
+    lib = _lib.load()
+    lib.icka_set_dropout_nonce(None)
+    rows, Skv, p, seed = 37, 50, 0.1, 0x0123_4567_89ab_cdef
+    m = k.attn_dropout_mask(rows, Skv, p, seed, "cuda").cpu().numpy()
+    r, c = np.meshgrid(np.arange(rows, dtype=np.uint32), np.arange(Skv, dtype=np.uint32), indexing="ij")
+    even, odd = keep_pair(seed, (r * np.uint32(Skv) + (c >> np.uint32(1))).astype(np.uint32), p)
+    keep = np.where((c & 1) == 1, odd, even)
+    assert np.array_equal(m > 0, keep)
+    assert np.allclose(m[m > 0], 1.0 / (1.0 - p), rtol=1e-6)
+
+
 @pytest.mark.parametrize("B,h,Sq,Skv,p", [(2, 2, 64, 64, 0.0), (2, 12, 128, 128, 0.0), (3, 2, 100, 49, 0.0),
                                           (2, 4, 128, 36, 0.1), (2, 3, 128, 128, 0.1), (1, 2, 32, 200, 0.0),
                                           (1, 16, 256, 256, 0.1), (2, 2, 49, 128, 0.1), (1, 2, 5, 7, 0.0),
