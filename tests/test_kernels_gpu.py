@@ -422,10 +422,8 @@ def test_attn_dropout_mask_matches_the_numpy_restatement():
     tests/test_dropout_hash_cpu.py: two decisions per 32-bit hash, hash(row * Skv + key / 2), even key -> low half."""
     import numpy as np
     from test_dropout_hash_cpu import keep_pair
-    from icka_amd import _lib
     k = _k()
-    lib = _lib.load()
-    lib.icka_set_dropout_nonce(None)
+    k.set_dropout_nonce(None)   # (the restatement knows nothing of a graph's replay nonce)
     rows, Skv, p, seed = 37, 50, 0.1, 0x0123_4567_89ab_cdef
     m = k.attn_dropout_mask(rows, Skv, p, seed, "cuda").cpu().numpy()
     r, c = np.meshgrid(np.arange(rows, dtype=np.uint32), np.arange(Skv, dtype=np.uint32), indexing="ij")
