@@ -10,7 +10,9 @@ seq_len 128, per-GPU batch 32, 1 cross-attention layer, gated head, 13 labels; b
 accumulation/statistics; train mode (dropout 0.1 active); loss = token-level cross-entropy over valid tokens;
 synthetic Twitter-2015-shaped batches and seeded random-init weights (icka_amd.synth).  One step = forward +
 backward of one batch per GPU (+ RCCL gradient all-reduce when N > 1, overlapped with backward).  The optimizer
-step is outside the metric and reported separately by --with-optimizer.
+step is outside the metric and reported beside it: ``with_optimizer_ms_per_step`` = the same step
+followed by clip_grad_norm_(1.0) + AdamW.step() (the reference's update, My_cross_attention.py:831-844) with one re-cast
+of the bf16 weight shadow per step, measured over a bounded number of steps after the timed region.
 
 Rank 0 prints ONE JSON line with the contract's keys plus
   roofline      -- the dominant kernel class (the MFMA GEMMs: >= 97 % of algorithmic FLOPs): algorithmic FLOPs of the
@@ -159,6 +161,60 @@ def cpu_baseline(args, fl_sample):
                          args.seq, args.regions, args.cpu_iters, cores)}
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int, json_fd: int) -> int:
+    """`python bench.py --gpus N` without a launcher (the reference's launch line, My_cross_attention.py:1104, is
+    `python -m torch.distributed.launch --nproc_per_node=N ...`): start `python -m torch.distributed.run` with N ranks as a
+    CHILD process, pass the ranks' stderr through, write rank 0's JSON line (the only JSON object on the children's stdout)
+    to our stdout and return the launcher's exit status.  Must be called before anything in this process touches the GPU."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.pop("MASTER_PORT", None)
+    log("self-launch: %s" % " ".join(cmd))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env)   # stderr inherited: progress lines stream
+    line = None
+    try:
+        for raw in p.stdout:
+            txt = raw.decode("utf-8", "replace").rstrip("\n")
+            ok = False
+            if txt.startswith("{"):
+                try:
+                    ok = "metric" in json.loads(txt)
+                except ValueError:
+                    ok = False
+            if ok:
+                line = txt
+            elif txt:
+                print(txt, file=sys.stderr, flush=True)
+        rc = p.wait()
+    finally:
+        if p.poll() is None:     # our own child (exact PID), e.g. on KeyboardInterrupt
+            p.terminate()
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if line is not None:
+        os.write(json_fd, (line + "\n").encode())
+    elif rc == 0:
+        log("self-launch: the ranks exited with status 0 but printed no JSON line")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +245,10 @@ def main():
                          "their own): every bucket is a fork/join of the captured graph, see DESIGN.md section 6")
     ap.add_argument("--comm-f32", action="store_true", help="fp32 gradient buckets on the wire (default at N > 1: bf16)")
     ap.add_argument("--comm-bf16", action="store_true", help="force bf16 buckets (already the default at N > 1)")
-    ap.add_argument("--with-optimizer", action="store_true", help="also time fwd+bwd+AdamW (reported separately)")
+    ap.add_argument("--with-optimizer", action="store_true", help="(kept for round-1/2 command lines; the optimizer leg "
+                                                                  "now always runs unless --no-optimizer-leg)")
+    ap.add_argument("--no-optimizer-leg", action="store_true", help="skip the fwd+bwd+clip+AdamW leg")
+    ap.add_argument("--optimizer-steps", type=int, default=20, help="steps of the optimizer leg (bounded: it is a side report)")
     ap.add_argument("--shadow-always", action="store_true",
                     help="keep the library default: re-cast the bf16 weight shadow in every forward.  The bench's default is "
                          "the 'tracked' policy: the optimizer is outside the metric (SURVEY.md section 8d), so the weights do "
@@ -218,10 +277,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` started directly: become the launcher.  Nothing in this process has touched the GPU
+        # yet (no HIP call, no torch.cuda.is_available()); the N ranks are CHILD processes of a torch.distributed.run
+        # child -- never an exec of this process -- and this process relays rank 0's JSON line and the exit status.
+        sys.exit(self_launch(args.gpus, json_fd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in icka_amd)")
@@ -279,7 +340,7 @@ def main():
                               comm_dtype="f32" if args.comm_f32 else ("bf16" if (args.comm_bf16 or args.force_dist) else None))
         reducer.broadcast_parameters(0)
         arena.reducer = reducer
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-5) if args.with_optimizer else None
+    opt = None if args.no_optimizer_leg else torch.optim.AdamW(model.parameters(), lr=3e-5)
 
     def sync():
         if use_dist:
@@ -376,20 +437,33 @@ def main():
     torch.cuda.synchronize()
     shadow_cast_us = 100.0 * e0.elapsed_time(e1)
 
-    opt_ms = None
+    # ---- the optimizer beside the metric: the same step + clip_grad_norm_(1.0) + AdamW.step(), as the
+    #      reference's loop does after backward (My_cross_attention.py:831-844).  Every optimizer step is seen by the arena
+    #      (global post-step hook), so each of these steps re-casts the bf16 weight shadow once -- what the library's default
+    #      "always" policy does per forward -- and the figure prices the "tracked" policy's exclusion from the headline number.
+    opt_ms, opt_steps = None, 0
     if opt is not None:
-        for _ in range(3):
+        params = [p for p in model.parameters()]
+        opt_steps = max(1, min(args.steps, args.optimizer_steps))
+
+        def opt_step():
             if mode == "eager":
                 model.zero_grad()
-            run_step(); opt.step()
+            run_step()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+        for _ in range(3):
+            opt_step()
         sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            if mode == "eager":
-                model.zero_grad()
-            run_step(); opt.step()
+        for _ in range(opt_steps):
+            opt_step()
         sync()
-        opt_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        topt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(topt, op=dist.ReduceOp.MAX)
+        opt_ms = 1e3 * topt.item() / opt_steps
+        log("with clip + AdamW: %.3f ms/step over %d steps" % (opt_ms, opt_steps))
 
     # ---- roofline of the dominant kernel class (MFMA GEMMs), instrumented pass, rank 0 only, N = 1 semantics
     roof = None
@@ -462,7 +536,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         if opt_ms is not None:
-            out["ms_per_step_with_adamw"] = round(opt_ms, 3)
+            out["with_optimizer_ms_per_step"] = round(opt_ms, 3)
+            out["with_optimizer"] = {"update": "clip_grad_norm_(1.0) + torch.optim.AdamW(lr=3e-5).step() over %d nn.Parameters"
+                                               % len(params), "steps": opt_steps, "shadow_casts_per_step": 1,
+                                     "samples_per_s": round(args.batch * world / (opt_ms * 1e-3), 2)}
         if cpu is not None:
             out["gpu_over_cpu"] = round(samples_per_s / cpu["value"], 1)
         sys.stdout.flush()

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
-ABI_VERSION = 3   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
+ABI_VERSION = 4   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
 GEMM_NT, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -114,6 +114,9 @@ PROTOTYPES = {
     "icka_lstm_set_handoff": (c_i32, [c_i32]),
     "icka_lstm_set_batch_split": (c_i32, [c_i32]),
     "icka_lstm_barrier_error": (c_i32, []),
+    "icka_lstm_clear_error": (c_i32, []),
+    "icka_lstm_set_reserved_cus": (c_i32, [c_i32]),
+    "icka_lstm_test_hooks": (c_i32, [c_i32, c_i32]),
     "icka_linear_small_m": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "icka_transpose_bf16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_crf_llh": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -80,6 +80,7 @@ class ParamArena(object):
             else:
                 self._cast_ranges.append((lo, hi))
         self._synced = None
+        self._synced_call = -1   # id of the outermost icka forward (ArenaModule.__call__) whose shadow refresh has run
         # "always": re-cast the bf16 shadow at every outermost forward (safe with ANY way of updating parameters);
         # "tracked": re-cast only when a parameter version counter moved, an optimizer step ran (global post-step
         # hook) or mark_dirty() was called -- the caller promises not to write parameters through ``.data``
@@ -319,13 +320,27 @@ def _collect(module: nn.Module, prefix: str):
 
 
 _FWD_DEPTH = [0]   # nesting depth of ArenaModule forwards (one Python thread per process)
+_CALL_ID = [0]     # bumped whenever an OUTERMOST ArenaModule forward starts
+
+
+def refresh_shadow_once(A: "ParamArena") -> None:
+    """The shadow refresh of the current outermost icka forward: ``A.sync()`` exactly once per outermost call and arena,
+    at whatever depth the first kernel-owning module of the call tree sits (a container such as BertAttention, whose own
+    forward launches nothing, leaves it to its children; a trunk function and the BertModel it calls share one).  Outside
+    any ArenaModule forward (free functions such as scalar_gate_fusion called on their own) every call refreshes."""
+    if _FWD_DEPTH[0] == 0 or A._synced_call != _CALL_ID[0] or A._synced is None:
+        A.sync()
+        A._synced_call = _CALL_ID[0]
 
 
 class ArenaModule(nn.Module):
     """Base of every icka module that owns parameters read by kernels.  ``_arena()`` returns the (shared) ParamArena
-    and, in the OUTERMOST icka forward of a call tree only, refreshes the bf16 shadow (ParamArena.sync)."""
+    and, ONCE per outermost icka forward of a call tree, refreshes the bf16 shadow (ParamArena.sync; with the "tracked"
+    policy the version / optimizer-step fingerprint decides whether anything is cast)."""
 
     def __call__(self, *args, **kwargs):
+        if _FWD_DEPTH[0] == 0:
+            _CALL_ID[0] += 1
         _FWD_DEPTH[0] += 1
         try:
             return super().__call__(*args, **kwargs)
@@ -337,8 +352,7 @@ class ArenaModule(nn.Module):
         if A.device.type != "cuda":
             raise RuntimeError("%s: parameters are on %s; move the module to a ROCm device (icka_amd has no CPU "
                                "path)" % (type(self).__name__, A.device))
-        if _FWD_DEPTH[0] <= 1 or A._synced is None:
-            A.sync()
+        refresh_shadow_once(A)
         return A
 
 

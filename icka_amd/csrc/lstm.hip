@@ -29,6 +29,8 @@ struct LstmArgs {
     bf16_t* dgates;                    // [B*S, 8H] gate pre-activation gradients
     float* dc_carry;                   // [2, B, H] dc_{t+1} * f_{t+1}
     int B, S, H, step;
+    int poll_limit;                    // persistent forms: polls before a hand-off wait gives up (error word + NaN poison)
+    int test_drop;                     // test hook (icka_lstm_test_hooks): block (0, 0, 0) does not publish this step; -1 = off
 };
 
 // 16-byte fragment of a k-contiguous row (8 bf16); zero when the row is invalid
@@ -222,17 +224,30 @@ typedef __attribute__((address_space(1))) unsigned long long gu64_t;
 __device__ __forceinline__ void lstm_store_wt(void* p, unsigned long long v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void lstm_grid_wait(unsigned int* ctr, unsigned int target, unsigned int* err) {
+// A wait that gives up (a peer block that is not resident, a lost word) must not pass for a result: it raises the error
+// word -- host-visible memory when the library could map it (lstm_err_word), so the host reads it without a device
+// synchronisation -- and POISONS the recurrence: the waiting block continues with NaN operands, which reach every later
+// step of every block through h / dgates, so y, the loss and the gradients of the call are NaN.  Once poisoned a block no
+// longer spins (a failed launch costs one time-out, not one per step).
+__device__ __forceinline__ void lstm_raise(unsigned int* err) {
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float lstm_nan() { return __uint_as_float(0x7fc00000u); }
+// returns true (to every thread of the block) when the block is poisoned; ``s_poison`` is a __shared__ word zeroed at kernel start
+__device__ __forceinline__ bool lstm_grid_wait(unsigned int* ctr, unsigned int target, unsigned int* err, int limit,
+                                               int* s_poison) {
     if (threadIdx.x == 0) {
         int polls = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++polls > (1 << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
+        if (*s_poison == 0)
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > limit) { lstm_raise(err); *s_poison = 1; break; }
+            }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    return *s_poison != 0;
 }
 __device__ __forceinline__ void lstm_grid_signal(unsigned int* ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
@@ -244,10 +259,13 @@ template <int NRT, int KS>
 __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs a, const LstmPersist ps) {
     __shared__ float s_g[4][NRT * 16][17];
     __shared__ __attribute__((aligned(16))) bf16_t s_h[NRT * 16][16];
+    __shared__ int s_poison;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
     const int i15 = lane & 15, g4 = lane >> 4;
     const unsigned int nblk = gridDim.x;
+    if (tid == 0) s_poison = 0;
+    __syncthreads();
     bf16x8 wf[KS];   // this wave's gate rows of W_hh, resident for the whole sequence
     {
         const bf16_t* wrow = a.whh + ((int64_t)d * 4 * H + (int64_t)wave * H + u0 + i15) * H + 8 * g4;
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs
 #pragma unroll
         for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            lstm_grid_wait(ps.tickets + d, (unsigned)step * nblk, ps.err);
+            const bool bad = lstm_grid_wait(ps.tickets + d, (unsigned)step * nblk, ps.err, a.poll_limit, &s_poison);
             const bf16_t* hbase = a.y + (int64_t)tp * 2 * H + (int64_t)d * H + 8 * g4;
             bf16x8 hf[NRT][KS];
 #pragma unroll
@@ -286,6 +304,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs
             for (int u = 0; u < KS; ++u)
 #pragma unroll
                 for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], hf[r][u], acc[r]);
+            if (bad) {
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = f32x4{lstm_nan(), lstm_nan(), lstm_nan(), lstm_nan()};
+            }
         }
         __syncthreads();   // s_g of the previous step fully consumed
 #pragma unroll
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs
                 lstm_store_wt(a.y + ((int64_t)b * S + tt) * 2 * H + (int64_t)d * H + u0 + 4 * part,
                               *reinterpret_cast<const unsigned long long*>(&s_h[b][4 * part]));
         }
-        if (step + 1 < S) lstm_grid_signal(ps.tickets + d);
+        if (step + 1 < S && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0)) lstm_grid_signal(ps.tickets + d);
     }
 }
 
@@ -362,6 +384,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
     float creg[NRT];
 #pragma unroll
     for (int i = 0; i < NRT; ++i) creg[i] = 0.f;
+    bool poison = false;   // wave-uniform: a wait of this wave gave up (lstm_raise); NaN operands from then on, no more spinning
     for (int step = 0; step < S; ++step) {
         const int tt = d == 0 ? step : S - 1 - step;
         float gxr[NRT][4];
@@ -383,8 +406,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
                                              ((kq0 + 8 * g4) >> 1);
             const uint32_t want = (uint32_t)step;
             bf16x8 hf[NRT][KQ];
-            int polls = 0;
-            {   // cheap poll first: the last word (row B-1, units 14..15) of each producer block of this wave's quarter -- a
+            int polls = poison ? a.poll_limit : 0;
+            if (!poison) {   // cheap poll first: the last word (row B-1, units 14..15) of each producer block of this wave's quarter -- a
                 // hint only (words become visible in any order); the full load below checks every tag
                 const int nsrc = H >> 6;   // (H / 4) / 16 producer blocks
                 const int blast = (a.B < bofs + 16 * NRT ? a.B : bofs + 16 * NRT) - 1;
@@ -393,7 +416,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
                     const unsigned long long v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_ballot_w64((uint32_t)(v >> 32) != want) == 0ull) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > (1 << 20)) break;   // (the full check below reports it)
+                    if (++polls > a.poll_limit) break;   // (the full check below reports it)
                 }
             }
             bool pending = true;
@@ -432,9 +455,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
                 pending = __builtin_amdgcn_ballot_w64(!ok) != 0ull;
                 if (pending) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > (1 << 20)) {
-                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++polls > a.poll_limit) {
+                        if (lane == 0) lstm_raise(err);
                         pending = false;
+                        poison = true;
                     }
                 }
             }
@@ -444,6 +468,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
                 for (int r = 0; r < NRT; ++r)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[r][q] = mfma16(wf[q][u], hf[r][u], acc[r][q]);
+            if (poison) {
+#pragma unroll
+                for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r][q] = f32x4{lstm_nan(), lstm_nan(), lstm_nan(), lstm_nan()};
+            }
         }
         __syncthreads();   // s_g / s_h of the previous step fully consumed
 #pragma unroll
@@ -468,7 +498,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_ll_kernel(const LstmArgs a, unsi
         }
         __syncthreads();
         // publish h_t first: 2 units + tag per 8-byte word, write-through
-        if (step + 1 < S) {
+        if (step + 1 < S && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)) {
             unsigned long long* out = g_lstm_ll + ((int64_t)((step & 1) * 2 + d) * LSTM_LL_ROWS) * (LSTM_LL_MAXH / 2) + (u0 >> 1);
             for (int p = tid; p < NRT * 16 * 8; p += 256) {
                 const int b = p >> 3, j = p & 7;
@@ -498,10 +528,13 @@ template <int NRT, int KS>
 __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs a, const LstmPersist ps) {
     __shared__ float s_p[4][NRT * 16][17];
     __shared__ __attribute__((aligned(16))) bf16_t s_dg[4][NRT * 16][16];
+    __shared__ int s_poison;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = blockIdx.y, u0 = blockIdx.x * 16, H = a.H, S = a.S;
     const int i15 = lane & 15, g4 = lane >> 4;
     const unsigned int nblk = gridDim.x;
+    if (tid == 0) s_poison = 0;
+    __syncthreads();
     bf16x8 wf[KS];   // rows u0.. of W_hh^T, this wave's quarter of the 4H reduction
     {
         const bf16_t* wrow = a.whh + ((int64_t)d * H + u0 + i15) * 4 * H + (int64_t)wave * H + 8 * g4;
@@ -533,7 +566,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
 #pragma unroll
         for (int r = 0; r < NRT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (step < S - 1) {
-            lstm_grid_wait(ps.tickets + d, (unsigned)(S - 1 - step) * nblk, ps.err);
+            const bool bad = lstm_grid_wait(ps.tickets + d, (unsigned)(S - 1 - step) * nblk, ps.err, a.poll_limit, &s_poison);
             const bf16_t* gbase = a.dgates + (int64_t)tn * a.ldg + (int64_t)d * 4 * H + (int64_t)wave * H + 8 * g4;
             bf16x8 gf[NRT][KS];
 #pragma unroll
@@ -547,6 +580,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
             for (int u = 0; u < KS; ++u)
 #pragma unroll
                 for (int r = 0; r < NRT; ++r) acc[r] = mfma16(wf[u], gf[r][u], acc[r]);
+            if (bad) {
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = f32x4{lstm_nan(), lstm_nan(), lstm_nan(), lstm_nan()};
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -578,7 +615,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
                                   4 * part,
                               *reinterpret_cast<const unsigned long long*>(&s_dg[gate][b][4 * part]));
         }
-        if (step > 0) lstm_grid_signal(ps.tickets + d);
+        if (step > 0 && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0)) lstm_grid_signal(ps.tickets + d);
     }
 }
 
@@ -616,6 +653,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
     const int br = lane >> 2, wp = lane & 3;              // this lane's (row, 4-unit group) of the partial tiles
     const bool lrow = bofs + br < a.B;
     float carry = 0.f;
+    bool poison = false;   // wave-uniform, as in lstm_fwd_ll_kernel
     for (int step = S - 1; step >= 0; --step) {
         const int tt = d == 0 ? step : S - 1 - step;
         const int tp = d == 0 ? tt - 1 : tt + 1;
@@ -637,7 +675,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
             const uint32_t want = (uint32_t)(S - 1 - step);
             const unsigned long long* base = llr + ((int64_t)(((step + 1) & 1) * 2 + d)) * region +
                                              (((int64_t)blk * nblk + wave * NT) * 32 + bofs + br) * 8 + 2 * wp;
-            int polls = 0;
+            int polls = poison ? a.poll_limit : 0;
             bool pending = true;
             while (pending) {
                 u32x4 raw[NT];
@@ -660,13 +698,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
                 pending = __builtin_amdgcn_ballot_w64(!ok) != 0ull;
                 if (pending) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > (1 << 17)) {   // (~0.2 s: a lost word.  Report instead of hanging the device.)
-                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++polls > a.poll_limit) {   // (default 2^17 ~ 0.2 s: a lost word.  Report + poison instead of hanging the device.)
+                        if (lane == 0) lstm_raise(err);
                         pending = false;
+                        poison = true;
                     }
                 }
             }
             if (!lrow) { part[0] = part[1] = part[2] = part[3] = 0.f; }
+            if (poison) { part[0] = part[1] = part[2] = part[3] = lstm_nan(); }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) s_p[wave][br][4 * wp + e] = part[e];
@@ -686,7 +726,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
             for (int q = 0; q < 4; ++q) s_dg[q][cb][cu] = f2bf(0.f);
         }
         __syncthreads();
-        if (step > 0) {
+        if (step > 0 && !(a.test_drop == step && blk == 0 && d == 0 && blockIdx.z == 0)) {
             // P tiles of this step: 2 MFMA k-steps each, sent as tagged words to the owners of the columns
             const bf16x8 g0 = as_bf16x8(*reinterpret_cast<const u32x4*>(&s_dg[g4 >> 1][i15][8 * (g4 & 1)]));
             const bf16x8 g1 = as_bf16x8(*reinterpret_cast<const u32x4*>(&s_dg[2 + (g4 >> 1)][i15][8 * (g4 & 1)]));
@@ -721,6 +761,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
 
 // The persistent launches wait on each other's blocks: every block of the grid must be resident at once, i.e. the grid may
 // not exceed the CUs of THIS device (256 on a whole MI355X, fewer in a partitioned mode); larger grids take one launch per step.
+// icka_lstm_set_reserved_cus: CUs kept free of persistent LSTM blocks.  A block of these kernels holds 352 of a SIMD's 512
+// registers per lane (one wave per SIMD), so a CU on which another kernel's workgroup already occupies more than 160
+// registers per lane of some SIMD -- an RCCL all-reduce workgroup on the communication stream of a data-parallel step
+// (dp.GradReducer) -- cannot take one until that workgroup exits: the grid is no longer co-resident by construction and
+// its blocks would spin on a peer that has not started.  The reducer reserves as many CUs as RCCL runs channels.
+int g_lstm_reserved_cus = 0;
 static int lstm_cus() {
     static int n = 0;
     if (n == 0) {
@@ -728,7 +774,8 @@ static int lstm_cus() {
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
         else { n = 1; (void)hipGetLastError(); }
     }
-    return n;
+    const int avail = n - g_lstm_reserved_cus;
+    return avail > 0 ? avail : 0;
 }
 int g_lstm_persistent = 1;   // icka_lstm_set_persistent
 int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
@@ -750,12 +797,45 @@ static unsigned long long* lstm_ll_words() {
     if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_ll)) != hipSuccess) p = nullptr;
     return p;
 }
-__device__ unsigned int g_lstm_sync[8];   // [0..1] tickets per direction (2..3 spare), [4] error word
+__device__ unsigned int g_lstm_sync[8];   // [0..1] tickets per direction (2..3 spare), [4] error word (fallback, see lstm_err_word)
 static unsigned int* lstm_sync_words() {   // address looked up once (not a stream operation: safe under graph capture)
     static unsigned int* p = nullptr;
     if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_lstm_sync)) != hipSuccess) p = nullptr;
     return p;
 }
+// The error word of the persistent recurrences lives in HOST memory mapped into the device (a kernel raises it with one
+// system-scope store, lstm_raise; the host reads it as plain memory: icka_lstm_barrier_error costs no device
+// synchronisation and may be polled at every host touch-point).  Allocated on the first call that is not inside a stream
+// capture; until then (and if the mapping fails) the device word g_lstm_sync[4] is used and read back with a memcpy.
+static volatile unsigned int* g_lstm_err_host = nullptr;
+static unsigned int* g_lstm_err_dev = nullptr;
+static bool g_lstm_fallback_used = false;   // a launch was given the device word g_lstm_sync[4] as its error word
+static unsigned int* lstm_err_word(hipStream_t st) {
+    if (g_lstm_err_dev) return g_lstm_err_dev;
+    static bool failed = false;
+    if (!failed) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = st != nullptr && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone);
+        if (!capturing) {
+            void* h = nullptr;
+            void* d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+                *reinterpret_cast<volatile unsigned int*>(h) = 0u;
+                g_lstm_err_host = reinterpret_cast<volatile unsigned int*>(h);
+                g_lstm_err_dev = reinterpret_cast<unsigned int*>(d);
+                return g_lstm_err_dev;
+            }
+            failed = true;
+            (void)hipGetLastError();
+        }
+    }
+    unsigned int* base = lstm_sync_words();
+    g_lstm_fallback_used = true;
+    return base ? base + 4 : nullptr;
+}
+int g_lstm_poll_limit = 0;    // icka_lstm_test_hooks: 0 = the per-form defaults below
+int g_lstm_test_drop = -1;    // icka_lstm_test_hooks
+static int lstm_poll_limit(int dflt) { return g_lstm_poll_limit > 0 ? g_lstm_poll_limit : dflt; }
 
 // W^T for both directions: in [2][R][C] -> out [2][C][R] (bf16), 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
@@ -841,20 +921,22 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     LstmArgs a{};
     a.gx = gates_x; a.ldg = ldg; a.whh = (const bf16_t*)w_hh; a.y = (bf16_t*)y; a.c_all = c_all;
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
+    a.test_drop = g_lstm_test_drop;
     const int nrt = (B + 15) / 16;
     if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 128 == 0 && (H / 16) * 2 <= lstm_cus()) {
         // flag-in-data hand-off: zero the word buffers (tags of an earlier launch), then one launch for all S steps
-        unsigned int* base = lstm_sync_words();
-        unsigned long long* ll = lstm_ll_words();
-        if (!base || !ll) return ICKA_E_ARG;
         hipStream_t st = (hipStream_t)stream;
+        unsigned int* errw = lstm_err_word(st);
+        unsigned long long* ll = lstm_ll_words();
+        if (!errw || !ll) return ICKA_E_ARG;
+        a.poll_limit = lstm_poll_limit(1 << 20);
         if (hipMemsetAsync(ll, 0, sizeof(unsigned long long) * 2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2), st) != hipSuccess) return ICKA_E_ARG;
         // batch rows are independent recurrences: two tiles of 16 rows run as separate blocks (grid.z) where all of them
         // are co-resident -- half the words to poll and half the MFMAs per block and step
         const bool split = g_lstm_bsplit && nrt == 2 && (H / 16) * 2 * 2 <= lstm_cus();
         const dim3 grid(H / 16, 2, split ? 2 : 1);
         const int nr = split ? 1 : nrt;
-#define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, base + 4)
+#define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, errw)
         switch (H / 128) {
             case 2: if (nr == 1) ICKA_LL_FWD(1, 2); else ICKA_LL_FWD(2, 2); break;
             case 4: if (nr == 1) ICKA_LL_FWD(1, 4); else ICKA_LL_FWD(2, 4); break;
@@ -871,8 +953,10 @@ ticket_form:
     if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
-        if (!base) return ICKA_E_ARG;
-        ps.tickets = base; ps.err = base + 4;
+        unsigned int* errw = lstm_err_word((hipStream_t)stream);
+        if (!base || !errw) return ICKA_E_ARG;
+        ps.tickets = base; ps.err = errw;
+        a.poll_limit = lstm_poll_limit(1 << 22);
         if (hipMemsetAsync(base, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
         // KS = resident W_hh fragments per wave (32 hidden units each): 24 up to H = 768, 32 up to H = 1024
         if (H > 768) {
@@ -903,21 +987,23 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.dy = (const bf16_t*)dy; a.whh = (const bf16_t*)w_hh_t; a.act = (bf16_t*)const_cast<void*>(act);
     a.c_all = const_cast<float*>(c_all); a.dgates = (bf16_t*)dgates; a.ldg = ldg; a.dc_carry = dc_carry;
     a.B = B; a.S = S; a.H = H;
+    a.test_drop = g_lstm_test_drop;
     const int nrt = (B + 15) / 16;
     if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= lstm_cus()) {
         // reduce-scatter form with tagged words (lstm_bwd_rs_kernel); the word buffer is allocated once (largest shape)
-        unsigned int* base = lstm_sync_words();
+        unsigned int* errw = lstm_err_word((hipStream_t)stream);
         unsigned long long* llr = lstm_rs_words((hipStream_t)stream);
-        if (base && llr) {
+        if (errw && llr) {
             hipStream_t st = (hipStream_t)stream;
+            a.poll_limit = lstm_poll_limit(1 << 17);
             const int nblk = H / 16;
             if (hipMemsetAsync(llr, 0, sizeof(unsigned long long) * 4 * nblk * nblk * 256, st) != hipSuccess) return ICKA_E_ARG;
             const dim3 grid(nblk, 2, nrt);
             switch (H / 256) {
-                case 1: hipLaunchKernelGGL((lstm_bwd_rs_kernel<4>), grid, dim3(256), 0, st, a, llr, base + 4); break;
-                case 2: hipLaunchKernelGGL((lstm_bwd_rs_kernel<8>), grid, dim3(256), 0, st, a, llr, base + 4); break;
-                case 3: hipLaunchKernelGGL((lstm_bwd_rs_kernel<12>), grid, dim3(256), 0, st, a, llr, base + 4); break;
-                default: hipLaunchKernelGGL((lstm_bwd_rs_kernel<16>), grid, dim3(256), 0, st, a, llr, base + 4); break;
+                case 1: hipLaunchKernelGGL((lstm_bwd_rs_kernel<4>), grid, dim3(256), 0, st, a, llr, errw); break;
+                case 2: hipLaunchKernelGGL((lstm_bwd_rs_kernel<8>), grid, dim3(256), 0, st, a, llr, errw); break;
+                case 3: hipLaunchKernelGGL((lstm_bwd_rs_kernel<12>), grid, dim3(256), 0, st, a, llr, errw); break;
+                default: hipLaunchKernelGGL((lstm_bwd_rs_kernel<16>), grid, dim3(256), 0, st, a, llr, errw); break;
             }
             ICKA_CHECK_LAUNCH();
             return 0;
@@ -926,8 +1012,10 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
-        if (!base) return ICKA_E_ARG;
-        ps.tickets = base; ps.err = base + 4;
+        unsigned int* errw = lstm_err_word((hipStream_t)stream);
+        if (!base || !errw) return ICKA_E_ARG;
+        ps.tickets = base; ps.err = errw;
+        a.poll_limit = lstm_poll_limit(1 << 22);
         if (hipMemsetAsync(base, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
         // (batch tiles as separate blocks, as in the forward launch, are slower here: 9.3 vs 8.9 us per step at H = 768 --
         //  every block reads all of dgates_t through L2 either way, twice the blocks only add contention)
@@ -986,9 +1074,33 @@ extern "C" int icka_lstm_set_persistent(int32_t on) {
     g_lstm_persistent = on ? 1 : 0;
     return 0;
 }
-/* 1 if a grid barrier of the persistent recurrence ever gave up waiting (results of that call are invalid). */
+/* 1 if a hand-off wait of a persistent recurrence ever gave up (the outputs of that call are NaN-poisoned).  Reads the
+   host-mapped error word when there is one (mapped by the first persistent launch issued outside a stream capture) -- a plain
+   host read, no runtime call; only launches that had to take the fallback device word cost a blocking copy here. */
 extern "C" int icka_lstm_barrier_error(void) {
-    unsigned int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_lstm_sync), sizeof(v)) != hipSuccess) return -1;
-    return (int)v[4];
+    if (g_lstm_err_host) return (int)*g_lstm_err_host;
+    if (!g_lstm_fallback_used) return 0;   // no persistent launch has raised into the device word: nothing to read (and no
+                                           // runtime call from here, so the query is legal inside a stream capture)
+    unsigned int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_lstm_sync), sizeof(w)) != hipSuccess) return -1;
+    return (int)w[4];
+}
+/* Reset the error word(s) after the caller has handled (raised) the error. */
+extern "C" int icka_lstm_clear_error(void) {
+    if (g_lstm_err_host) *g_lstm_err_host = 0u;
+    unsigned int* base = lstm_sync_words();
+    if (base && hipMemset(base + 4, 0, sizeof(unsigned int)) != hipSuccess) return ICKA_E_ARG;
+    return 0;
+}
+extern "C" int icka_lstm_set_reserved_cus(int32_t n) {
+    if (n < 0) return ICKA_E_ARG;
+    g_lstm_reserved_cus = n;
+    return 0;
+}
+/* Test hooks of the give-up path: poll_limit > 0 replaces the per-form poll budgets (0 restores them); drop_step >= 0 makes
+   block (0, direction 0, batch tile 0) of the persistent launches skip publishing that step, so its consumers time out. */
+extern "C" int icka_lstm_test_hooks(int32_t poll_limit, int32_t drop_step) {
+    g_lstm_poll_limit = poll_limit > 0 ? poll_limit : 0;
+    g_lstm_test_drop = drop_step >= 0 ? drop_step : -1;
+    return 0;
 }

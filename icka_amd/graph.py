@@ -64,6 +64,9 @@ class GraphedStep(object):
             raise RuntimeError("GraphedStep is closed")
         if self.arena.shadow_policy != "always":   # "always": the cast is a node of the captured forward
             self.arena.sync()
+        # a persistent LSTM launch of an EARLIER replay that gave up a hand-off (NaN-poisoned outputs): raise at this host
+        # touch-point (a host read of a mapped word, no synchronisation)
+        K.lstm_check_error("detected before a GraphedStep replay")
         self.graph.replay()
         self.arena.attach_grads(self._grad_slots)   # replay runs no Python: p.grad may have been dropped by zero_grad
         return self.loss
@@ -153,6 +156,7 @@ class SegmentedStep(object):
             raise RuntimeError("SegmentedStep is closed")
         if self.arena.shadow_policy != "always":
             self.arena.sync()
+        K.lstm_check_error("detected before a SegmentedStep replay")
         for graph, buckets in self.segments:
             graph.replay()
             for bi in buckets:

@@ -468,6 +468,30 @@ def lstm_bwd(dy, w_hh_t, act, c_all, dgates, dc_carry, B, S, H):
           "icka_lstm_bwd")
 
 
+class LstmHandoffError(RuntimeError):
+    """A hand-off wait of a persistent LSTM launch gave up: the outputs of that call are NaN-poisoned."""
+
+
+def lstm_check_error(where: str = "") -> None:
+    """Raise if a persistent LSTM launch ever reported a failed hand-off (icka_hip.h: icka_lstm_barrier_error).  The error
+    word is host-mapped memory: the check is a plain host read, no device synchronisation, so it runs at every host
+    touch-point (BiLSTM.forward, GraphedStep / SegmentedStep replays).  The word is cleared when the error is raised."""
+    lib = _lib.load()
+    rc = lib.icka_lstm_barrier_error()
+    if rc != 0:
+        lib.icka_lstm_clear_error()
+        raise LstmHandoffError(
+            "icka_amd BiLSTM%s: a block of a persistent LSTM launch gave up waiting for another block's words (status %d): "
+            "the grid was not co-resident (another kernel held its CUs, e.g. a collective on the communication stream, or "
+            "the GPU is partitioned / shared).  The outputs and gradients of that call are NaN.  Reserve CUs "
+            "(icka_lstm_set_reserved_cus) or take the per-step launches (icka_lstm_set_persistent(0))."
+            % ((" (" + where + ")") if where else "", rc))
+
+
+def lstm_set_reserved_cus(n: int) -> None:
+    check(_lib.load().icka_lstm_set_reserved_cus(int(n)), "icka_lstm_set_reserved_cus")
+
+
 def linear_small_m(x, W, bias, y, act: int = 0):
     """y bf16 [M<=64, N] = act(x . W^T + bias); x may be a strided row view (the pooler's first-token rows)."""
     _mat(x, "x"); _mat(W, "W"); _mat(y, "y")

@@ -120,6 +120,9 @@ class BiLSTM(ArenaModule):
         from .modeling import _hidden2d, _is_exact
         A = self._arena()
         H = self.hidden_size
+        # host touch-point: a failed hand-off of an EARLIER persistent launch (its outputs are NaN-poisoned) is raised here;
+        # the check is a host read of a mapped word -- no device synchronisation, legal inside a stream capture
+        K.lstm_check_error("detected at the next BiLSTM.forward")
         if _is_exact(self):     # fp32 mode: f32 in / out, per-step f32 GEMMs (icka_amd/exact.py)
             from . import exact as X
             y, c_all = X.LstmFn.apply(A.anchor, _hidden2d(x, "input", True), self, A, B, S)

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import exact as X
 from . import kernels as K
 from . import ops
-from .arena import ArenaModule, ParamArena, arena_of
+from .arena import ArenaModule, ParamArena, arena_of, refresh_shadow_once
 from .config import BertConfig, check_config, check_head_size_bf16
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -487,7 +487,7 @@ def scalar_gate_fusion(owner: nn.Module, cross_output_layer: torch.Tensor, token
     returns g*token_embedding + (1-g)*cross_output_layer  ([B,S,H] bf16).  ``token_embedding`` comes from the
     out-of-scope RoBERTa stage and is an input here."""
     A = arena_of(owner)
-    A.sync()
+    refresh_shadow_once(A)      # once per outermost forward (every call when used as a free function)
     B, S, H = cross_output_layer.shape
     if _is_exact(owner):
         cross = _hidden2d(cross_output_layer, "cross_output_layer", True)

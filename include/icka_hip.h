@@ -25,8 +25,10 @@ extern "C" {
 /* library / ABI version, and the code-object architecture it was built for ("gfx950") */
 /* 2: round 2 -- icka_gemm_desc grew (ab_f16, C3, ldc3, aux_f16), c_is_f32 may be 2 (fp16 output); new entry points
  * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm.
- * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive). */
-#define ICKA_ABI_VERSION 3
+ * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive).
+ * 4: round 3 -- icka_lstm_clear_error, icka_lstm_set_reserved_cus, icka_lstm_test_hooks; a hand-off wait that gives up now
+ *    NaN-poisons the recurrence and raises a host-visible error word (additive). */
+#define ICKA_ABI_VERSION 4
 int icka_abi_version(void);
 const char* icka_build_arch(void);
 
@@ -373,7 +375,24 @@ int icka_lstm_set_handoff(int32_t mode);
 /* 1 (default): in the forward launch with the tagged-word hand-off a batch of 17..32 rows runs as two independent tiles of
  * 16 rows (separate blocks); 0: one block per 16 hidden units holds all rows.  Same results. */
 int icka_lstm_set_batch_split(int32_t on);
+/* The persistent launches wait on words written by other blocks of the same grid, with a bounded spin.  A wait that gives
+ * up (a peer block that never became resident, a lost word) raises a sticky error word AND poisons the recurrence: the
+ * waiting block continues with NaN operands, so every later step of every block -- y, the loss, every gradient of the
+ * call -- is NaN: a failed launch never passes for a result.  icka_lstm_barrier_error() returns 1 once that has happened,
+ * 0 otherwise, -1 if the query itself failed; the word lives in host memory mapped into the device, so the query costs no
+ * device synchronisation and the host side (icka_amd/lstm.py, icka_amd/graph.py) polls it at every touch-point and raises.
+ * icka_lstm_clear_error() resets it.  (The reference's nn.LSTM, Cross_Modal_Interaction_Module.py:905-908 / :1042, cannot
+ * fail this way; this is the price of the one-launch recurrence.) */
 int icka_lstm_barrier_error(void);
+int icka_lstm_clear_error(void);
+/* CUs to keep free of persistent LSTM blocks (default 0): the persistent forms are used only when their grid fits into the
+ * device's CUs minus this reserve, else the one-launch-per-step form runs.  dp.GradReducer reserves the CUs RCCL's
+ * all-reduce workgroups may occupy on the communication stream while the recurrence runs. */
+int icka_lstm_set_reserved_cus(int32_t n);
+/* Test hooks of the give-up path (tests/test_lstm_gpu.py): poll_limit > 0 replaces the poll budgets of all persistent
+ * forms (0 restores the defaults); drop_step >= 0 makes block (0, direction 0, batch tile 0) skip publishing that step so
+ * that its consumers time out (-1: off). */
+int icka_lstm_test_hooks(int32_t poll_limit, int32_t drop_step);
 /* y bf16 [M <= 64, N] = act(x . W^T + bias) for a handful of rows (BertPooler.forward :675-681: tanh(dense(h[:, 0])),
  * 32 rows at c2): x bf16 rows with stride ldx, W bf16 [N,K], K % 128 == 0; act 0 = none, 1 = tanh. */
 int icka_linear_small_m(const void* x, int64_t ldx, const void* W, const float* bias, void* y, int64_t ldy, int32_t M,

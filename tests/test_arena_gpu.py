@@ -163,3 +163,54 @@ def test_mixed16_graphed_training_loop_matches_eager_and_refreshes_both_shadows(
     assert seqs[0][-1] < seqs[0][0]
     for a, b in zip(*seqs):
         assert abs(a - b) < 2e-3 * max(1.0, abs(a)), seqs
+
+
+def test_standalone_container_block_sees_weight_updates_between_calls():
+    """BertAttention / BertCrossAttention launch nothing themselves; when one of them is the OUTERMOST call its
+    children run at nesting depth 2 and must still refresh the bf16 shadow on every outermost call (default policy), or
+    after an optimizer step / in-place update (tracked policy): a second forward after a weight update must change."""
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import BertAttention
+    cfg = BertConfig(512, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256)
+    att = BertAttention(cfg)
+    synth.fill_module_(att)
+    att = att.cuda().eval()
+    x = (torch.randn(2, 16, 128, generator=torch.Generator().manual_seed(0)) * 0.5).cuda().to(torch.bfloat16)
+    mask = torch.zeros(2, 1, 1, 16, device="cuda")
+    y0 = att(x, mask).float().clone()
+    y0b = att(x, mask).float().clone()
+    assert torch.equal(y0, y0b)
+    with torch.no_grad():
+        for p in att.parameters():              # BertAdam-style update through .data: no version counter moves
+            p.data.mul_(1.25)
+    y1 = att(x, mask).float().clone()
+    A = att._icka_arena
+    assert _shadow_ok(A), "stale bf16 weights after a .data update of a standalone BertAttention"
+    assert (y1 - y0).abs().max().item() > 1e-3
+    # tracked policy: an in-place update that bumps the version counters is seen at depth 2 as well
+    A.shadow_policy = "tracked"
+    att(x, mask)
+    with torch.no_grad():
+        att.output.dense.weight.mul_(0.5)
+    y2 = att(x, mask).float().clone()
+    assert _shadow_ok(A)
+    assert (y2 - y1).abs().max().item() > 1e-3
+    opt = torch.optim.SGD(att.parameters(), lr=0.5)
+    att(x, mask).float().sum().backward()
+    opt.step()                                   # seen through the global post-step hook
+    att(x, mask)
+    assert _shadow_ok(A)
+
+
+def test_one_shadow_cast_per_outermost_forward(monkeypatch):
+    """the default policy used to re-cast the arena 2-3 times per model forward (trunk + BertModel.encode +
+    scalar gate); it is ONE cast per contiguous range and outermost call now."""
+    from icka_amd import kernels as K
+    model, args, labels = _model()
+    model(*args, labels=labels)                  # builds the arena
+    A = model._icka_arena
+    calls = []
+    real = K.cast_f32_to_bf16
+    monkeypatch.setattr(K, "cast_f32_to_bf16", lambda s, d: (calls.append(s.numel()), real(s, d))[1])
+    model(*args, labels=labels)
+    assert len(calls) == len(A._cast_ranges), (len(calls), len(A._cast_ranges))

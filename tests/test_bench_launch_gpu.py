@@ -1,0 +1,48 @@
+"""`python bench.py --gpus N` started WITHOUT a launcher must start its N ranks itself (children of a torch.distributed.run
+child, spawned before the parent touches the GPU), relay rank 0's single JSON line and exit with the ranks' status
+(reference launch line: My_cross_attention.py:1104; process group per rank :653-657; apex DDP :768-776).
+
+One-GPU rehearsal: two ranks share the box's one MI355X (ICKA_BENCH_ONE_GPU=1) and exchange gradients over gloo through
+the host (ICKA_BENCH_BACKEND=gloo) -- the N > 1 flow of bench.py end to end, real HIP forward/backward in both ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    env = dict(os.environ, ICKA_BENCH_BACKEND="gloo", ICKA_BENCH_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline", "--optimizer-steps", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = p.stderr.decode("utf-8", "replace")
+    assert p.returncode == 0, err[-4000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, (lines, err[-2000:])        # stdout carries exactly ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 64
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 3
+    assert out["value"] == pytest.approx(64 / (out["ms_per_step"] * 1e-3), rel=1e-3)    # whole-job samples/s
+    assert out["with_optimizer_ms_per_step"] >= out["ms_per_step"] * 0.9
+    assert "self-launch" in err
+    print("\n[bench --gpus 2, self-launched, one-GPU gloo rehearsal] %s" % lines[0][:300])
+
+
+def test_bench_exit_status_of_a_failing_rank_is_relayed():
+    env = dict(os.environ, ICKA_BENCH_BACKEND="gloo", ICKA_BENCH_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # an impossible shape makes every rank raise before its first step
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--hidden", "100", "--no-cpu-baseline", "--no-roofline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert p.returncode != 0
+    assert p.stdout.decode().strip() == ""

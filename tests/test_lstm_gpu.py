@@ -119,3 +119,116 @@ def test_gate_1_tagger_end_to_end_against_oracle_composition():
     print("\n[_gate_1 tagger] emissions max abs err %.3e, loss %.4f (oracle %.4f), worst grad rel err %.3e"
           % (err, loss.item(), rloss.item(), worst))
     assert worst < TAGGER_GRAD_BAR, worst
+
+
+@pytest.mark.parametrize("handoff", [1, 0])
+@pytest.mark.parametrize("phase", ["forward", "backward"])
+def test_a_failed_handoff_is_never_silent(handoff, phase, request):
+    """VERDICT r02 #4 / ADVICE: a hand-off wait of a persistent launch that gives up must not pass for a result.  The test
+    hook makes block (0, direction 0) skip publishing step 3 (with a small poll budget, so the time-out takes
+    milliseconds): the outputs of that call must be NaN-poisoned and the NEXT host touch-point must raise -- BiLSTM.forward
+    itself and a GraphedStep replay -- after which the error is cleared and the layer works again.
+    (reference: nn.LSTM at Cross_Modal_Interaction_Module.py:905-908, :1042 cannot fail this way.)"""
+    from icka_amd import _lib
+    from icka_amd import kernels as K
+    from icka_amd.lstm import BiLSTM
+    lib = _lib.load()
+    lib.icka_lstm_set_persistent(1)
+    lib.icka_lstm_set_handoff(handoff)
+
+    def restore():
+        lib.icka_lstm_test_hooks(0, -1)
+        lib.icka_lstm_set_handoff(1)
+        lib.icka_lstm_clear_error()
+    request.addfinalizer(restore)
+    B, S, H = 8, 12, 256
+    torch.manual_seed(5)
+    m = BiLSTM(H, H).cuda()
+    x = (torch.randn(B, S, H) * 0.5).cuda().requires_grad_(True)
+    out, _ = m(x)                      # healthy call first (also maps the host-visible error word)
+    out.float().sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(x.grad.float()).all()
+    assert lib.icka_lstm_barrier_error() == 0
+    x.grad = None
+    m.zero_grad()
+    if phase == "forward":
+        lib.icka_lstm_test_hooks(2000, 3)
+        out, _ = m(x)
+        lib.icka_lstm_test_hooks(0, -1)
+        torch.cuda.synchronize()
+        assert torch.isnan(out.float()).any(), "a failed forward hand-off left finite outputs"
+        # direction 0 is poisoned from step 4 on, for every batch row and unit
+        assert torch.isnan(out.float()[:, 4:, :H]).all()
+    else:
+        out, _ = m(x)
+        lib.icka_lstm_test_hooks(2000, 3)
+        out.float().sum().backward()
+        lib.icka_lstm_test_hooks(0, -1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert torch.isnan(x.grad.float()).any(), "a failed backward hand-off left finite gradients"
+        assert torch.isnan(m.weight_hh_l0.grad).any()
+    assert lib.icka_lstm_barrier_error() == 1
+    with pytest.raises(K.LstmHandoffError):
+        m(x)                                   # next host touch-point raises ...
+    assert lib.icka_lstm_barrier_error() == 0  # ... and clears the word
+    out2, _ = m(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out2.float()).all()
+    print("\n[BiLSTM give-up path, handoff=%d, %s] outputs NaN-poisoned, error raised at the next touch-point" % (handoff, phase))
+
+
+def test_a_failed_handoff_inside_a_graph_replay_is_raised_by_the_next_replay(request):
+    from icka_amd import _lib
+    from icka_amd import kernels as K
+    from icka_amd.graph import GraphedStep
+    from icka_amd.lstm import BiLSTM
+    lib = _lib.load()
+    request.addfinalizer(lambda: (lib.icka_lstm_test_hooks(0, -1), lib.icka_lstm_clear_error()))
+    B, S, H = 8, 12, 256
+    torch.manual_seed(6)
+    m = BiLSTM(H, H).cuda()
+    x = (torch.randn(B, S, H) * 0.5).cuda()
+
+    def step():
+        # the hook values are kernel arguments: set only while the step is being captured, they are baked into the graph's
+        # launches (the eager warm-up steps stay healthy)
+        cap = torch.cuda.is_current_stream_capturing()
+        lib.icka_lstm_test_hooks(2000 if cap else 0, 3 if cap else -1)
+        out, _ = m(x)
+        loss = out.float().sum()
+        loss.backward()
+        return loss
+    step()                                       # builds the arena, maps the error word
+    torch.cuda.synchronize()
+    g = GraphedStep(m, step, warmup=1)
+    lib.icka_lstm_test_hooks(0, -1)
+    torch.cuda.synchronize()
+    assert lib.icka_lstm_barrier_error() == 0    # nothing has run with the hook yet (capture launches nothing)
+    loss = g()
+    torch.cuda.synchronize()
+    assert torch.isnan(loss).item()
+    with pytest.raises(K.LstmHandoffError):
+        g()
+    g.close()
+
+
+def test_reserved_cus_take_the_per_step_launches_when_the_grid_no_longer_fits(request):
+    """dp.GradReducer reserves CUs for RCCL's workgroups: a persistent grid that would need them falls back to one launch
+    per step (same results)."""
+    from icka_amd import _lib
+    from icka_amd.lstm import BiLSTM
+    lib = _lib.load()
+    request.addfinalizer(lambda: lib.icka_lstm_set_reserved_cus(0))
+    B, S, H = 20, 9, 512
+    torch.manual_seed(7)
+    m = BiLSTM(H, H).cuda()
+    x = (torch.randn(B, S, H) * 0.5).cuda()
+    with torch.no_grad():
+        ref, _ = m(x)
+        lib.icka_lstm_set_reserved_cus(torch.cuda.get_device_properties(0).multi_processor_count - 8)
+        out, _ = m(x)
+    torch.cuda.synchronize()
+    assert (out.float() - ref.float()).abs().max().item() < 1e-2
+    assert lib.icka_lstm_barrier_error() == 0
