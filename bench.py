@@ -243,8 +243,15 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=50.0,
                     help="minimum gradient bucket size in MB of fp32 gradients (the embedding tables are always a bucket of "
                          "their own): every bucket is a fork/join of the captured graph, see DESIGN.md section 6")
-    ap.add_argument("--comm-f32", action="store_true", help="fp32 gradient buckets on the wire (default at N > 1: bf16)")
-    ap.add_argument("--comm-bf16", action="store_true", help="force bf16 buckets (already the default at N > 1)")
+    ap.add_argument("--comm-f32", action="store_true", help="fp32 gradient buckets on the wire (the library default; the "
+                                                            "bench's default at N > 1 is bf16, see DESIGN.md section 6)")
+    ap.add_argument("--comm-bf16", action="store_true", help="force bf16 buckets (already the bench's default at N > 1)")
+    ap.add_argument("--dp-step", choices=("flagged", "segmented"), default="flagged",
+                    help="data parallel: 'flagged' = ONE hipGraph whose bucket-ready points are flag words waited for on the "
+                         "communication stream (graph.FlaggedStep); 'segmented' = linear graph segments with the all-reduces "
+                         "between them (graph.SegmentedStep, the round-2 form and the fallback)")
+    ap.add_argument("--dp-diag", default="", help="DIAGNOSTIC: GradReducer(diag=...) -- 'none', 'cast', 'comm', 'cast,comm': "
+                                                  "prices parts of the exchange, the gradients are wrong")
     ap.add_argument("--with-optimizer", action="store_true", help="(kept for round-1/2 command lines; the optimizer leg "
                                                                   "now always runs unless --no-optimizer-leg)")
     ap.add_argument("--no-optimizer-leg", action="store_true", help="skip the fwd+bwd+clip+AdamW leg")
@@ -336,8 +343,8 @@ def main():
         arena.shadow_policy = "tracked"
     if use_dist:
         from icka_amd.dp import GradReducer
-        reducer = GradReducer(arena, bucket_mb=args.bucket_mb,
-                              comm_dtype="f32" if args.comm_f32 else ("bf16" if (args.comm_bf16 or args.force_dist) else None))
+        reducer = GradReducer(arena, bucket_mb=args.bucket_mb, comm_dtype="f32" if args.comm_f32 else "bf16",
+                              diag=args.dp_diag)
         reducer.broadcast_parameters(0)
         arena.reducer = reducer
     opt = None if args.no_optimizer_leg else torch.optim.AdamW(model.parameters(), lr=3e-5)
@@ -351,8 +358,24 @@ def main():
     #      cannot be captured): the timed region then replays the graph
     mode = "eager"
     run_step = step
-    if not args.no_graph and reducer is not None and not args.capture_collectives:
-        # data parallel: linear graph segments with the bucket all-reduces issued eagerly between them (graph.SegmentedStep)
+    if not args.no_graph and reducer is not None and not args.capture_collectives and args.dp_step == "flagged" \
+            and reducer.backend == "nccl":
+        # data parallel: ONE graph, bucket-ready flag words, eager all-reduces behind flag waits on the communication stream
+        try:
+            from icka_amd.graph import FlaggedStep
+            log("capturing the step as one hipGraph with bucket-ready flags (eager all-reduces on the communication stream)")
+            if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallbacks below
+                raise RuntimeError("simulated capture failure")
+            fstep = FlaggedStep(model, step, reducer)
+            run_step = fstep
+            mode = "hipgraph+flag-waits+eager-allreduce(%d buckets, overlapped)" % len(reducer.buckets)
+        except Exception as e:  # noqa: BLE001
+            log("flagged capture failed (%s: %s)" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            reducer.capture = None
+            arena.reducer = reducer
+    if not args.no_graph and mode == "eager" and reducer is not None and not args.capture_collectives:
+        # fallback: linear graph segments with the bucket all-reduces issued eagerly between them (graph.SegmentedStep)
         try:
             from icka_amd.graph import SegmentedStep
             log("capturing the step as linear hipGraph segments (eager all-reduces in between)")
@@ -530,7 +553,11 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.seq, "regions": args.regions,
                        "parallelism": "dp%d" % world, "flops_per_sample_fwd_bwd": fl_sample, "launch": mode,
                        "precision": args.precision,
-                       "shadow_policy": arena.shadow_policy},
+                       "shadow_policy": arena.shadow_policy,
+                       "gradient_exchange": None if reducer is None else
+                       "%s buckets x %d, %s on the wire (%d MB per rank and step)%s"
+                       % ("bf16" if reducer.comm_bf16 else "f32", len(reducer.buckets), reducer.backend,
+                          reducer.wire_bytes() >> 20, (" DIAG=" + args.dp_diag) if args.dp_diag else "")},
             "shadow_cast_us": round(shadow_cast_us, 1),
             "loss": round(final_loss, 5),
             "roofline": roof, "cpu_baseline": cpu,

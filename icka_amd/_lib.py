@@ -160,6 +160,16 @@ PROTOTYPES = {
     "icka_bump_dropout_nonce": (c_i32, [c_vp, c_vp]),
     "icka_dropout_mask": (c_i32, [c_vp, c_i64, c_f32, c_u64, c_vp]),
     "icka_attn_dropout_mask": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_u64, c_vp]),
+    # ---- data-parallel helpers (csrc/dp.hip)
+    "icka_dp_chunk_elems": (c_i64, []),
+    "icka_dp_cast_chunks": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "icka_dp_cast_back_scaled": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "icka_dp_init": (c_i32, []),
+    "icka_dp_error": (c_i32, []),
+    "icka_dp_clear_error": (c_i32, []),
+    "icka_dp_step_bump": (c_i32, [c_vp, c_vp]),
+    "icka_dp_flag_set": (c_i32, [c_vp, c_vp, c_vp]),
+    "icka_dp_flag_wait": (c_i32, [c_vp, C.c_uint32, c_vp, c_i32, c_vp]),
     # ---- fp32 "exact" mode (csrc/exact.hip)
     "icka_x_gemm": (c_i32, [C.POINTER(XGemmDesc), c_vp]),
     "icka_x_ln_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64,

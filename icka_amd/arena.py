@@ -95,6 +95,7 @@ class ParamArena(object):
         self.pending_reductions = []  # LayerNorm dgamma/dbeta slab reductions riding on the next grouped launch
         self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self._seed_ctr = 0
+        self.seed_log = None     # tests: set to a list to record every seed handed out (one per dropout site call, in order)
 
     # ------------------------------------------------------------------------------------------ dropout seeds
     def set_seed(self, seed: int) -> None:
@@ -106,7 +107,10 @@ class ParamArena(object):
         z = (self._seed_base + self._seed_ctr * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        return z ^ (z >> 31)
+        z ^= z >> 31
+        if self.seed_log is not None:
+            self.seed_log.append(z)
+        return z
 
     # ------------------------------------------------------------------------------------------ validity
     def valid_for(self, root: nn.Module) -> bool:
@@ -169,6 +173,19 @@ class ParamArena(object):
         if len(first.shape) == 2:
             return self.gflat[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
         return self.gflat[first.off:first.off + rows]
+
+    def wire_of(self, gview: torch.Tensor) -> Optional[torch.Tensor]:
+        """Data parallel with bf16 buckets (dp.GradReducer): the slice of the reducer's bf16 wire buffer that mirrors the
+        gradient view ``gview`` (a contiguous view of ``gflat``, e.g. ``g(p)`` / ``g_cat(ps)``) -- handed to a weight-
+        gradient GEMM as its second output (icka_gemm_desc.C3), so that the wire copy comes out of the GEMM epilogue.
+        None when there is no reducer, it exchanges f32, or the view is not contiguous."""
+        r = self.reducer
+        if r is None or getattr(r, "gwire", None) is None or not gview.is_contiguous():
+            return None
+        off = (gview.data_ptr() - self.gflat.data_ptr()) // 4
+        if off < 0 or off + gview.numel() > self.total:
+            return None
+        return r.wire_view(off, gview.numel(), gview.shape)
 
     def _adjacent(self, ps: Sequence[nn.Parameter]):
         sl = [self.slots[id(p)] for p in ps]
@@ -341,6 +358,13 @@ class ArenaModule(nn.Module):
     def __call__(self, *args, **kwargs):
         if _FWD_DEPTH[0] == 0:
             _CALL_ID[0] += 1
+            # the OUTERMOST module of a call tree owns the arena of its whole sub-tree, also when its own forward launches
+            # nothing (BertAttention, BertCrossAttention: containers whose children would otherwise build one arena each)
+            if getattr(self, "_icka_arena", None) is None:
+                for p in self.parameters():
+                    if p.device.type == "cuda":
+                        arena_of(self)
+                    break
         _FWD_DEPTH[0] += 1
         try:
             return super().__call__(*args, **kwargs)

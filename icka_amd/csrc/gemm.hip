@@ -48,7 +48,9 @@ struct GemmArgs {
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
     int f16;           // operands are IEEE fp16 (v_mfma_f32_16x16x32_f16; NT only): the "mixed16" forward GEMMs
     int c_f16;         // main output C is fp16 (c_f32 == 0)
-    bf16_t* C3; int64_t ldc3;   // optional bf16 copy of the main output (the weight-gradient operand of an fp16 activation)
+    bf16_t* C3; int64_t ldc3;   // optional bf16 copy of the main output: of an fp16 activation (the weight-gradient operand of
+                                // the "mixed16" mode), or of an f32 weight gradient (the data-parallel wire copy: the value
+                                // AFTER beta-accumulation, written by the same epilogue -- dp.GradReducer)
     int aux_f16;       // the epilogue operand aux is fp16 (read through load8_aux / load4_aux)
     // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
     // output pixel m and the reduction index is k = tap * cvC + c -- the loader waves compute the patch addresses, no
@@ -214,10 +216,12 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
             f32x4 o = {v[0], v[1], v[2], v[3]};
             if (g.beta != 0.f) o += g.beta * *reinterpret_cast<const f32x4*>(p);
             *reinterpret_cast<f32x4*>(p) = o;
+            for (int r = 0; r < 4; ++r) v[r] = o[r];
         } else {
             for (int r = 0; r < 4; ++r)
-                if (r < nvalid) p[r] = v[r] + (g.beta != 0.f ? g.beta * p[r] : 0.f);
+                if (r < nvalid) { v[r] += g.beta != 0.f ? g.beta * p[r] : 0.f; p[r] = v[r]; }
         }
+        if (g.C3) store4_bf16(g.C3, g.ldc3, m, n, nvalid, v);
     } else if (g.c_f16) {
         _Float16* p = reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n;
         for (int r = 0; r < 4; ++r)
@@ -586,6 +590,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
             }
             st_out(reinterpret_cast<f32x4*>(p), o0);
             st_out(reinterpret_cast<f32x4*>(p + 4), o1);
+            if (g.C3) {
+                const float w[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+                store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, w);
+            }
         } else if (g.c_f16) {   // fp16 main output (+ optional bf16 copy); beta is rejected on the host
             store8_f16(reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n, v);
             if (g.C3) store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, v);
@@ -1094,8 +1102,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                 for (int mi = 0; mi < 4; ++mi) {
                     const int m = m0 + wr + 16 * mi + (lane & 15);
                     const f32x4 v = acc[mi][ni] * g.alpha + b4;
-                    if (g.c_f32) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
-                    else st_out(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
+                    if (g.c_f32) {
+                        st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
+                        if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+                    } else st_out(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
                                 pack4(v[0], v[1], v[2], v[3]));
                 }
             }
@@ -1408,7 +1418,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
         // (M <= 256 only: weight-gradient shapes.  Forward outputs such as the [tokens, labels] emissions stay on one
         //  block per tile so that two identical calls give bitwise identical logits -- atomic split-K order flipped
         //  Viterbi near-ties between a 'dev' and a 'test' pass of the same batch.)
-        if (g.c_f32 && g.epi == ICKA_EPI_NONE && nb < 64 && nk >= 16 && g.M <= 256) {
+        if (g.c_f32 && g.epi == ICKA_EPI_NONE && nb < 64 && nk >= 16 && g.M <= 256 && !g.C3) {   // (a wire copy needs the final value in one epilogue)
             ks = 256 / nb;
             if (ks > nk / 4) ks = nk / 4;
             if (ks < 1) ks = 1;
@@ -1488,7 +1498,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.f16 = d->ab_f16 != 0; g.C3 = (bf16_t*)d->C3; g.ldc3 = d->ldc3; g.aux_f16 = d->aux_f16 != 0;
     if (g.f16 && d->op != ICKA_GEMM_NT) return ICKA_E_ARG;       // fp16 operands: forward (NT) GEMMs only
     if (g.c_f16 && d->beta != 0.f) return ICKA_E_ARG;              // fp16 outputs are never accumulated into
-    if (g.C3 && !g.c_f16) return ICKA_E_ARG;                       // C3 = bf16 twin of an fp16 main output
+    if (g.C3 && !g.c_f16 && !g.c_f32) return ICKA_E_ARG;           // C3 = bf16 twin of an fp16 or an f32 main output
     if (g.c_f16 && d->colsum_out) return ICKA_E_ARG;
     g.abl = g_abl;
     g.stamp = g_stamp;
@@ -1758,6 +1768,7 @@ __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, 
             f32x4 v = acc[mi][ni] * g.alpha;
             if (g.beta != 0.f) v += g.beta * ld_once(dst);   // gradient accumulation across micro-batches
             st_out(dst, v);
+            if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
         }
     }
 }
@@ -1887,6 +1898,7 @@ __device__ __forceinline__ void gemm_big12_tn_body(const GemmArgs& g, char* smem
             f32x4 v = acc[mi][ni] * g.alpha;
             if (g.beta != 0.f) v += g.beta * ld_once(dst);
             st_out(dst, v);
+            if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
         }
     }
 }

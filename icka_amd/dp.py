@@ -2,7 +2,7 @@
 
 The hot path shards over (sentence, image) pairs: every rank holds a full weight replica and
 processes its own micro-batch; the only exchange is one gradient all-reduce (mean) per optimisation step -- the
-counterpart of the reference's apex DistributedDataParallel (My_cross_attention.py:768-776).
+counterpart of the reference's apex DistributedDataParallel (My_cross_attention.py:768-776; process group :653-657).
 
 Because all gradients live in ONE flat fp32 buffer (ParamArena.gflat), laid out in execution order, the reduction is
 a handful of large contiguous all-reduces instead of ~200 small ones: buckets are slices of that buffer, taken from
@@ -11,17 +11,26 @@ tables (whose gradient is final only at the very end of backward) in a bucket of
 launched on a side stream as soon as every gradient in it is final (``ParamArena.flush_final`` -> ``mark_final``),
 overlapping RCCL traffic over xGMI with the remaining backward kernels; ``finish`` joins the streams.
 
-Wire format: with more than one rank on ROCm devices the buckets travel as **bf16** by default (cast -> all-reduce AVG
--> cast back, all on the side stream): 239 MB instead of 477 MB per step for the bert-base path, which is what puts the
-exchange under the backward it overlaps with (budget in DESIGN.md section 6).  ``comm_dtype="f32"`` keeps fp32 buckets.
+Wire format.  ``comm_dtype="f32"`` (the default: what the reference's apex DDP exchanges) all-reduces the gradient buffer in
+place (AVG).  ``comm_dtype="bf16"`` (ROCm devices; what bench.py runs: 239 MB instead of 477 MB per step for the bert-base
+path, which is what puts the exchange under the backward it overlaps with) keeps a bf16 WIRE BUFFER with
+the layout of the gradient buffer:
+  * the weight-gradient GEMMs write the wire copy of every matrix gradient from their own epilogue (``ParamArena.wire_of``
+    -> icka_gemm_desc.C3): no cast pass over the 85 M matrix gradients of bert-base;
+  * what no GEMM produces (bias / LayerNorm vectors, classifier, embedding tables) is cast by ONE launch per bucket over a
+    chunk table (icka_dp_cast_chunks), on the side stream;
+  * the all-reduce is a SUM of the bucket's wire slice (bf16 on the wire), and one launch brings the bucket back into the f32
+    gradient buffer with the 1 / world factor folded in (icka_dp_cast_back_scaled).
+The N-rank bf16 ring sum rounds once per hop; tests/test_dp_gloo_cpu.py bounds that error against the fp32 mean.
 
 A slot counts as final when it has received ALL the gradient contributions it received in the calibration (first)
 step -- a module applied twice per forward contributes twice -- so a bucket is never reduced while a late write into it
-is still to come.  Works with the ``nccl`` (= RCCL) backend on ROCm devices and with ``gloo`` (CPU tensors; device
-tensors are staged through the host: tests only).
+is still to come; a write that arrives for a bucket already in flight raises.  Works with the ``nccl`` (= RCCL) backend on
+ROCm devices and with ``gloo`` (CPU tensors; device tensors are staged through the host: tests only).
 """
 from __future__ import annotations
 
+import sys
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -29,17 +38,18 @@ import torch.distributed as dist
 
 from .arena import ParamArena
 
-
-import os as _os
-_DIAG = _os.environ.get("ICKA_DP_DIAG", "")   # "", or any of "none" / "cast" / "comm" (comma-separated): see _allreduce
+# CUs dp.GradReducer keeps free of persistent BiLSTM blocks while RCCL workgroups may share the GPU (icka_hip.h:
+# icka_lstm_set_reserved_cus): RCCL runs one workgroup per channel, at most 64 channels
+LSTM_RESERVED_CUS = 64
 
 
 class GradReducer(object):
     def __init__(self, arena: ParamArena, group=None, bucket_mb: float = 64.0, comm_dtype: Optional[str] = None,
-                 comm_bf16: Optional[bool] = None):
-        """``bucket_mb``: minimum bucket size in MB of fp32 gradients.  ``comm_dtype``: "bf16" | "f32" | None (= bf16
-        when the world has more than one rank and the arena is on a device, else f32).  ``comm_bf16`` is the round-1
-        spelling of the same switch."""
+                 comm_bf16: Optional[bool] = None, diag: str = "", lstm_reserved_cus: Optional[int] = None):
+        """``bucket_mb``: minimum bucket size in MB of fp32 gradients.  ``comm_dtype``: "f32" (default) | "bf16" (ROCm devices
+        only; module docstring).  ``comm_bf16`` is the round-1 spelling of the same switch.  ``diag``: DIAGNOSTIC ONLY --
+        any of "cast" / "comm" (comma-separated), or "none": leave parts of the exchange out to price the others
+        (tools/fd_sweep.sh, bench.py --dp-diag); the gradients are then WRONG and every construction says so on stderr."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.arena = arena
@@ -50,12 +60,16 @@ class GradReducer(object):
         if comm_dtype is None and comm_bf16 is not None:
             comm_dtype = "bf16" if comm_bf16 else "f32"
         if comm_dtype is None:
-            comm_dtype = "bf16" if (self.world > 1 and self.is_cuda) else "f32"
+            comm_dtype = "f32"
         if comm_dtype not in ("bf16", "f32"):
             raise ValueError("comm_dtype must be 'bf16' or 'f32'")
         if comm_dtype == "bf16" and not self.is_cuda:
             raise ValueError("bf16 buckets need a ROCm device (the casts are HIP kernels)")
         self.comm_bf16 = comm_dtype == "bf16"
+        self.diag = diag or ""
+        if self.diag:
+            print("[icka_amd.dp] DIAGNOSTIC MODE diag=%r: parts of the gradient exchange are skipped -- the gradients of "
+                  "this process are WRONG (pricing runs only)" % self.diag, file=sys.stderr, flush=True)
         self.buckets: List[Tuple[int, int]] = arena.buckets(int(bucket_mb * (1 << 20) / 4))
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.is_cuda else None
         # slot -> bucket index
@@ -70,13 +84,22 @@ class GradReducer(object):
         self._seen: Dict[int, int] = {}
         self._waiting = [0] * len(self.buckets)   # per bucket: slots that have not received all their writes yet
         self._launched = [False] * len(self.buckets)
-        # segmented hipGraph capture (graph.SegmentedStep): while ``capture`` is set, a bucket that becomes ready is not
-        # launched but reported -- the capture cuts the graph there and the all-reduce is issued eagerly between the
-        # replayed segments, so no collective and no cross-stream edge ever sits inside a captured graph
+        # graph capture (graph.SegmentedStep / graph.FlaggedStep): while ``capture`` is set, a bucket that becomes ready is
+        # not launched but reported to it (``bucket_ready(idx)``, then ``after_mark()`` once per mark_final call)
         self.capture = None
-        self._stage = None
+        # ---- bf16 wire buffer (module docstring)
+        self.gwire = None
+        self._wire_ranges = set()                 # (offset, numel) of gradients whose wire copy a GEMM epilogue writes
+        self._tables: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         if self.comm_bf16:
-            self._stage = torch.empty(max(e - s for s, e in self.buckets), dtype=torch.bfloat16, device=arena.device)
+            self.gwire = torch.zeros(arena.total, dtype=torch.bfloat16, device=arena.device)
+            from . import kernels as K
+            K._lib.load().icka_dp_init()
+            for bi in range(len(self.buckets)):   # until the calibration step has shown who writes wire copies: cast all
+                self._tables[bi] = K.dp_chunk_table([self.buckets[bi]], arena.device)
+        if self.is_cuda and self.backend == "nccl" and self.world > 1 or lstm_reserved_cus is not None:
+            from . import kernels as K
+            K.lstm_set_reserved_cus(LSTM_RESERVED_CUS if lstm_reserved_cus is None else lstm_reserved_cus)
 
     # -------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -89,54 +112,98 @@ class GradReducer(object):
             dist.broadcast(self.arena.flat, src=src, group=self.group)
         self.arena.mark_dirty()
 
+    # ------------------------------------------------------------------------------------------------- wire copies
+    def wire_view(self, off: int, numel: int, shape) -> Optional[torch.Tensor]:
+        """The bf16 wire slice [off, off + numel) shaped like the gradient view a GEMM is about to write (ParamArena.wire_of);
+        noted, so that the bucket's cast launch skips it once calibration is over."""
+        if self.gwire is None:
+            return None
+        self._wire_ranges.add((off, numel))
+        return self.gwire[off:off + numel].view(shape)
+
+    def _build_tables(self) -> None:
+        """Chunk tables of what still has to be cast per bucket: the bucket minus the ranges GEMM epilogues fill."""
+        from . import kernels as K
+        wired = sorted(self._wire_ranges)
+        for bi, (lo, hi) in enumerate(self.buckets):
+            ranges, cur = [], lo
+            for off, n in wired:
+                end = off + (n + 7) // 8 * 8          # slots are padded to 8 elements: the pad belongs to nobody
+                if end <= lo or off >= hi:
+                    continue
+                if off > cur:
+                    ranges.append((cur, off))
+                cur = max(cur, end)
+            if cur < hi:
+                ranges.append((cur, hi))
+            self._tables[bi] = K.dp_chunk_table(ranges, self.arena.device)
+
+    def cast_elements(self) -> int:
+        """Elements per step that still go through the cast launches (diagnostics / DESIGN.md)."""
+        return sum(int(t[:, 1].sum().item()) for t in self._tables if t is not None and t.numel())
+
+    # ------------------------------------------------------------------------------------------------- launches
     def _launch(self, idx: int) -> None:
         self._launched[idx] = True
         if self.capture is not None:
-            self.capture.ready.append(idx)
+            self.capture.bucket_ready(idx)
             return
         self.launch_now(idx)
 
-    def launch_now(self, idx: int) -> None:
-        """Issue bucket ``idx``'s all-reduce (side stream on devices, ordered after everything on the current stream)."""
+    def launch_now(self, idx: int, wait=None) -> None:
+        """Issue bucket ``idx``'s all-reduce: on the side stream on devices, ordered after everything on the current
+        stream -- or, with ``wait = (device address of the flag word, tag, poll budget)`` (graph.FlaggedStep), after a
+        flag-wait kernel on the side stream and NOT after the current stream (which already holds the whole step's graph)."""
+        s, e = self.buckets[idx]
+        if self.is_cuda and self.backend == "nccl":
+            if wait is None:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                if wait is not None:
+                    from . import kernels as K
+                    flag, tag, polls = wait
+                    # poison target of a wait that gives up: the bucket's first wire element, or the upper half of its
+                    # first f32 gradient (0x7fc0 there is a NaN as well)
+                    poison = self.gwire.data_ptr() + 2 * s if self.gwire is not None else self.arena.gflat.data_ptr() + 4 * s + 2
+                    K.check(K._lib.load().icka_dp_flag_wait(flag, tag & 0xFFFFFFFF, poison, polls, K._stream()),
+                            "icka_dp_flag_wait")
+                self._allreduce(idx)
+        else:
+            self._allreduce(idx)
+
+    def _allreduce(self, idx: int) -> None:
         s, e = self.buckets[idx]
         buf = self.arena.gflat[s:e]
-        if self.is_cuda and self.backend == "nccl":
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                self._allreduce(buf)
-        else:
-            self._allreduce(buf)
-
-    def _allreduce(self, buf: torch.Tensor) -> None:
-        if _DIAG:   # diagnostic only (tools/fd_sweep.sh): leave out parts of the exchange to price them; wrong gradients
+        if self.diag:   # diagnostic only: leave out parts of the exchange to price them; wrong gradients (see __init__)
             from . import kernels as K
-            if "cast" in _DIAG and self.comm_bf16:
-                st = self._stage[:buf.numel()]
-                K.cast_f32_to_bf16(buf, st)
-                K.cast_bf16_to_f32(st, buf)
-            if "comm" in _DIAG:
-                dist.all_reduce(self._stage[:buf.numel()] if self.comm_bf16 else buf, op=dist.ReduceOp.AVG, group=self.group)
+            if "cast" in self.diag and self.comm_bf16:
+                K.dp_cast_chunks(self.arena.gflat, self.gwire, self._tables[idx])
+                K.dp_cast_back_scaled(self.gwire[s:e], buf, 1.0 / self.world)
+            if "comm" in self.diag:
+                dist.all_reduce(self.gwire[s:e] if self.comm_bf16 else buf, op=dist.ReduceOp.SUM, group=self.group)
             return
         if self.backend == "nccl":
             if self.comm_bf16:
                 from . import kernels as K
-                st = self._stage[:buf.numel()]
-                K.cast_f32_to_bf16(buf, st)
-                dist.all_reduce(st, op=dist.ReduceOp.AVG, group=self.group)
-                K.cast_bf16_to_f32(st, buf)
+                K.dp_cast_chunks(self.arena.gflat, self.gwire, self._tables[idx])
+                w = self.gwire[s:e]
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                K.dp_cast_back_scaled(w, buf, 1.0 / self.world)
             else:
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
             return
         # gloo has no AVG; device tensors go through the host (2-process tests on one GPU)
         if self.is_cuda:
-            if self.comm_bf16:      # same rounding points as the RCCL path: bf16 on the wire, fp32 result
-                host = buf.to(torch.bfloat16).float().cpu()
+            if self.comm_bf16:      # same data flow and rounding points as the RCCL path: wire copies + chunk cast, bf16 sum
+                from . import kernels as K
+                K.dp_cast_chunks(self.arena.gflat, self.gwire, self._tables[idx])
+                host = self.gwire[s:e].float().cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                host = host.to(torch.bfloat16).float().mul_(1.0 / self.world)
             else:
                 host = buf.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            host.mul_(1.0 / self.world)
-            if self.comm_bf16:
-                host = host.to(torch.bfloat16).float()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                host.mul_(1.0 / self.world)
             buf.copy_(host)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
@@ -147,30 +214,35 @@ class GradReducer(object):
         the calibration step the writes per slot are only counted (buckets are reduced in ``finish``).  Afterwards a
         slot is final once it has received as many writes as in the calibration step; a bucket whose slots are all
         final is all-reduced right away on the side stream.  Order-independent: nothing is assumed about the order in
-        which autograd runs the blocks."""
+        which autograd runs the blocks.  A write into a bucket whose all-reduce is already in flight (more writes than in
+        the calibration step: a data-dependent branch, a module applied more often) would be lost or race with the
+        in-place reduction: it raises."""
         if not self._calibrated:
             for s in slots:
                 self._expected[id(s)] = self._expected.get(id(s), 0) + 1
             return
         for s in slots:
             sid = id(s)
+            bi = self._bucket_of[sid]
+            if self._launched[bi]:
+                raise RuntimeError(
+                    "icka_amd.dp.GradReducer: gradient write into %s after its bucket (%d) was handed to the all-reduce of "
+                    "this step -- the step wrote this parameter more often than the calibration (first) step did.  Build a "
+                    "new GradReducer after changing what the step computes." % (s.name, bi))
             exp = self._expected.get(sid)
             if exp is None:
                 # a parameter that got no gradient in the calibration step: its bucket can no longer be trusted to be
                 # complete early -- reduce it in finish()
-                bi = self._bucket_of[sid]
-                if not self._launched[bi]:
-                    self._waiting[bi] = 1 << 30
+                self._waiting[bi] = 1 << 30
                 continue
             n = self._seen.get(sid, 0) + 1
             self._seen[sid] = n
             if n == exp:
-                bi = self._bucket_of[sid]
                 self._waiting[bi] -= 1
-                if self._waiting[bi] == 0 and not self._launched[bi]:
+                if self._waiting[bi] == 0:
                     self._launch(bi)
-        if self.capture is not None and self.capture.ready:
-            self.capture.cut()
+        if self.capture is not None:
+            self.capture.after_mark()
 
     def finish(self) -> None:
         """Launch every bucket not launched yet (parameters that got no gradient this step keep their bucket
@@ -180,6 +252,8 @@ class GradReducer(object):
                 self._launch(bi)
         if self.capture is None:
             self.join()
+        if not self._calibrated and self.gwire is not None:
+            self._build_tables()      # the calibration step has shown which gradients GEMM epilogues copy to the wire
         self._calibrated = True
         # parameters that never receive a gradient (e.g. the pooler when only logits are used) are not waited for
         self._seen = {}

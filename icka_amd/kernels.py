@@ -98,7 +98,8 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
               out3: Optional[torch.Tensor] = None) -> GemmDesc:
     """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched).
     Operands are bf16, or -- op NT only, the "mixed16" forward GEMMs -- both fp16; ``out`` may then be fp16 too, with
-    ``out3`` an optional bf16 copy of it."""
+    ``out3`` an optional bf16 copy of it.  With an f32 ``out``, ``out3`` is the data-parallel wire copy (bf16 of the final,
+    beta-accumulated value) the weight-gradient GEMMs write for dp.GradReducer."""
     odt = A.dtype if A.dtype == F16 else BF16     # operand dtype of this launch
     if odt == F16 and op != GEMM_NT:
         raise ValueError("fp16 operands: NT (forward) GEMMs only")
@@ -126,8 +127,8 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
     if out.dtype == F16 and (beta != 0.0 or colsum_out is not None):
         raise ValueError("fp16 outputs are plain forward outputs (no accumulate, no fused column sums)")
     if out3 is not None:
-        if out.dtype != F16:
-            raise ValueError("out3 is the bf16 copy of an fp16 main output")
+        if out.dtype not in (F16, F32):
+            raise ValueError("out3 is the bf16 copy of an fp16 main output, or the data-parallel wire copy of an f32 one")
         _mat(out3, "out3")
         if tuple(out3.shape) != (M, N):
             raise ValueError("out3 must be [%d,%d]" % (M, N))
@@ -748,6 +749,55 @@ def clear_dropout_nonce_if(words: torch.Tensor) -> None:
 
 def bump_dropout_nonce(words: torch.Tensor) -> None:
     check(_lib.load().icka_bump_dropout_nonce(words.data_ptr(), _stream()), "icka_bump_dropout_nonce")
+
+
+# ------------------------------------------------------------------------------------------------- data parallel
+class DpFlagError(RuntimeError):
+    """A bucket-ready wait on the communication stream gave up: that step's all-reduce ran on unfinished gradients (the
+    bucket was poisoned with a NaN)."""
+
+
+def dp_chunk_table(ranges, device) -> torch.Tensor:
+    """Chunk table for dp_cast_chunks: [(lo, hi)] element ranges (multiples of 8) -> int64 [n, 2] device tensor of
+    (first element, count <= icka_dp_chunk_elems())."""
+    ch = _lib.load().icka_dp_chunk_elems()
+    rows = []
+    for lo, hi in ranges:
+        if lo % 8 or hi % 8:
+            raise ValueError("chunk ranges must start and end on multiples of 8 elements")
+        while lo < hi:
+            n = min(ch, hi - lo)
+            rows.append((lo, n))
+            lo += n
+    return torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, 2)
+
+
+def dp_cast_chunks(src_f32: torch.Tensor, dst_bf16: torch.Tensor, table: torch.Tensor) -> None:
+    """dst[i] = bf16(src[i]) over the chunks of ``table`` (dp_chunk_table); src / dst are the whole flat buffers."""
+    _dev(src_f32, "src"); _dev(dst_bf16, "dst")
+    if src_f32.dtype != F32 or dst_bf16.dtype != BF16 or src_f32.numel() != dst_bf16.numel():
+        raise TypeError("dp_cast_chunks: f32 source and bf16 destination of the same length")
+    if table.numel() == 0:
+        return
+    check(_lib.load().icka_dp_cast_chunks(src_f32.data_ptr(), dst_bf16.data_ptr(), table.data_ptr(), table.shape[0],
+                                          _stream()), "icka_dp_cast_chunks")
+
+
+def dp_cast_back_scaled(src_bf16: torch.Tensor, dst_f32: torch.Tensor, scale: float) -> None:
+    _dev(src_bf16, "src"); _dev(dst_f32, "dst")
+    if src_bf16.dtype != BF16 or dst_f32.dtype != F32 or src_bf16.numel() != dst_f32.numel():
+        raise TypeError("dp_cast_back_scaled: bf16 source and f32 destination of the same length")
+    check(_lib.load().icka_dp_cast_back_scaled(src_bf16.data_ptr(), dst_f32.data_ptr(), src_bf16.numel(), float(scale),
+                                               _stream()), "icka_dp_cast_back_scaled")
+
+
+def dp_check_error(where: str = "") -> None:
+    lib = _lib.load()
+    if lib.icka_dp_error() != 0:
+        lib.icka_dp_clear_error()
+        raise DpFlagError("icka_amd data-parallel step%s: a bucket-ready wait on the communication stream gave up (the "
+                          "compute graph did not reach the bucket's flag in time); the gradients of that step are NaN-"
+                          "poisoned" % ((" (" + where + ")") if where else ""))
 
 
 # ------------------------------------------------------------------------------------------------- per-sample gates

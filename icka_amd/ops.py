@@ -74,8 +74,10 @@ def _wgrad(A: ParamArena, dy, x, gout, beta: float, bias=None) -> None:
             csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(M))
             K.colsum(dy, bout, csw, accumulate=bacc)
             bout = None
-    A.pending_wgrad.append((K.gemm_desc(K.GEMM_TN, dy, x, gout, beta=beta, colsum_out=bout, colsum_accumulate=bacc),
-                            dy, x, gout, bout))
+    # data parallel with bf16 buckets: the same epilogue writes the bf16 wire copy of the gradient (ParamArena.wire_of)
+    wire = A.wire_of(gout)
+    A.pending_wgrad.append((K.gemm_desc(K.GEMM_TN, dy, x, gout, beta=beta, colsum_out=bout, colsum_accumulate=bacc,
+                                        out3=wire), dy, x, gout, bout, wire))
 
 
 def _flush_wgrad(A: ParamArena) -> None:
@@ -468,9 +470,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.epi == K.EPI_TANH:   # y = tanh(pre): d(pre) = dy * (1 - y^2)
             dyv = K.tanh_bwd(dyv if dyv.is_contiguous() else dyv.contiguous(), y, torch.empty_like(y))
         fused = lin.bias is not None and N % 128 == 0 and x.shape[1] % 128 == 0 and M % 64 == 0
-        K.gemm(K.GEMM_TN, dyv, x, A.g(lin.weight), beta=A.grad_beta(lin.weight),
+        gw = A.g(lin.weight)
+        K.gemm(K.GEMM_TN, dyv, x, gw, beta=A.grad_beta(lin.weight),
                colsum_out=A.g(lin.bias) if fused else None,
-               colsum_accumulate=fused and A.grad_beta(lin.bias) > 0)   # bias gradient inside the wgrad GEMM
+               colsum_accumulate=fused and A.grad_beta(lin.bias) > 0,   # bias gradient inside the wgrad GEMM
+               out3=A.wire_of(gw))                                       # + the data-parallel wire copy
         if lin.bias is not None and not fused:
             csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(N))
             K.colsum(dyv, A.g(lin.bias), csw, accumulate=A.grad_beta(lin.bias) > 0)

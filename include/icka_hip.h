@@ -27,7 +27,8 @@ extern "C" {
  * icka_ln_fwd_h, icka_embed_fwd_h, icka_attn_fwd_ex, icka_cls_head_fwd_h, icka_cast_*f16, icka_conv3x3_gemm.
  * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive).
  * 4: round 3 -- icka_lstm_clear_error, icka_lstm_set_reserved_cus, icka_lstm_test_hooks; a hand-off wait that gives up now
- *    NaN-poisons the recurrence and raises a host-visible error word (additive). */
+ *    NaN-poisons the recurrence and raises a host-visible error word; icka_gemm_desc.C3 may accompany an f32 main output
+ *    (the data-parallel wire copy); icka_dp_* (additive). */
 #define ICKA_ABI_VERSION 4
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -73,7 +74,10 @@ typedef struct icka_gemm_desc {
     int32_t colsum_accumulate;
     /* "mixed16" forward GEMMs (op NT only): operands A, B (A2, B2) are IEEE fp16 instead of bf16
      * (v_mfma_f32_16x16x32_f16, same rate); c_is_f32 == 2 makes the main output fp16 (saturating at +-65504, beta must
-     * be 0) and C3, if not NULL, receives a bf16 copy of it (the operand the bf16 weight-gradient GEMM reads later). */
+     * be 0) and C3, if not NULL, receives a bf16 copy of it (the operand the bf16 weight-gradient GEMM reads later).
+     * With an f32 main output (c_is_f32 == 1, any op) C3 is the DATA-PARALLEL WIRE COPY: a bf16 copy of the final value
+     * (after beta-accumulation) written by the same epilogue -- the weight-gradient GEMMs fill the bf16 all-reduce buffer
+     * of icka_amd/dp.py themselves instead of a separate cast pass over the gradients (see icka_dp_* below). */
     int32_t ab_f16;
     void* C3; int64_t ldc3;
     int32_t aux_f16;       /* the epilogue operand `aux` is fp16 instead of bf16 (mixed16 gate: sigmoid(.) * cross_fp16) */
@@ -534,6 +538,38 @@ int icka_x_embed_prompt_scatter(const float* dpre, const int64_t* ids, const int
 int icka_x_token_ce(const float* logits, int64_t ld, const int64_t* labels, const int64_t* mask, float* loss_sum,
                     float* count, float* dlogits, int32_t M, int32_t C, void* stream);
 int icka_x_scale_by_ratio(const float* x, float* y, const float* num, const float* den, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Data-parallel helpers (csrc/dp.hip).  Reference: apex DistributedDataParallel all-reduces the gradients of every
+ * parameter during backward (My_cross_attention.py:768-776, process group :653-657, launch line :1104); here the exchange
+ * is RCCL over xGMI driven by icka_amd/dp.py, and these entry points are what runs around it on the GPU.
+ *
+ * Wire format: gradients travel as bf16.  Matrix gradients get their wire copy from the weight-gradient GEMM itself
+ * (icka_gemm_desc.C3 beside an f32 C: the value after beta-accumulation); everything else in a bucket is cast by ONE launch
+ * over a chunk table:
+ *   icka_dp_cast_chunks: table_dev = n_chunks x {first element, element count} (int64 pairs in device memory; counts are
+ *     multiples of 8 and at most icka_dp_chunk_elems()); dst[i] = bf16(src[i]) for every i in a chunk; src / dst are the
+ *     BASES of the flat f32 gradient buffer / the bf16 wire buffer (same element offsets).
+ *   icka_dp_cast_back_scaled: dst f32 [n] = src bf16 [n] * scale (the reduced bucket back into the gradient buffer, with the
+ *     1 / world factor of the mean folded in: the all-reduce is a SUM).
+ * Bucket-ready flags for a step captured as ONE hipGraph with eager collectives (icka_amd/graph.py: FlaggedStep):
+ *   icka_dp_step_bump(step_word): step_word[0] += 1 -- first node of the graph;
+ *   icka_dp_flag_set(flag_word, step_word): flag_word[0] = step_word[0] -- a node right after the kernel that finishes the
+ *     bucket's last gradient;
+ *   icka_dp_flag_wait(flag_word, tag, poison_bf16, max_polls): a one-wave kernel for the COMMUNICATION stream that returns once
+ *     flag_word[0] >= tag (wrap-safe), polling with s_sleep at most max_polls times; if it gives up it raises the error word
+ *     read by icka_dp_error() (host memory mapped into the device: no synchronisation) and, when poison_bf16 is given,
+ *     stores a bf16 NaN there (the first wire element of the bucket: it reaches every rank's gradients through the
+ *     all-reduce).  icka_dp_init() maps the error word (not inside a stream capture); icka_dp_clear_error() resets it. */
+int64_t icka_dp_chunk_elems(void);
+int icka_dp_cast_chunks(const float* src, void* dst_bf16, const int64_t* table_dev, int32_t n_chunks, void* stream);
+int icka_dp_cast_back_scaled(const void* src_bf16, float* dst, int64_t n, float scale, void* stream);
+int icka_dp_init(void);
+int icka_dp_error(void);
+int icka_dp_clear_error(void);
+int icka_dp_step_bump(void* step_word, void* stream);
+int icka_dp_flag_set(void* flag_word, const void* step_word, void* stream);
+int icka_dp_flag_wait(const void* flag_word, uint32_t tag, void* poison_bf16, int32_t max_polls, void* stream);
 
 #ifdef __cplusplus
 }

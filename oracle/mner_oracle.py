@@ -68,7 +68,36 @@ def dense(x: Tensor, P: Params, prefix: str) -> Tensor:
     return F.linear(x, P[prefix + ".weight"], P[prefix + ".bias"])
 
 
-def _drop(x: Tensor, p: float, training: bool) -> Tensor:
+class MaskFeed(object):
+    """Keep-multipliers for the dropout sites of ONE forward, in the order the sites run (nn.Dropout multiplies by
+    0 or 1/(1-p): Cross_Modal_Interaction_Module.py:411, :500, :534, :563, :616, :953).  Passed in place of
+    ``training=True``: every ``_drop`` call then multiplies by the next mask instead of drawing from the CPU RNG, so a
+    train-mode step of the HIP path (whose masks come from its counter hash, exported with icka_dropout_mask /
+    icka_attn_dropout_mask or restated in numpy) can be compared with the oracle end to end.  Site order of
+    ``mner_logits``: embeddings; per BERT layer: attention probabilities, attention-output dense, FFN-output dense; the
+    encoder output (:953); per cross layer: the same three.  ``masks`` is a list of tensors, or a callable
+    ``(site_index, shape) -> tensor`` (masks made on demand: a whole bert-base step holds 1.3 GB of them)."""
+
+    def __init__(self, masks):
+        self.masks = masks
+        self.used = 0
+
+    def __bool__(self):
+        return True
+
+    def next(self, shape) -> Tensor:
+        i = self.used
+        self.used += 1
+        m = self.masks(i, tuple(shape)) if callable(self.masks) else self.masks[i]
+        if tuple(m.shape) != tuple(shape):
+            raise ValueError("dropout site %d: mask shape %s, activation shape %s" % (i, tuple(m.shape), tuple(shape)))
+        return m
+
+
+def _drop(x: Tensor, p: float, training) -> Tensor:
+    """nn.Dropout.  ``training`` is a bool, or a MaskFeed (train mode with the masks supplied by the caller)."""
+    if isinstance(training, MaskFeed):
+        return x * training.next(x.shape) if p > 0.0 else x
     return F.dropout(x, p, training) if (training and p > 0.0) else x
 
 

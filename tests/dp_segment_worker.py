@@ -13,6 +13,7 @@ import torch.distributed as dist
 
 def main():
     port, out, comm = sys.argv[1], sys.argv[2], sys.argv[3]
+    kind = sys.argv[4] if len(sys.argv) > 4 else "segmented"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -20,7 +21,7 @@ def main():
     from icka_amd import synth
     from icka_amd.config import BertConfig
     from icka_amd.dp import GradReducer
-    from icka_amd.graph import SegmentedStep
+    from icka_amd.graph import FlaggedStep, SegmentedStep
     from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
     cfg = BertConfig(512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                      max_position_embeddings=64)
@@ -48,7 +49,7 @@ def main():
         red.finish()
         return loss
 
-    ss = SegmentedStep(model, step, red)
+    ss = SegmentedStep(model, step, red) if kind == "segmented" else FlaggedStep(model, step, red)
     worst = 0.0
     for it in range(3):
         loss = ss()
@@ -58,8 +59,17 @@ def main():
                 assert p.grad is not None, n
                 worst = max(worst, ((p.grad - ref[n]).norm() / (ref[n].norm() + 1e-12)).item())
         model.zero_grad()                      # the reference loop drops the gradients after every step
-    torch.save({"worst": worst, "segments": len(ss.segments), "buckets": len(red.buckets),
-                "after": [len(a) for _, a in ss.segments], "loss": loss.item(), "ref_loss": ref_loss}, out)
+    from icka_amd import _lib
+    assert _lib.load().icka_dp_error() == 0
+    if kind == "segmented":
+        res = {"segments": len(ss.segments), "after": [len(a) for _, a in ss.segments]}
+    else:
+        res = {"segments": 1, "after": [len(ss.order)], "order": list(ss.order),
+               "step_word": int(ss.sync[0].item()), "flags": ss.sync[ss.FLAG0:ss.FLAG0 + len(red.buckets)].tolist()}
+    res.update({"worst": worst, "buckets": len(red.buckets), "loss": loss.item(), "ref_loss": ref_loss,
+                "cast_elements": red.cast_elements() if red.gwire is not None else None,
+                "total_elements": sum(e - s for s, e in red.buckets), "wire_ranges": len(red._wire_ranges)})
+    torch.save(res, out)
     ss.close()
     dist.destroy_process_group()
 

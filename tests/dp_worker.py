@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 def main():
     rank, world, port, out, precision = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    comm = sys.argv[6] if len(sys.argv) > 6 else "f32"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,7 +44,7 @@ def main():
 
     step(half)                                          # builds the arena
     arena = model._icka_arena
-    red = GradReducer(arena, bucket_mb=0.25, comm_dtype="f32")
+    red = GradReducer(arena, bucket_mb=0.25, comm_dtype=comm)
     red.broadcast_parameters(0)
     arena.reducer = red
     early = []
@@ -66,7 +67,10 @@ def main():
         if rel > worst:
             worst, wkey = rel, n
     overlapped = sum(1 for idx, cal in early if cal)     # buckets launched from inside backward after calibration
-    torch.save({"worst": worst, "key": wkey, "buckets": len(red.buckets), "overlapped": overlapped}, out)
+    total = sum(e - s for s, e in red.buckets)
+    torch.save({"worst": worst, "key": wkey, "buckets": len(red.buckets), "overlapped": overlapped,
+                "cast_elements": red.cast_elements() if red.gwire is not None else None, "total_elements": total,
+                "wire_ranges": len(red._wire_ranges)}, out)
     dist.destroy_process_group()
 
 

@@ -176,3 +176,73 @@ def test_arena_keeps_state_dict_contract():
     assert arena.valid_for(model)
     with pytest.raises(RuntimeError):
         arena.sync()   # bf16 shadows need a device: no CPU path
+
+
+def _late_write_worker(rank, world, port, tmp):
+    """after calibration a slot that is written MORE often than in the calibration step would be written while
+    its bucket's all-reduce is already in flight: mark_final must raise instead of losing / racing the late write."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from icka_amd.dp import GradReducer
+    model = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 64))
+    arena = ParamArena(model)
+    red = GradReducer(arena, bucket_mb=64 * 65 * 4 / (1 << 20))     # one Linear per bucket
+    assert len(red.buckets) == 2 and not red.comm_bf16                # library default on the wire: f32, like apex DDP
+    arena.reducer = red
+
+    def write(layer):
+        for p in (layer.weight, layer.bias):
+            arena.grad_beta(p)
+            arena.g(p).fill_(1.0)
+        arena.flush_final()
+    for step in range(2):                       # calibration: every layer written once per step
+        for p in model.parameters():
+            p.grad = None
+        write(model[1]); write(model[0])
+        red.finish()
+    for p in model.parameters():
+        p.grad = None
+    write(model[1])                             # its bucket is launched right here (all its slots are final)
+    raised = False
+    try:
+        write(model[1])                         # a second write in the same step: the bucket is already in flight
+    except RuntimeError as e:
+        raised = "after its bucket" in str(e)
+    torch.save({"raised": raised}, os.path.join(tmp, "l%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_a_gradient_write_into_a_bucket_already_in_flight_raises(tmp_path):
+    mp.spawn(_late_write_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "l0.pt"))["raised"]
+
+
+def test_bf16_ring_sum_over_8_ranks_is_bounded_against_the_fp32_mean():
+    """comm_dtype="bf16" sums bf16 buckets over the ring -- every hop adds two values in f32 and rounds the
+    partial sum to bf16 (N - 1 roundings per element), where the reference's apex DDP averages in fp32.  Emulate the ring
+    reduce-scatter order for N = 8 on gradient-like data and bound the error of sum / N against the fp32 mean: relative L2
+    within 2^-8 (a bf16 rounding is at most 2^-8 relative -- half an ulp of an 8-bit significand -- per hop; the errors of
+    the hops add as a random walk), and never worse than (N - 1) * 2^-8 of the largest partial sum element-wise."""
+    N, n = 8, 1 << 16
+    g = torch.Generator().manual_seed(11)
+    grads = [torch.randn(n, generator=g) * 1e-3 * (1.0 + 0.1 * r) for r in range(N)]     # one gradient slice per rank
+    wire = [x.to(torch.bfloat16) for x in grads]                                          # what each rank puts on the wire
+    ref = torch.stack([w.float() for w in wire]).mean(0)                                  # fp32 mean of the SAME wire inputs
+    # ring reduce-scatter: chunk c starts at rank c + 1 and travels N - 1 hops, rounding to bf16 after every add
+    chunks = torch.arange(n).chunk(N)
+    out = torch.empty(n)
+    worst_partial = torch.zeros(n)
+    for c, idx in enumerate(chunks):
+        acc = wire[(c + 1) % N][idx]
+        for hop in range(2, N + 1):
+            acc = (acc.float() + wire[(c + hop) % N][idx].float()).to(torch.bfloat16)
+            worst_partial[idx] = torch.maximum(worst_partial[idx], acc.float().abs())
+        out[idx] = acc.float() / N                                                        # icka_dp_cast_back_scaled
+    rel = ((out - ref).norm() / ref.norm()).item()
+    assert rel < 2.0 ** -8, rel
+    assert ((out - ref).abs() <= (N - 1) * 2.0 ** -8 * worst_partial / N + 1e-12).all()
+    # and against the true fp32 gradients (wire rounding of the inputs included) it stays within 2^-7
+    rel_true = ((out - torch.stack(grads).mean(0)).norm() / torch.stack(grads).mean(0).norm()).item()
+    assert rel_true < 2.0 ** -7, rel_true
+    print("\n[bf16 ring sum, N = 8] rel-L2 vs fp32 mean of the wire inputs %.2e, vs the fp32 gradients %.2e" % (rel, rel_true))

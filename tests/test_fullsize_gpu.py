@@ -134,3 +134,118 @@ def test_c4_full_depth_bert_large_l24_s256_r50():
 def test_c5_full_size_fp8_cross_attention_b64():
     # measured: bf16+fp8 gradients worst 1.53e-2 (cross-attention out-proj, the fp8 layer), median 4.5e-3; fp32 worst 1.7e-6
     _both_modes("c5 B64 S128 R36 L12", BASE, 64, 128, 36, 19260819, grad_bf16=3.1e-2, grad_fp32=1e-5, fp8=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Train mode (dropout p = 0.1 ACTIVE) end to end: the configuration bench.py times.  The reference trains with dropout on
+# (My_cross_attention.py:791 model.train(); sites Cross_Modal_Interaction_Module.py:411, :500, :534, :563, :616, :953).  The
+# HIP path draws its masks from a counter hash of (site seed [^ graph nonce], element index); the very masks of the step
+# are exported site by site (icka_dropout_mask / icka_attn_dropout_mask fold the same nonce, and are pinned to the numpy
+# restatement of the hash by tests/test_dropout_hash_cpu.py / test_kernels_gpu.py) and fed to the oracle (MaskFeed), so
+# logits, loss and EVERY parameter gradient of one whole train-mode step are compared -- a mask-indexing disagreement
+# between two sites, or between a forward and its recomputing backward, shows up here.
+def _site_kinds(L, Lc):
+    return ["h"] + ["a", "h", "h"] * L + ["h"] + ["a", "h", "h"] * Lc
+
+
+def _train_step_vs_oracle(tag, precision, graphed, logit_tol, grad_tol, B=32, S=128, R=36, cfgkw=BASE, seed=19260817):
+    import icka_amd
+    from icka_amd import kernels as K
+    from icka_amd.config import BertConfig
+    from icka_amd.graph import GraphedStep
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF, token_ce_loss
+    from oracle import mner_oracle as O
+    batch = synth.synthetic_batch(B, S, R, vocab_size=cfgkw["vocab_size"], seed=seed)
+    cfg = BertConfig(cfgkw["vocab_size"], **{k: v for k, v in cfgkw.items() if k != "vocab_size"})
+    model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=R, max_seq_length=S)
+    synth.fill_module_(model)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    if precision != "bf16":
+        icka_amd.set_precision(model, precision)
+    g = {k: v.cuda() for k, v in batch.items()}
+    K.set_dropout_nonce(None)
+    holder = {}
+    one = torch.ones((), device="cuda")
+
+    def step():
+        logits = model.logits(g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"],
+                              g["visual_embeds_att"])
+        loss = token_ce_loss(logits, g["labels"], g["input_mask"], exact=precision == "fp32")
+        loss.backward(gradient=one)
+        holder["logits"], holder["loss"] = logits, loss
+        return loss
+    model.zero_grad()
+    step()                                   # builds the arena
+    A = model._icka_arena
+    A.set_seed(0x5eed0000 + B)
+    A.seed_log = []
+    model.zero_grad()
+    if graphed:
+        gs = GraphedStep(model, step, warmup=1)     # logs the warm-up step's seeds, then the captured step's
+        nsite = len(_site_kinds(cfgkw["num_hidden_layers"], 1))
+        seeds = A.seed_log[-nsite:]
+        gs(); gs()                                  # two replays: the masks compared are those of the LAST one (nonce != 0)
+        nonce = gs.nonce.cpu().tolist()
+        assert nonce[0] != 0
+    else:
+        step()
+        seeds = list(A.seed_log)
+    A.seed_log = None
+    torch.cuda.synchronize()
+    kinds = _site_kinds(cfgkw["num_hidden_layers"], 1)
+    assert len(seeds) == len(kinds), (len(seeds), len(kinds))
+    p_h, p_a = cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
+    keep_rates = []
+
+    def mask_of(i, shape):     # the multiplier site i applied in the step just run (the graph's nonce is still registered)
+        if kinds[i] == "a":
+            b, h, sq, skv = shape
+            m = K.attn_dropout_mask(b * h * sq, skv, p_a, seeds[i], "cuda").view(shape)
+        else:
+            n = 1
+            for d in shape:
+                n *= d
+            m = K.dropout_mask(n, p_h, seeds[i], "cuda").view(shape)
+        keep_rates.append((m > 0).float().mean().item())
+        return m.cpu()
+    ocfg = O.OracleConfig(**cfgkw)
+    feed = O.MaskFeed(mask_of)
+    t0 = time.time()
+    ref = O.mner_logits(P, ocfg, batch["input_ids"], batch["segment_ids"], batch["input_mask"],
+                        batch["added_attention_mask"], batch["visual_embeds_att"], 1, R, training=feed)
+    rloss = O.token_ce_loss(ref, batch["labels"], batch["input_mask"])
+    rloss.backward()
+    assert feed.used == len(kinds)
+    assert all(abs(r - 0.9) < 0.01 for r in keep_rates), keep_rates
+    print("\n  [oracle, train mode with the step's own %d masks] CPU fwd+bwd %.1f s" % (feed.used, time.time() - t0))
+    logits, loss = holder["logits"], holder["loss"]
+    err = (logits.float().cpu() - ref.detach()).abs().max().item()
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    rows = []
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        rows.append((((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-4 * gmax)).item(), k))
+    rows.sort(reverse=True)
+    print("  [%s] TRAIN-mode step%s: logits max abs err %.3e (tol %.0e), loss %.6f (oracle %.6f), worst gradient rel-L2 %.3e at "
+          "%s (bar %.1e), median %.3e over %d tensors" % (tag, " through GraphedStep (nonce %s)" % nonce if graphed else "", err,
+                                                          logit_tol, loss.item(), rloss.item(), rows[0][0], rows[0][1], grad_tol,
+                                                          rows[len(rows) // 2][0], len(rows)))
+    if graphed:
+        gs.close()
+    K.set_dropout_nonce(None)
+    assert err < logit_tol
+    assert abs(loss.item() - rloss.item()) < logit_tol
+    assert rows[0][0] < grad_tol, rows[:5]
+    assert model.bert.embeddings.word_embeddings.weight.grad[0].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_c2_train_mode_step_with_the_steps_own_dropout_masks_bf16(graphed):
+    _train_step_vs_oracle("c2 B32 S128 R36 L12 bf16", "bf16", graphed, LOGIT_TOL_BF16, 4e-2)
+
+
+def test_c2_train_mode_step_with_the_steps_own_dropout_masks_fp32():
+    _train_step_vs_oracle("c2 B32 S128 R36 L12 fp32", "fp32", True, LOGIT_TOL_FP32, 1e-4)
