@@ -84,9 +84,8 @@ def build_model(args, dev):
     model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=args.cross_layers, num_labels=args.labels,
                                                  regions=args.regions, cross_attention_fp8=args.fp8_cross)
     synth.fill_module_(model)
-    if args.precision != "bf16":
-        import icka_amd
-        icka_amd.set_precision(model, args.precision)
+    import icka_amd
+    icka_amd.set_precision(model, args.precision)   # explicit: the library default ("auto") would pick by depth
     return model.to(dev).train(), cfg
 
 
@@ -264,6 +263,9 @@ def main():
     ap.add_argument("--capture-collectives", action="store_true",
                     help="data parallel: capture the all-reduces INSIDE one hipGraph (side-stream branches) instead of the "
                          "default linear segments with eager all-reduces between them")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="single GPU: replay the grouped weight-gradient launches on a side stream behind flag waits "
+                         "instead of inside the captured graph (graph.GraphedStep(wgrad_stream=True))")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (tests the "
                                                               "RCCL path on a single GPU)")
@@ -395,9 +397,9 @@ def main():
             log("capturing the step into a hipGraph")
             if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallback below
                 raise RuntimeError("simulated capture failure")
-            gstep = GraphedStep(model, step)
+            gstep = GraphedStep(model, step, wgrad_stream=args.wgrad_stream and reducer is None)
             run_step = gstep
-            mode = "hipgraph"
+            mode = "hipgraph" + ("+wgrad-stream(%d launches)" % len(gstep.wgrad.items) if gstep.wgrad is not None else "")
         except Exception as e:  # noqa: BLE001
             log("graph capture failed (%s: %s)" % (type(e).__name__, e))
             torch.cuda.synchronize()

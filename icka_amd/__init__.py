@@ -8,7 +8,7 @@ from .modeling import (BertAttention, BertCoAttention, BertCrossAttention, BertC
                        BertCrossEncoder, BertEmbeddings, BertEncoder, BertIntermediate, BertLayer, BertLayerNorm,
                        BertModel, BertOutput, BertPooler, BertPreTrainedModel, BertSelfAttention, BertSelfEncoder,
                        BertSelfOutput, MTCCMBertForMMTokenClassificationCRF, cls_layer_both, scalar_gate_fusion,
-                       set_precision, token_ce_loss)
+                       resolved_precision, set_precision, token_ce_loss)
 from .arena import ParamArena
 from .crf import CRF
 from .lstm import BiLSTM
@@ -21,5 +21,5 @@ __all__ = ["CRF", "BiLSTM", "MTCCMBertForMMTokenClassificationCRF_gate_1", "Bert
            "BertSelfEncoder", "BertCrossEncoder", "BertCrossAttentionLayer", "BertAttention", "BertCrossAttention",
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
            "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",
-           "token_ce_loss", "set_precision", "ParamArena", "cross_modal", "PromptRobertaModel",
+           "token_ce_loss", "set_precision", "resolved_precision", "ParamArena", "cross_modal", "PromptRobertaModel",
            "GradReducer"]

@@ -93,6 +93,7 @@ class ParamArena(object):
         self._pending_final: List[Slot] = []
         self.pending_wgrad = []      # queued weight-gradient GEMM descriptors (+ keep-alive tensors), see ops._wgrad
         self.pending_reductions = []  # LayerNorm dgamma/dbeta slab reductions riding on the next grouped launch
+        self.wgrad_defer = None       # set by graph.GraphedStep(wgrad_stream=True) while it captures (ops._flush_wgrad)
         self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self._seed_ctr = 0
         self.seed_log = None     # tests: set to a list to record every seed handed out (one per dropout site call, in order)

@@ -227,6 +227,30 @@ def cls_head_bwd(dl, seq, gated, gate, cross, W, dseq, du, dcross, partials):
     return lib.icka_cls_head_bwd_slabs(M)
 
 
+class GroupedLaunch(object):
+    """A gemm_grouped call frozen into its C arrays (descriptors + slab reductions, operands kept alive) so that it can be
+    issued again and again -- on any stream -- without rebuilding anything: graph.GraphedStep(wgrad_stream=True) replays the
+    weight-gradient launches of a captured step eagerly on a side stream."""
+
+    def __init__(self, descs, reductions=None):
+        reductions = list(reductions or [])
+        self.n = len(descs)
+        self.arr = (GemmDesc * max(self.n, 1))(*descs)
+        self.red = [((_lib.SlabReduction * len(reductions[i:i + 4]))(*reductions[i:i + 4]), len(reductions[i:i + 4]))
+                    for i in range(0, len(reductions), 4)]
+        self._keep = (list(descs), reductions)
+
+    def launch(self, stream: int) -> None:
+        lib = _lib.load()
+        if not self.red:
+            if self.n:
+                check(lib.icka_gemm_grouped(self.arr, self.n, stream), "icka_gemm_grouped")
+            return
+        for i, (rarr, nr) in enumerate(self.red):   # the ABI takes 4 reductions per call; GEMMs go with the first chunk
+            check(lib.icka_gemm_grouped_ex(self.arr if i == 0 else None, self.n if i == 0 else 0, rarr, nr, stream),
+                  "icka_gemm_grouped_ex")
+
+
 def gemm_grouped(descs, reductions=None) -> None:
     """Launch several GEMMs (gemm_desc results) at once; same-layout fast-path problems share one launch.
     ``reductions``: slab_reduction descriptors (at most 4) summed by extra blocks of the same launch."""

@@ -92,12 +92,16 @@ def _add_mask2d(mask: torch.Tensor, B: int, T: int) -> torch.Tensor:
     return mask.reshape(B, T).contiguous()
 
 
-PRECISIONS = ("bf16", "mixed16", "fp32")
+PRECISIONS = ("auto", "bf16", "mixed16", "fp32")
+AUTO_MIXED16_DEPTH = 12     # "auto": stacks deeper than this run mixed16 (pure bf16 exceeds the 2e-2 logit bar at 24 layers)
 
 
 def set_precision(module: nn.Module, precision: str) -> nn.Module:
     """Select the arithmetic of every icka block under ``module``:
-    "bf16" (default): bf16 MFMA operands, f32 accumulation / statistics / residual stream -- the product path;
+    "auto" (the default of a module nobody called set_precision on): "mixed16" for stacks of more than 12 encoder layers
+               (``config.num_hidden_layers``; bert-large, BASELINE config c4, measures 2.2e-2 .. 2.5e-2 in pure bf16,
+               above north_star's 2e-2, and 3.8e-3 in mixed16), "bf16" otherwise;
+    "bf16": bf16 MFMA operands, f32 accumulation / statistics / residual stream -- the product path up to 12 layers;
     "mixed16": the FORWARD GEMMs of the encoder layers read IEEE fp16 operands (activations: an fp16 copy that is also
                the residual stream; weights: an fp16 shadow of the masters) on v_mfma_f32_16x16x32_f16 -- 11 significand
                bits instead of 8, same MFMA rate -- and so do the gate GEMM and the classifier of the gated head; q/k/v, the
@@ -113,12 +117,22 @@ def set_precision(module: nn.Module, precision: str) -> nn.Module:
     return module
 
 
+def resolved_precision(module: nn.Module) -> str:
+    """The arithmetic mode ``module`` runs in: its ``icka_precision`` ("auto" when set_precision was never called), with
+    "auto" resolved from the depth of the stack the module belongs to (its ``config.num_hidden_layers``)."""
+    p = getattr(module, "icka_precision", "auto")
+    if p != "auto":
+        return p
+    depth = getattr(getattr(module, "config", None), "num_hidden_layers", 0) or 0
+    return "mixed16" if depth > AUTO_MIXED16_DEPTH else "bf16"
+
+
 def _is_exact(module: nn.Module) -> bool:
-    return getattr(module, "icka_precision", "bf16") == "fp32"
+    return getattr(module, "icka_precision", "auto") == "fp32"
 
 
 def _is_mixed(module: nn.Module) -> bool:
-    return getattr(module, "icka_precision", "bf16") == "mixed16"
+    return resolved_precision(module) == "mixed16"
 
 
 def _dims(config, B, S, R, train: bool, exact: bool = False, mixed: bool = False) -> ops.Dims:

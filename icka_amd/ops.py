@@ -84,7 +84,13 @@ def _flush_wgrad(A: ParamArena) -> None:
     """One grouped launch for the block's queued weight gradients; the LayerNorm dgamma / dbeta slab reductions queued
     by _ln_bwd_deferred are summed by extra blocks of the same launch."""
     if A.pending_wgrad or A.pending_reductions:
-        K.gemm_grouped([t[0] for t in A.pending_wgrad], reductions=A.pending_reductions)
+        if A.wgrad_defer is not None:
+            # graph.GraphedStep(wgrad_stream=True) is capturing: the launch is not put into the graph -- it is replayed
+            # on a side stream behind a flag that a node of the graph raises here (the weight gradients have no consumer
+            # inside backward, so they can fill the CUs the dependent chain of backward leaves idle)
+            A.wgrad_defer.defer(K.GroupedLaunch([t[0] for t in A.pending_wgrad], A.pending_reductions), A.pending_wgrad)
+        else:
+            K.gemm_grouped([t[0] for t in A.pending_wgrad], reductions=A.pending_reductions)
         A.pending_wgrad = []
         A.pending_reductions = []
 
@@ -93,6 +99,8 @@ def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres
     """LayerNorm backward of a block: rows now, the parameter-gradient finalize with the block's weight-gradient launch
     (saves one launch per LayerNorm).  ``tag`` keeps the slab workspaces of one block apart."""
     H = dy.shape[1]
+    if A.wgrad_defer is not None:   # the slab reduction runs later, on another stream: every LayerNorm keeps its own slabs
+        tag = "%s:%d" % (tag, id(norm))
     ws = A.workspace(tag, K._lib.load().icka_ln_bwd_workspace_floats(H))
     acc = A.grad_beta((norm.weight, norm.bias)) > 0
     nslab = K.ln_bwd_slabs(dy, xhat, rstd, norm.weight, ws, dy2=dy2, dres=dres, dx=dx, p_drop=p_drop, seed=seed)

@@ -103,7 +103,7 @@ def _both_modes(tag, cfgkw, B, S, R, seed, grad_bf16, grad_fp32, fp8=False, logi
     if fp8:
         for layer in model.txt2img_attention.layer:
             layer.attention.self.fp8_scores = True
-    m16 = copy.deepcopy(model).cuda()
+    m16 = icka_amd.set_precision(copy.deepcopy(model).cuda(), "bf16")   # explicit: "auto" picks mixed16 beyond 12 layers
     err, _ = _compare(tag + " bf16" + ("+fp8 cross" if fp8 else ""), m16, P, ref, rloss, batch, logit_bf16, grad_bf16)
     if err >= LOGIT_TOL_BF16:
         print("  [%s bf16] NOTE: %.3e exceeds north_star's 2e-2 bf16 tolerance (known gap at this depth; bar used %.1e)"
