@@ -263,9 +263,6 @@ def main():
     ap.add_argument("--capture-collectives", action="store_true",
                     help="data parallel: capture the all-reduces INSIDE one hipGraph (side-stream branches) instead of the "
                          "default linear segments with eager all-reduces between them")
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="single GPU: replay the grouped weight-gradient launches on a side stream behind flag waits "
-                         "instead of inside the captured graph (graph.GraphedStep(wgrad_stream=True))")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (tests the "
                                                               "RCCL path on a single GPU)")
@@ -397,9 +394,9 @@ def main():
             log("capturing the step into a hipGraph")
             if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallback below
                 raise RuntimeError("simulated capture failure")
-            gstep = GraphedStep(model, step, wgrad_stream=args.wgrad_stream and reducer is None)
+            gstep = GraphedStep(model, step)
             run_step = gstep
-            mode = "hipgraph" + ("+wgrad-stream(%d launches)" % len(gstep.wgrad.items) if gstep.wgrad is not None else "")
+            mode = "hipgraph"
         except Exception as e:  # noqa: BLE001
             log("graph capture failed (%s: %s)" % (type(e).__name__, e))
             torch.cuda.synchronize()

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("alpha", c_f32), ("beta", c_f32),
         ("epilogue", c_i32),
         ("colsum_out", c_vp), ("colsum_accumulate", c_i32),
-        ("ab_f16", c_i32), ("C3", c_vp), ("ldc3", c_i64), ("aux_f16", c_i32),
+        ("ab_f16", c_i32), ("C3", c_vp), ("ldc3", c_i64), ("aux_f16", c_i32), ("c3_only", c_i32),
     ]
 
 

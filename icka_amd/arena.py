@@ -93,7 +93,6 @@ class ParamArena(object):
         self._pending_final: List[Slot] = []
         self.pending_wgrad = []      # queued weight-gradient GEMM descriptors (+ keep-alive tensors), see ops._wgrad
         self.pending_reductions = []  # LayerNorm dgamma/dbeta slab reductions riding on the next grouped launch
-        self.wgrad_defer = None       # set by graph.GraphedStep(wgrad_stream=True) while it captures (ops._flush_wgrad)
         self._seed_base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self._seed_ctr = 0
         self.seed_log = None     # tests: set to a list to record every seed handed out (one per dropout site call, in order)
@@ -175,18 +174,21 @@ class ParamArena(object):
             return self.gflat[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
         return self.gflat[first.off:first.off + rows]
 
-    def wire_of(self, gview: torch.Tensor) -> Optional[torch.Tensor]:
-        """Data parallel with bf16 buckets (dp.GradReducer): the slice of the reducer's bf16 wire buffer that mirrors the
-        gradient view ``gview`` (a contiguous view of ``gflat``, e.g. ``g(p)`` / ``g_cat(ps)``) -- handed to a weight-
-        gradient GEMM as its second output (icka_gemm_desc.C3), so that the wire copy comes out of the GEMM epilogue.
-        None when there is no reducer, it exchanges f32, or the view is not contiguous."""
+    def wire_of(self, gview: torch.Tensor, beta: float = 0.0):
+        """Data parallel with bf16 buckets (dp.GradReducer): ``{"out3": wire, "out3_only": only}`` for kernels.gemm_desc --
+        the slice of the reducer's bf16 wire buffer that mirrors the gradient view ``gview`` (a contiguous view of ``gflat``,
+        e.g. ``g(p)`` / ``g_cat(ps)``), handed to a weight-gradient GEMM as its second output (icka_gemm_desc.C3) so that the
+        wire copy comes out of the GEMM epilogue, and whether the GEMM may skip the f32 store altogether (GradReducer.wire_view;
+        never when it accumulates, ``beta`` != 0).  Empty when there is no reducer, it exchanges f32, or the view is not
+        contiguous."""
         r = self.reducer
         if r is None or getattr(r, "gwire", None) is None or not gview.is_contiguous():
-            return None
+            return {}
         off = (gview.data_ptr() - self.gflat.data_ptr()) // 4
         if off < 0 or off + gview.numel() > self.total:
-            return None
-        return r.wire_view(off, gview.numel(), gview.shape)
+            return {}
+        wire, only = r.wire_view(off, gview.numel(), gview.shape)
+        return {"out3": wire, "out3_only": bool(only and beta == 0.0)}
 
     def _adjacent(self, ps: Sequence[nn.Parameter]):
         sl = [self.slots[id(p)] for p in ps]

@@ -52,6 +52,8 @@ struct GemmArgs {
                                 // the "mixed16" mode), or of an f32 weight gradient (the data-parallel wire copy: the value
                                 // AFTER beta-accumulation, written by the same epilogue -- dp.GradReducer)
     int aux_f16;       // the epilogue operand aux is fp16 (read through load8_aux / load4_aux)
+    int c3_only;       // f32 C + C3 + beta == 0: write ONLY the bf16 wire copy C3 (the f32 value is produced later, from the
+                       // reduced wire buffer, by icka_dp_cast_back_scaled): the epilogue stores 2 bytes per element, not 4 + 2
     // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
     // output pixel m and the reduction index is k = tap * cvC + c -- the loader waves compute the patch addresses, no
     // patch matrix exists.  cvZero: at least 128 B of zeros for the taps that fall off the image / rows past cvRows.
@@ -210,7 +212,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& g, int m, int n, f32x4
             if (r < nvalid) atomicAdd(p + r, v[r]);
         return;
     }
-    if (g.c_f32) {
+    if (g.c_f32 && g.c3_only) {
+        store4_bf16(g.C3, g.ldc3, m, n, nvalid, v);
+    } else if (g.c_f32) {
         float* p = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n;
         if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
             f32x4 o = {v[0], v[1], v[2], v[3]};
@@ -588,8 +592,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 o0 += g.beta * ld_once(reinterpret_cast<const f32x4*>(p));
                 o1 += g.beta * ld_once(reinterpret_cast<const f32x4*>(p + 4));
             }
-            st_out(reinterpret_cast<f32x4*>(p), o0);
-            st_out(reinterpret_cast<f32x4*>(p + 4), o1);
+            if (!g.c3_only) {
+                st_out(reinterpret_cast<f32x4*>(p), o0);
+                st_out(reinterpret_cast<f32x4*>(p + 4), o1);
+            }
             if (g.C3) {
                 const float w[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
                 store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, w);
@@ -1103,7 +1109,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                     const int m = m0 + wr + 16 * mi + (lane & 15);
                     const f32x4 v = acc[mi][ni] * g.alpha + b4;
                     if (g.c_f32) {
-                        st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
+                        if (!g.c3_only) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
                         if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
                     } else st_out(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
                                 pack4(v[0], v[1], v[2], v[3]));
@@ -1499,6 +1505,8 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     if (g.f16 && d->op != ICKA_GEMM_NT) return ICKA_E_ARG;       // fp16 operands: forward (NT) GEMMs only
     if (g.c_f16 && d->beta != 0.f) return ICKA_E_ARG;              // fp16 outputs are never accumulated into
     if (g.C3 && !g.c_f16 && !g.c_f32) return ICKA_E_ARG;           // C3 = bf16 twin of an fp16 or an f32 main output
+    g.c3_only = d->c3_only != 0;
+    if (g.c3_only && !(g.C3 && g.c_f32 && d->beta == 0.f && d->epilogue == ICKA_EPI_NONE)) return ICKA_E_ARG;
     if (g.c_f16 && d->colsum_out) return ICKA_E_ARG;
     g.abl = g_abl;
     g.stamp = g_stamp;
@@ -1767,7 +1775,7 @@ __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, 
             f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
             f32x4 v = acc[mi][ni] * g.alpha;
             if (g.beta != 0.f) v += g.beta * ld_once(dst);   // gradient accumulation across micro-batches
-            st_out(dst, v);
+            if (!g.c3_only) st_out(dst, v);
             if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
         }
     }
@@ -1897,7 +1905,7 @@ __device__ __forceinline__ void gemm_big12_tn_body(const GemmArgs& g, char* smem
             f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
             f32x4 v = acc[mi][ni] * g.alpha;
             if (g.beta != 0.f) v += g.beta * ld_once(dst);
-            st_out(dst, v);
+            if (!g.c3_only) st_out(dst, v);
             if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
         }
     }

@@ -90,6 +90,7 @@ class GradReducer(object):
         # ---- bf16 wire buffer (module docstring)
         self.gwire = None
         self._wire_ranges = set()                 # (offset, numel) of gradients whose wire copy a GEMM epilogue writes
+        self._wire_only = set()                   # ... those of them that are written once per step (see wire_view)
         self._tables: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         if self.comm_bf16:
             self.gwire = torch.zeros(arena.total, dtype=torch.bfloat16, device=arena.device)
@@ -113,13 +114,17 @@ class GradReducer(object):
         self.arena.mark_dirty()
 
     # ------------------------------------------------------------------------------------------------- wire copies
-    def wire_view(self, off: int, numel: int, shape) -> Optional[torch.Tensor]:
-        """The bf16 wire slice [off, off + numel) shaped like the gradient view a GEMM is about to write (ParamArena.wire_of);
-        noted, so that the bucket's cast launch skips it once calibration is over."""
+    def wire_view(self, off: int, numel: int, shape):
+        """(wire, only): the bf16 wire slice [off, off + numel) shaped like the gradient view a GEMM is about to write
+        (ParamArena.wire_of) -- noted, so that the bucket's cast launch skips it once calibration is over -- and whether the
+        GEMM may store ONLY the wire copy (icka_gemm_desc.c3_only): after calibration, for gradients written exactly once
+        per step.  Their f32 value is produced by the cast-back of the reduced bucket, which every step of a reducer runs
+        before anything reads the gradient buffer; the 4-byte store of a value nobody reads is dropped from the epilogue."""
         if self.gwire is None:
-            return None
-        self._wire_ranges.add((off, numel))
-        return self.gwire[off:off + numel].view(shape)
+            return None, False
+        key = (off, numel)
+        self._wire_ranges.add(key)
+        return self.gwire[off:off + numel].view(shape), key in self._wire_only
 
     def _build_tables(self) -> None:
         """Chunk tables of what still has to be cast per bucket: the bucket minus the ranges GEMM epilogues fill."""
@@ -137,6 +142,21 @@ class GradReducer(object):
             if cur < hi:
                 ranges.append((cur, hi))
             self._tables[bi] = K.dp_chunk_table(ranges, self.arena.device)
+        # gradients written exactly once per step may drop their f32 store (wire_view)
+        once = {}
+        for s in self.arena.order:
+            once[s.off] = (s, self._expected.get(id(s), 0) == 1)
+        self._wire_only = set()
+        for off, n in wired:
+            ok, cur = True, off
+            while cur < off + n:                      # every slot the range covers (fused q|k|v: three)
+                ent = once.get(cur)
+                if ent is None or not ent[1]:
+                    ok = False
+                    break
+                cur += (ent[0].numel + 7) // 8 * 8
+            if ok and cur >= off + n:
+                self._wire_only.add((off, n))
 
     def cast_elements(self) -> int:
         """Elements per step that still go through the cast launches (diagnostics / DESIGN.md)."""
@@ -247,13 +267,14 @@ class GradReducer(object):
     def finish(self) -> None:
         """Launch every bucket not launched yet (parameters that got no gradient this step keep their bucket
         waiting until here) and make the compute stream wait for the reductions."""
+        if not self._calibrated and self.gwire is not None:
+            self._build_tables()      # the calibration step has shown which gradients GEMM epilogues copy to the wire:
+                                      # the casts below (and of every later step) leave those ranges alone
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch(bi)
         if self.capture is None:
             self.join()
-        if not self._calibrated and self.gwire is not None:
-            self._build_tables()      # the calibration step has shown which gradients GEMM epilogues copy to the wire
         self._calibrated = True
         # parameters that never receive a gradient (e.g. the pooler when only logits are used) are not waited for
         self._seen = {}

@@ -34,43 +34,13 @@ import torch
 from . import kernels as K
 
 
-class _WgradDefer(object):
-    """Capture-time recorder of ``GraphedStep(wgrad_stream=True)`` (ops._flush_wgrad): every grouped weight-gradient launch
-    of the step becomes a flag-set node in the graph + a frozen launch (kernels.GroupedLaunch) for the side stream."""
-
-    def __init__(self, sync_words: torch.Tensor, flag0: int):
-        self.sync, self.flag0 = sync_words, flag0
-        self.items = []      # (GroupedLaunch, device address of its flag word)
-        self.keep = []       # operands of the deferred launches: graph-pool tensors that must never be handed out again
-
-    def defer(self, launch, pending) -> None:
-        k = len(self.items)
-        if self.flag0 + k >= self.sync.numel():
-            raise RuntimeError("GraphedStep(wgrad_stream=True): more than %d deferred launches" % (self.sync.numel() - self.flag0))
-        flag = self.sync.data_ptr() + 4 * (self.flag0 + k)
-        K.check(K._lib.load().icka_dp_flag_set(flag, self.sync.data_ptr(), K._stream()), "icka_dp_flag_set")
-        self.items.append((launch, flag))
-        self.keep.append(pending)
-
-
 class GraphedStep(object):
-    WG_FLAG0 = 16          # sync words of the wgrad_stream form: [0] step counter, [WG_FLAG0 + k] flag of deferred launch k
-    WG_POLLS = 1 << 20
-
-    def __init__(self, model: torch.nn.Module, step_fn: Callable[[], torch.Tensor], warmup: int = 3,
-                 wgrad_stream: bool = False):
+    def __init__(self, model: torch.nn.Module, step_fn: Callable[[], torch.Tensor], warmup: int = 3):
         """``step_fn`` runs forward + backward (+ gradient all-reduce launches) and returns the loss tensor.
-        ``wgrad_stream``: the grouped weight-gradient launches (dW = dY^T . X, bias column sums, LayerNorm parameter
-        reductions) are taken OUT of the captured graph: a node of the graph raises a flag word where each of them
-        becomes possible, and every replay issues them eagerly on a side stream, each behind a one-wave flag-wait kernel
-        (icka_dp_flag_wait) -- the tagged-word hand-off FlaggedStep uses for the gradient buckets.  Weight gradients have
-        no consumer inside backward: on their own stream they run beside the dependent chain of backward (whose grids
-        are one round of the CUs each, with nothing to overlap their prologues, epilogues and launch boundaries)
-        instead of in series with it."""
+        (Replaying the grouped weight-gradient launches on a side stream behind flag waits, beside the dependent chain of
+        backward, was built and measured in round 3: -0.6 %, inside the noise -- profiles/r03_wgrad_side_stream.txt.)"""
         dev = next(model.parameters()).device
         self.model = model
-        self.wgrad = None
-        self.wg_side = None
         self.nonce = torch.zeros(2, dtype=torch.int32, device=dev)
         K.set_dropout_nonce(self.nonce)
         side = torch.cuda.Stream(device=dev)
@@ -85,23 +55,11 @@ class GraphedStep(object):
         self.arena = model._icka_arena
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
-        if wgrad_stream:
-            self.sync = torch.zeros(self.WG_FLAG0 + 240, dtype=torch.int32, device=dev)
-            K.check(K._lib.load().icka_dp_init(), "icka_dp_init")
-            self.wgrad = _WgradDefer(self.sync, self.WG_FLAG0)
-            self.wg_side = torch.cuda.Stream(device=dev)
-            self._tag = 0
-            self.arena.wgrad_defer = self.wgrad
         # thread_local: only this thread's calls are checked against the capture -- with a process group alive, RCCL's
         # watchdog / heartbeat threads make runtime calls of their own that must not invalidate it
-        try:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                if wgrad_stream:
-                    K.check(K._lib.load().icka_dp_step_bump(self.sync.data_ptr(), K._stream()), "icka_dp_step_bump")
-                K.bump_dropout_nonce(self.nonce)
-                self.loss = step_fn()
-        finally:
-            self.arena.wgrad_defer = None
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            K.bump_dropout_nonce(self.nonce)
+            self.loss = step_fn()
         self._grad_slots = [s for s in self.arena.order if s.live]
 
     def __call__(self) -> torch.Tensor:
@@ -112,20 +70,7 @@ class GraphedStep(object):
         # a persistent LSTM launch of an EARLIER replay that gave up a hand-off (NaN-poisoned outputs): raise at this host
         # touch-point (a host read of a mapped word, no synchronisation)
         K.lstm_check_error("detected before a GraphedStep replay")
-        if self.wgrad is None:
-            self.graph.replay()
-        else:
-            K.dp_check_error("detected before a GraphedStep replay")
-            self._tag += 1                      # == the step counter the graph's first node is about to write
-            self.graph.replay()
-            lib = K._lib.load()
-            tag = self._tag & 0xFFFFFFFF
-            with torch.cuda.stream(self.wg_side):
-                st = K._stream()
-                for launch, flag in self.wgrad.items:
-                    K.check(lib.icka_dp_flag_wait(flag, tag, None, self.WG_POLLS, st), "icka_dp_flag_wait")
-                    launch.launch(st)
-            torch.cuda.current_stream().wait_stream(self.wg_side)
+        self.graph.replay()
         self.arena.attach_grads(self._grad_slots)   # replay runs no Python: p.grad may have been dropped by zero_grad
         return self.loss
 

@@ -95,7 +95,7 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
               alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
               B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
               colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False,
-              out3: Optional[torch.Tensor] = None) -> GemmDesc:
+              out3: Optional[torch.Tensor] = None, out3_only: bool = False) -> GemmDesc:
     """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched).
     Operands are bf16, or -- op NT only, the "mixed16" forward GEMMs -- both fp16; ``out`` may then be fp16 too, with
     ``out3`` an optional bf16 copy of it.  With an f32 ``out``, ``out3`` is the data-parallel wire copy (bf16 of the final,
@@ -138,6 +138,9 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
     d.A2, d.lda2, d.B2, d.ldb2 = _ptr(A2), _ld(A2), _ptr(B2), _ld(B2)
     d.C, d.ldc, d.c_is_f32 = out.data_ptr(), out.stride(0), {BF16: 0, F32: 1, F16: 2}[out.dtype]
     d.ab_f16, d.C3, d.ldc3 = int(odt == F16), _ptr(out3), _ld(out3)
+    if out3_only and not (out3 is not None and out.dtype == F32 and beta == 0.0 and epilogue == EPI_NONE):
+        raise ValueError("out3_only: an f32 output with a wire copy, beta == 0, no epilogue")
+    d.c3_only = int(bool(out3_only))
     if out2 is not None:
         _mat(out2, "out2")
     d.C2, d.ldc2 = _ptr(out2), _ld(out2)
@@ -225,30 +228,6 @@ def cls_head_bwd(dl, seq, gated, gate, cross, W, dseq, du, dcross, partials):
                                 cross.data_ptr(), W.data_ptr(), dseq.data_ptr(), du.data_ptr(), dcross.data_ptr(),
                                 partials.data_ptr(), M, H, Cn, _stream()), "icka_cls_head_bwd")
     return lib.icka_cls_head_bwd_slabs(M)
-
-
-class GroupedLaunch(object):
-    """A gemm_grouped call frozen into its C arrays (descriptors + slab reductions, operands kept alive) so that it can be
-    issued again and again -- on any stream -- without rebuilding anything: graph.GraphedStep(wgrad_stream=True) replays the
-    weight-gradient launches of a captured step eagerly on a side stream."""
-
-    def __init__(self, descs, reductions=None):
-        reductions = list(reductions or [])
-        self.n = len(descs)
-        self.arr = (GemmDesc * max(self.n, 1))(*descs)
-        self.red = [((_lib.SlabReduction * len(reductions[i:i + 4]))(*reductions[i:i + 4]), len(reductions[i:i + 4]))
-                    for i in range(0, len(reductions), 4)]
-        self._keep = (list(descs), reductions)
-
-    def launch(self, stream: int) -> None:
-        lib = _lib.load()
-        if not self.red:
-            if self.n:
-                check(lib.icka_gemm_grouped(self.arr, self.n, stream), "icka_gemm_grouped")
-            return
-        for i, (rarr, nr) in enumerate(self.red):   # the ABI takes 4 reductions per call; GEMMs go with the first chunk
-            check(lib.icka_gemm_grouped_ex(self.arr if i == 0 else None, self.n if i == 0 else 0, rarr, nr, stream),
-                  "icka_gemm_grouped_ex")
 
 
 def gemm_grouped(descs, reductions=None) -> None:

@@ -75,22 +75,16 @@ def _wgrad(A: ParamArena, dy, x, gout, beta: float, bias=None) -> None:
             K.colsum(dy, bout, csw, accumulate=bacc)
             bout = None
     # data parallel with bf16 buckets: the same epilogue writes the bf16 wire copy of the gradient (ParamArena.wire_of)
-    wire = A.wire_of(gout)
+    wire = A.wire_of(gout, beta)
     A.pending_wgrad.append((K.gemm_desc(K.GEMM_TN, dy, x, gout, beta=beta, colsum_out=bout, colsum_accumulate=bacc,
-                                        out3=wire), dy, x, gout, bout, wire))
+                                        **wire), dy, x, gout, bout, wire))
 
 
 def _flush_wgrad(A: ParamArena) -> None:
     """One grouped launch for the block's queued weight gradients; the LayerNorm dgamma / dbeta slab reductions queued
     by _ln_bwd_deferred are summed by extra blocks of the same launch."""
     if A.pending_wgrad or A.pending_reductions:
-        if A.wgrad_defer is not None:
-            # graph.GraphedStep(wgrad_stream=True) is capturing: the launch is not put into the graph -- it is replayed
-            # on a side stream behind a flag that a node of the graph raises here (the weight gradients have no consumer
-            # inside backward, so they can fill the CUs the dependent chain of backward leaves idle)
-            A.wgrad_defer.defer(K.GroupedLaunch([t[0] for t in A.pending_wgrad], A.pending_reductions), A.pending_wgrad)
-        else:
-            K.gemm_grouped([t[0] for t in A.pending_wgrad], reductions=A.pending_reductions)
+        K.gemm_grouped([t[0] for t in A.pending_wgrad], reductions=A.pending_reductions)
         A.pending_wgrad = []
         A.pending_reductions = []
 
@@ -99,8 +93,6 @@ def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres
     """LayerNorm backward of a block: rows now, the parameter-gradient finalize with the block's weight-gradient launch
     (saves one launch per LayerNorm).  ``tag`` keeps the slab workspaces of one block apart."""
     H = dy.shape[1]
-    if A.wgrad_defer is not None:   # the slab reduction runs later, on another stream: every LayerNorm keeps its own slabs
-        tag = "%s:%d" % (tag, id(norm))
     ws = A.workspace(tag, K._lib.load().icka_ln_bwd_workspace_floats(H))
     acc = A.grad_beta((norm.weight, norm.bias)) > 0
     nslab = K.ln_bwd_slabs(dy, xhat, rstd, norm.weight, ws, dy2=dy2, dres=dres, dx=dx, p_drop=p_drop, seed=seed)
@@ -479,10 +471,11 @@ class LinearFn(torch.autograd.Function):
             dyv = K.tanh_bwd(dyv if dyv.is_contiguous() else dyv.contiguous(), y, torch.empty_like(y))
         fused = lin.bias is not None and N % 128 == 0 and x.shape[1] % 128 == 0 and M % 64 == 0
         gw = A.g(lin.weight)
-        K.gemm(K.GEMM_TN, dyv, x, gw, beta=A.grad_beta(lin.weight),
+        beta_w = A.grad_beta(lin.weight)
+        K.gemm(K.GEMM_TN, dyv, x, gw, beta=beta_w,
                colsum_out=A.g(lin.bias) if fused else None,
                colsum_accumulate=fused and A.grad_beta(lin.bias) > 0,   # bias gradient inside the wgrad GEMM
-               out3=A.wire_of(gw))                                       # + the data-parallel wire copy
+               **A.wire_of(gw, beta_w))                                  # + the data-parallel wire copy
         if lin.bias is not None and not fused:
             csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(N))
             K.colsum(dyv, A.g(lin.bias), csw, accumulate=A.grad_beta(lin.bias) > 0)

@@ -81,6 +81,9 @@ typedef struct icka_gemm_desc {
     int32_t ab_f16;
     void* C3; int64_t ldc3;
     int32_t aux_f16;       /* the epilogue operand `aux` is fp16 instead of bf16 (mixed16 gate: sigmoid(.) * cross_fp16) */
+    int32_t c3_only;       /* f32 C with a wire copy C3, beta == 0, no epilogue: store ONLY C3 (2 bytes per element instead of
+                              4 + 2); C is left untouched -- icka_amd/dp.py writes it from the reduced wire buffer
+                              (icka_dp_cast_back_scaled), which is the only consumer of such a gradient before that point */
 } icka_gemm_desc;
 int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that
