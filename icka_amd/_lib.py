@@ -134,6 +134,8 @@ PROTOTYPES = {
     "icka_additive_mask": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),
     "icka_dropout": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_u64, c_vp]),
     "icka_regions_to_tokens": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_regions_to_tokens_h": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_sample_gate_fwd_h": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "icka_colsum": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_colsum_workspace_floats": (c_i64, [c_i32]),
     "icka_gate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),

@@ -130,7 +130,7 @@ __global__ void attn_dropout_mask_kernel(float* out, int64_t rows, int Skv, Drop
 
 // layout 1: src f32 [B, C, R] -> dst bf16 [B, R, C]; one block per (b, 64-channel strip), transposed through LDS
 __global__ __launch_bounds__(256) void regions_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B,
-                                                        int R, int C) {
+                                                        int R, int C, _Float16* __restrict__ dsth = nullptr) {
     extern __shared__ float tile[];  // [64][R+1]
     const int strips = (C + 63) / 64;
     const int b = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 64;
@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void regions_t_kernel(const float* __restrict_
     __syncthreads();
     for (int i = threadIdx.x; i < R * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
-        if (c < nc) dst[((int64_t)b * R + r) * C + c0 + c] = f2bf(tile[c * (R + 1) + r]);
+        if (c < nc) {
+            const float v = tile[c * (R + 1) + r];
+            dst[((int64_t)b * R + r) * C + c0 + c] = f2bf(v);
+            if (dsth) dsth[((int64_t)b * R + r) * C + c0 + c] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);   // "mixed16" twin
+        }
     }
 }
 
@@ -475,6 +479,19 @@ extern "C" int icka_regions_to_tokens(const float* src, void* dst, int32_t B, in
     if (layout != 1) return ICKA_E_ARG;
     hipLaunchKernelGGL(regions_t_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 64 * (R + 1) * sizeof(float),
                        (hipStream_t)stream, src, (bf16_t*)dst, B, R, C);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+/* "mixed16": region tokens in both 16-bit types in one pass over the f32 features (the fp16 copy is the forward operand of
+   the region projection, the bf16 copy the operand of its weight gradient). */
+extern "C" int icka_regions_to_tokens_h(const float* src, void* dst_bf16, void* dst_f16, int32_t B, int32_t R, int32_t C,
+                                        int32_t layout, void* stream) {
+    if (!src || !dst_bf16 || !dst_f16) return ICKA_E_ARG;
+    if (B <= 0 || R <= 0 || C <= 0 || R > 256) return ICKA_E_SHAPE;
+    if (layout == 0) return icka_cast_f32_to_bf16_f16(src, dst_bf16, dst_f16, (int64_t)B * R * C, stream);
+    if (layout != 1) return ICKA_E_ARG;
+    hipLaunchKernelGGL(regions_t_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 64 * (R + 1) * sizeof(float),
+                       (hipStream_t)stream, src, (bf16_t*)dst_bf16, B, R, C, (_Float16*)dst_f16);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -68,6 +68,32 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const bf16_t* __restrict_
     }
 }
 
+// "mixed16" form of mode 1 (the relevance-scaled cross stream of the gate_cl head, gate_cl_modeling.py:1369-1373): the fp16
+// twin of the stream in, g * a out in BOTH 16-bit types -- fp16 (operand of the gate GEMM and the classifier) and bf16 (what
+// the backward reads) -- from the f32 product, so the fp16 copy carries no bf16 rounding
+__global__ __launch_bounds__(256) void gate_fwd_h_kernel(const _Float16* __restrict__ a, int64_t lda,
+                                                         const float* __restrict__ gate, int mode,
+                                                         bf16_t* __restrict__ out, _Float16* __restrict__ out16, int64_t ldo,
+                                                         int S, int H) {
+    const int b = blockIdx.y;
+    const float g = sample_gate(gate, b, mode);
+    const int cpr = H >> 3, total = S * cpr;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int s = i / cpr, ch = (i - s * cpr) * 8;
+        const int64_t row = (int64_t)b * S + s;
+        const f16x8 xv = *reinterpret_cast<const f16x8*>(a + row * lda + ch);
+        float x[8];
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[e] = g * (float)xv[e];
+            h[e] = (_Float16)fminf(fmaxf(x[e], -65504.f), 65504.f);
+        }
+        st8(out + row * ldo + ch, x);
+        *reinterpret_cast<f16x8*>(out16 + row * ldo + ch) = h;
+    }
+}
+
 // backward of the above: da = g*dout ; dc = (1-g)*dout (mode 0 with c) ;
 // dgate: mode 0: dgate[b] += g(1-g) * sum dout*(a-c) ; mode 1: dgate[b,1] += t, dgate[b,0] -= t, t = g(1-g)*sum dout*a
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict__ dout, int64_t lddo,
@@ -227,6 +253,16 @@ extern "C" int icka_sample_gate_fwd(const void* a, int64_t lda, const void* c, i
     return 0;
 }
 
+extern "C" int icka_sample_gate_fwd_h(const void* a16, int64_t lda, const float* gate, int32_t mode, void* out, void* out16,
+                                      int64_t ldo, int32_t B, int32_t S, int32_t H, void* stream) {
+    if (!a16 || !gate || !out || !out16) return ICKA_E_ARG;
+    if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || (mode != 0 && mode != 1)) return ICKA_E_SHAPE;
+    if (!ok16(a16, lda) || !ok16(out, ldo) || !ok16(out16, ldo)) return ICKA_E_ALIGN;
+    hipLaunchKernelGGL(gate_fwd_h_kernel, dim3(SPLIT, B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)a16, lda, gate,
+                       mode, (bf16_t*)out, (_Float16*)out16, ldo, S, H);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" int icka_sample_gate_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* c,
                                     int64_t ldc, const float* gate, int32_t mode, void* da, int64_t ldda, void* dc,
                                     int64_t lddc, float* dgate, int32_t B, int32_t S, int32_t H, void* stream) {

@@ -652,6 +652,15 @@ def regions_to_tokens(src: torch.Tensor, dst: torch.Tensor, B: int, R: int, Cc: 
     return dst
 
 
+def regions_to_tokens_h(src: torch.Tensor, dst: torch.Tensor, dst16: torch.Tensor, B: int, R: int, Cc: int, layout: int) -> None:
+    """regions_to_tokens with an fp16 twin of the tokens (the "mixed16" operand of the region projection)."""
+    _dev(src, "src"); _dev(dst, "dst"); _dev(dst16, "dst16")
+    if src.dtype != F32 or not src.is_contiguous() or dst.dtype != BF16 or dst16.dtype != F16:
+        raise TypeError("regions_to_tokens_h: contiguous f32 features, bf16 + fp16 token buffers")
+    check(_lib.load().icka_regions_to_tokens_h(src.data_ptr(), dst.data_ptr(), dst16.data_ptr(), B, R, Cc, layout, _stream()),
+          "icka_regions_to_tokens_h")
+
+
 def colsum_workspace(N: int, device) -> torch.Tensor:
     return torch.empty(_lib.load().icka_colsum_workspace_floats(N), dtype=F32, device=device)
 
@@ -809,6 +818,17 @@ def sample_gate_fwd(a, c, gate, mode, out, B, S):
     H = a.shape[1]
     check(_lib.load().icka_sample_gate_fwd(a.data_ptr(), a.stride(0), _ptr(c), _ld(c), gate.data_ptr(), mode,
                                            out.data_ptr(), out.stride(0), B, S, H, _stream()), "icka_sample_gate_fwd")
+    return out
+
+
+def sample_gate_fwd_h(a16, gate, mode, out, out16, B, S):
+    """out (bf16) and out16 (fp16) = g(gate[b]) * a16 (fp16): the "mixed16" form of the gate without blend operand."""
+    _mat(a16, "a16", F16); _mat(out, "out"); _mat(out16, "out16", F16)
+    H = a16.shape[1]
+    if out.stride(0) != out16.stride(0):
+        raise ValueError("out and out16 share one row stride")
+    check(_lib.load().icka_sample_gate_fwd_h(a16.data_ptr(), a16.stride(0), gate.data_ptr(), mode, out.data_ptr(),
+                                             out16.data_ptr(), out.stride(0), B, S, H, _stream()), "icka_sample_gate_fwd_h")
     return out
 
 

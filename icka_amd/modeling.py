@@ -102,13 +102,16 @@ def set_precision(module: nn.Module, precision: str) -> nn.Module:
                (``config.num_hidden_layers``; bert-large, BASELINE config c4, measures 2.2e-2 .. 2.5e-2 in pure bf16,
                above north_star's 2e-2, and 3.8e-3 in mixed16), "bf16" otherwise;
     "bf16": bf16 MFMA operands, f32 accumulation / statistics / residual stream -- the product path up to 12 layers;
-    "mixed16": the FORWARD GEMMs of the encoder layers read IEEE fp16 operands (activations: an fp16 copy that is also
-               the residual stream; weights: an fp16 shadow of the masters) on v_mfma_f32_16x16x32_f16 -- 11 significand
-               bits instead of 8, same MFMA rate -- and so do the gate GEMM and the classifier of the gated head; q/k/v, the
-               attention kernels, the region projection and the WHOLE backward stay bf16 (no loss scaling needed: no gradient is ever held in fp16).  For deep stacks whose bf16 rounding
-               noise exceeds the 2e-2 logit bar (bert-large, BASELINE config c4).  It is implemented by the fused layer
-               Functions (BertEmbeddings, BertLayer, BertCrossAttentionLayer and the models built from them); sub-modules
-               called one by one (BertAttention, BertIntermediate, ...) and the hf_style shim keep bf16 operands;
+    "mixed16": every FORWARD GEMM of the path reads IEEE fp16 operands (activations: an fp16 copy that is also the residual
+               stream; weights: an fp16 shadow of the masters) on v_mfma_f32_16x16x32_f16 -- 11 significand bits instead
+               of 8, same MFMA rate: the encoder and cross layers (q/k/v, out-proj, FFN), the region projection (fp16 region
+               tokens made from the f32 features), the K/V projections of the cross layers (fp16 twin of the projected
+               regions), the relevance-scaled cross stream of the gate_cl head, the gate GEMM and the classifier.  The
+               OUTPUTS q / k / v (the attention kernels' operand type), the attention kernels and the WHOLE backward stay
+               bf16 (no loss scaling needed: no gradient is ever held in fp16).  For deep stacks whose bf16 rounding noise
+               exceeds the 2e-2 logit bar (bert-large, BASELINE config c4).  It is implemented by the fused layer Functions
+               (BertEmbeddings, BertLayer, BertCrossAttentionLayer and the models built from them); sub-modules called one
+               by one (BertAttention, BertIntermediate, ...) and the hf_style shim keep bf16 operands;
     "fp32": f32 storage and f32-input MFMA arithmetic (icka_amd/exact.py) for the 1e-3 parity bar of BASELINE.json."""
     if precision not in PRECISIONS:
         raise ValueError("precision must be one of %s" % (PRECISIONS,))
@@ -659,9 +662,19 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     rows_p = (B * R + 127) // 128 * 128
     tokens = torch.empty(rows_p, 2048, dtype=BF16, device=dev)
     K.zero_rows_(tokens, B * R)
-    K.regions_to_tokens(v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v, tokens, B, R,
-                        2048, layout)
-    vis = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE)
+    vsrc = v.float().contiguous() if v.dtype != F32 or not v.is_contiguous() else v
+    mixed = _is_mixed(self)
+    vis16 = None
+    if mixed:
+        # mixed16: the region projection reads fp16 tokens (made from the f32 features in the same pass as the bf16 ones)
+        # and fp16 weights, and hands the cross encoder an fp16 twin of the projected regions for its K/V projections
+        tokens16 = torch.empty(rows_p, 2048, dtype=torch.float16, device=dev)
+        K.zero_rows_(tokens16, B * R)
+        K.regions_to_tokens_h(vsrc, tokens, tokens16, B, R, 2048, layout)
+        vis, vis16 = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE, tokens16)
+    else:
+        K.regions_to_tokens(vsrc, tokens, B, R, 2048, layout)
+        vis = ops.LinearFn.apply(A.anchor, tokens, self.vismap2text, A, False, K.EPI_NONE)
     # ---- image mask (:1353-1356)
     img_mask = K.additive_mask(added_attention_mask if added_attention_mask.dtype == torch.int64
                                else added_attention_mask.long(), R, torch.empty(B, R, dtype=F32, device=dev))
@@ -675,7 +688,8 @@ def _mner_trunk(self, input_ids, segment_ids, input_mask, added_attention_mask, 
     crossf = seqf
     for layer in self.txt2img_attention.layer:
         d = _dims(cfg, B, S, R, self.training, mixed=_is_mixed(layer))
-        cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d)
+        cross, crossf = ops.CrossLayerFn.apply(A.anchor, cross, crossf, vis, layer, A, img_mask, d,
+                                               vis16 if d.h16 else None)
     return A, seq, seqf, cross, crossf
 
 
@@ -773,14 +787,21 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
                 else:
                     seq_c, cross_c = seq, cross
                 crs = ops.CrsFn.apply(A.anchor, seq_c, cross_c, self.crs_classifier, A, B, S)
-                cross = ops.SampleGateFn.apply(cross, None, crs, 1, B, S)
+                if _is_mixed(self):
+                    # mixed16: the relevance-scaled cross stream is formed from the fp16 twin of the cross encoder's output
+                    # and leaves in both 16-bit types (the relevance score itself sums 2 H S products per sample: the bf16
+                    # rounding of its operands averages out)
+                    d16 = _dims(cfg, B, S, 0, self.training, mixed=True)
+                    cross, crossf = ops.SampleGateFn.apply(cross, None, crs, 1, B, S, ops._fwd_twin(A, cross, crossf, d16))
+                else:
+                    cross = ops.SampleGateFn.apply(cross, None, crs, 1, B, S)
         # ---- gate + classifier (:1363-1371)
         if _is_exact(self):
             return X.GatedHeadFn.apply(A.anchor, seq, cross, self, A).view(B, S, self.num_labels)
         seq16 = cross16 = None
-        if _is_mixed(self) and self.variant != "gate_cl":
-            # the fp16 twins of the two streams (left by the last encoder / cross layer; made from the bf16 tensors when a
-            # dropout or fan-out node sits in between) feed the gate GEMM and the classifier
+        if _is_mixed(self):
+            # the fp16 twins of the two streams (left by the last encoder / cross layer / relevance gate; made from the bf16
+            # tensors when a dropout or fan-out node sits in between) feed the gate GEMM and the classifier
             d16 = _dims(cfg, B, S, 0, self.training, mixed=True)
             seq16 = ops._fwd_twin(A, seq, seqf, d16)
             cross16 = ops._fwd_twin(A, cross, crossf, d16)

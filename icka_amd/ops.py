@@ -104,10 +104,11 @@ def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres
 # CrossLayerFn) chain them with the gradient fan-ins fused into GEMM epilogues, the sub-module Functions further down
 # (AttnCoreFn, DenseResidualNormFn, IntermediateFn) expose the same pairs one by one for callers that compose
 # BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput themselves (as BertAttention.forward :451-454 does).
-def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, save: bool, x16=None):
+def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, save: bool, x16=None, kv16=None):
     """BertSelfAttention / BertCoAttention (:478-506, :590-624): fused projection GEMM -> fused attention kernel.
     Returns (ctx bf16 [M,H], ctx fp16 or None, saved).  x16: fp16 copy of x (mixed16) -> the projections of x read fp16
-    operands; q/k/v stay bf16 (the attention kernels' operand type), the K/V projection of ``kv_src`` stays bf16."""
+    operands; kv16: fp16 copy of ``kv_src`` -> so does the K/V projection of the co-attention; the projection OUTPUTS
+    q / k / v stay bf16 (the attention kernels' operand type)."""
     M, H = x.shape
     h16 = x16 is not None
     xa = x16 if h16 else x
@@ -122,8 +123,11 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         qkv = _empty(x, M, H)
         K.gemm(K.GEMM_NT, xa, A.w16(sa.query.weight) if h16 else A.w(sa.query.weight), qkv, bias=sa.query.bias)
         kvbuf = _empty(x, kv_src.shape[0], 2 * H)
-        K.gemm(K.GEMM_NT, kv_src, A.w_cat((sa.key.weight, sa.value.weight)), kvbuf,
-               bias=A.f_cat((sa.key.bias, sa.value.bias)))
+        wkv = (sa.key.weight, sa.value.weight)
+        if h16 and kv16 is not None:
+            K.gemm(K.GEMM_NT, kv16, A.w16_cat(wkv), kvbuf, bias=A.f_cat((sa.key.bias, sa.value.bias)))
+        else:
+            K.gemm(K.GEMM_NT, kv_src, A.w_cat(wkv), kvbuf, bias=A.f_cat((sa.key.bias, sa.value.bias)))
         q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
     ctx = _empty(x, M, H)
     ctx16 = _empty(x, M, H, dtype=F16) if h16 else None
@@ -233,13 +237,14 @@ def _inter_bwd(A: ParamArena, inter, x, dz, dres):
     return dx
 
 
-def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool):
+def _attn_block_fwd(A: ParamArena, att, x, xres, kv_src, add_mask, d: Dims, Skv: int, save: bool, kv16=None):
     """BertAttention / BertCrossAttention: projections -> fused attention -> out-proj -> bias+dropout+residual+LN.
     ``att`` is the reference-named module (``.self.{query,key,value}``, ``.output.{dense,LayerNorm}``).
     x is the bf16 MFMA operand; xres its forward twin: f32 (residual only; None -> x) or, in the mixed16 mode, fp16
     (residual AND forward GEMM operand).  Returns (y bf16, y twin, saved)."""
     xres = _fwd_twin(A, x, xres, d)
-    ctx, ctx16, s_core = _attn_core_fwd(A, att.self, x, kv_src, add_mask, d, Skv, save, x16=xres if d.h16 else None)
+    ctx, ctx16, s_core = _attn_core_fwd(A, att.self, x, kv_src, add_mask, d, Skv, save, x16=xres if d.h16 else None,
+                                        kv16=kv16 if d.h16 else None)
     y, yf, s_out = _dense_norm_fwd(A, att.output, ctx, x if xres is None else xres, d, save, h16=ctx16)
     return y, yf, ((ctx, s_core, s_out) if save else None)
 
@@ -341,9 +346,10 @@ class CrossLayerFn(torch.autograd.Function):
     """BertCrossAttentionLayer.forward (:646-650): Q from s1 (text), K/V from s2 (regions), residual = s1."""
 
     @staticmethod
-    def forward(ctx, anchor, s1, s1f, s2, layer, A: ParamArena, add_mask, d: Dims):
+    def forward(ctx, anchor, s1, s1f, s2, layer, A: ParamArena, add_mask, d: Dims, s2_16=None):
+        """s2_16 (mixed16): the fp16 twin of the key/value source (the projected regions)."""
         save = any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
-        x1, x1f, s_att = _attn_block_fwd(A, layer.attention, s1, s1f, s2, add_mask, d, d.R, save)
+        x1, x1f, s_att = _attn_block_fwd(A, layer.attention, s1, s1f, s2, add_mask, d, d.R, save, kv16=s2_16)
         x2, x2f, s_ffn = _ffn_block_fwd(A, layer, x1, x1f, d, save)
         ctx.layer, ctx.A, ctx.d, ctx.s_att, ctx.s_ffn = layer, A, d, s_att, s_ffn
         ctx.need_s2 = s2.requires_grad
@@ -361,7 +367,7 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.s_att = ctx.s_ffn = None
         _flush_wgrad(A)
         A.flush_final()
-        return None, ds1, None, ds2, None, None, None, None
+        return None, ds1, None, ds2, None, None, None, None, None
 
 
 class AttnCoreFn(torch.autograd.Function):
@@ -440,9 +446,26 @@ class LinearFn(torch.autograd.Function):
     """nn.Linear on a [tokens, in] bf16 matrix (vismap2text :958, generic dense)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, lin, A: ParamArena, out_f32: bool, epilogue: int):
+    def forward(ctx, anchor, x, lin, A: ParamArena, out_f32: bool, epilogue: int, x16=None):
+        """x16 (mixed16): the fp16 twin of x -> the GEMM reads fp16 operands (x16, the fp16 weight shadow) and returns
+        (y bf16, y fp16); the backward is the bf16 one either way."""
         M = x.shape[0]
         N = lin.weight.shape[0]
+        if x16 is not None:
+            if out_f32 or epilogue != K.EPI_NONE:
+                raise ValueError("LinearFn: the fp16-operand form is a plain bf16-output projection")
+            if A.shadow16 is None:
+                A.enable_fp16_shadow()
+                A.sync(force=True)
+            y = torch.empty(M, N, dtype=BF16, device=x.device)
+            y16 = torch.empty(M, N, dtype=F16, device=x.device)
+            K.gemm(K.GEMM_NT, x16, A.w16(lin.weight), y16, bias=lin.bias, out3=y)
+            ctx.lin, ctx.A, ctx.epi = lin, A, epilogue
+            ctx.need_dx = x.requires_grad
+            ctx.save_for_backward(x, None)
+            ctx.mark_non_differentiable(y16)
+            ctx.set_materialize_grads(False)
+            return y, y16
         y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x.device)
         if M <= 64 and not out_f32 and x.shape[1] % 128 == 0 and x.stride(0) % 8 == 0 and \
                 epilogue in (K.EPI_NONE, K.EPI_TANH):
@@ -456,7 +479,7 @@ class LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dy16=None):
         x, y = ctx.saved_tensors
         lin, A = ctx.lin, ctx.A
         M, N = dy.shape
@@ -484,7 +507,7 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             K.gemm(K.GEMM_NN, dyv, A.w(lin.weight), dx)
         A.flush_final()
-        return None, dx, None, None, None, None
+        return None, dx, None, None, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):
@@ -612,22 +635,31 @@ class SampleGateFn(torch.autograd.Function):
     (Cross_Modal_Interaction_Module.py:1035-1036); mode 1: out = softmax(gate[b])[1] * a (gate_cl_modeling.py:1369-1373)."""
 
     @staticmethod
-    def forward(ctx, a, c, gate, mode: int, B: int, S: int):
+    def forward(ctx, a, c, gate, mode: int, B: int, S: int, a16=None):
+        """a16 (mixed16, no blend operand): the fp16 twin of a -> returns (out bf16, out fp16), both from g * a16."""
         out = torch.empty_like(a)
-        K.sample_gate_fwd(a, c, gate, mode, out, B, S)
         ctx.mode, ctx.B, ctx.S = mode, B, S
         ctx.save_for_backward(a, c, gate)
+        if a16 is not None:
+            if c is not None:
+                raise ValueError("SampleGateFn: the fp16 form has no blend operand")
+            out16 = torch.empty(a.shape[0], a.shape[1], dtype=F16, device=a.device)
+            K.sample_gate_fwd_h(a16, gate, mode, out, out16, B, S)
+            ctx.mark_non_differentiable(out16)
+            ctx.set_materialize_grads(False)
+            return out, out16
+        K.sample_gate_fwd(a, c, gate, mode, out, B, S)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d16=None):
         a, c, gate = ctx.saved_tensors
         dout = _c(dout)
         da = torch.empty_like(a)
         dc = torch.empty_like(a) if c is not None else None
         dgate = torch.zeros_like(gate)
         K.sample_gate_bwd(dout, a, c, gate, ctx.mode, da, dc, dgate, ctx.B, ctx.S)
-        return da, dc, dgate, None, None, None
+        return da, dc, dgate, None, None, None, None
 
 
 class CrsFn(torch.autograd.Function):

@@ -28,7 +28,7 @@ extern "C" {
  * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive).
  * 4: round 3 -- icka_lstm_clear_error, icka_lstm_set_reserved_cus, icka_lstm_test_hooks; a hand-off wait that gives up now
  *    NaN-poisons the recurrence and raises a host-visible error word; icka_gemm_desc.C3 may accompany an f32 main output
- *    (the data-parallel wire copy); icka_dp_* (additive). */
+ *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h (additive). */
 #define ICKA_ABI_VERSION 4
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -264,6 +264,9 @@ int icka_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, void* y2, int
  * (myResnet 'att' output [B,2048,7,7] viewed [B,2048,49] and permuted, :956). */
 int icka_regions_to_tokens(const float* src, void* dst, int32_t B, int32_t R, int32_t C, int32_t layout,
                            void* stream);
+/* "mixed16": the same with an fp16 twin of the tokens written in the same pass (dst_f16, same shape). */
+int icka_regions_to_tokens_h(const float* src, void* dst_bf16, void* dst_f16, int32_t B, int32_t R, int32_t C, int32_t layout,
+                             void* stream);
 /* out[N] (+)= column sums of x[M,N] bf16 (bias gradients). */
 int icka_colsum(const void* x, int64_t ldx, float* out, float* partials, int32_t M, int32_t N, int32_t accumulate,
                 void* stream);
@@ -298,6 +301,10 @@ int64_t icka_cls_head_slab_floats(int32_t H, int32_t C);
  * Backward: da = g*dout, dc = (1-g)*dout (mode 0), and dgate (f32 [B] or [B,2], ZEROED BY THE CALLER) += its gradient. */
 int icka_sample_gate_fwd(const void* a, int64_t lda, const void* c, int64_t ldc, const float* gate, int32_t mode,
                          void* out, int64_t ldo, int32_t B, int32_t S, int32_t H, void* stream);
+/* "mixed16" forward of a per-sample gate without blend operand (mode 1 = gate_cl_modeling.py:1369-1373, cross = P * cross):
+ * a16 fp16 [B*S, H] (row stride lda) -> out bf16 and out16 fp16 (row stride ldo), both rounded from the f32 product. */
+int icka_sample_gate_fwd_h(const void* a16, int64_t lda, const float* gate, int32_t mode, void* out, void* out16, int64_t ldo,
+                           int32_t B, int32_t S, int32_t H, void* stream);
 int icka_sample_gate_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* c, int64_t ldc,
                          const float* gate, int32_t mode, void* da, int64_t ldda, void* dc, int64_t lddc, float* dgate,
                          int32_t B, int32_t S, int32_t H, void* stream);

@@ -249,3 +249,45 @@ def test_c2_train_mode_step_with_the_steps_own_dropout_masks_bf16(graphed):
 
 def test_c2_train_mode_step_with_the_steps_own_dropout_masks_fp32():
     _train_step_vs_oracle("c2 B32 S128 R36 L12 fp32", "fp32", True, LOGIT_TOL_FP32, 1e-4)
+
+
+def test_c4_logits_at_the_bench_batch_with_five_cross_layers():
+    """the c4 parity test ran at B = 4 with one cross layer while bench.py --config c4 runs B = 32 and the
+    reference CLI default is layer_num1 = 5 (My_cross_attention.py:603).  Logits of bert-large, seq 256, 50 regions, batch 32,
+    FIVE cross layers against the oracle's forward (no_grad: the gradient bars are covered at B = 4): the "auto" default
+    (-> mixed16 at 24 layers, now with fp16 operands in the region projection and the cross K/V projections as well) must
+    stay within 5e-3; the pure-bf16 figure is printed beside it."""
+    import copy
+    import icka_amd
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    from oracle import mner_oracle as O
+    B, S, R, LC = 32, 256, 50, 5
+    batch = synth.synthetic_batch(B, S, R, vocab_size=LARGE["vocab_size"], seed=19260820)
+    cfg = BertConfig(LARGE["vocab_size"], **{k: v for k, v in LARGE.items() if k != "vocab_size"})
+    model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=LC, num_labels=13, regions=R, max_seq_length=S)
+    synth.fill_module_(model)
+    P = {k: v.detach() for k, v in model.state_dict().items()}
+    t0 = time.time()
+    with torch.no_grad():
+        ref = O.mner_logits(P, O.OracleConfig(**LARGE), batch["input_ids"], batch["segment_ids"], batch["input_mask"],
+                            batch["added_attention_mask"], batch["visual_embeds_att"], LC, R)
+    print("\n  [oracle] bert-large B32 S256, %d cross layers, forward only: %.1f s" % (LC, time.time() - t0))
+    g = {k: v.cuda() for k, v in batch.items()}
+    args = (g["input_ids"], g["segment_ids"], g["input_mask"], g["added_attention_mask"], g["visual_embeds_mean"],
+            g["visual_embeds_att"])
+    errs = {}
+    for mode in ("auto", "bf16"):
+        m = copy.deepcopy(model).cuda().eval()
+        if mode != "auto":
+            icka_amd.set_precision(m, mode)
+        assert icka_amd.resolved_precision(m) == ("mixed16" if mode == "auto" else mode)
+        with torch.no_grad():
+            logits = m(*args)
+        errs[mode] = (logits.float().cpu() - ref).abs().max().item()
+        del m
+        torch.cuda.empty_cache()
+    print("  [c4 B32 S256 R50 L24, 5 cross layers] logits max abs err: default (auto -> mixed16) %.3e (bar 5e-3), pure bf16 %.3e "
+          "(north_star 2e-2)" % (errs["auto"], errs["bf16"]))
+    assert errs["auto"] < 5e-3
+    assert errs["auto"] < 0.5 * errs["bf16"]
