@@ -346,7 +346,11 @@ def main():
                               diag=args.dp_diag)
         reducer.broadcast_parameters(0)
         arena.reducer = reducer
-    opt = None if args.no_optimizer_leg else torch.optim.AdamW(model.parameters(), lr=3e-5)
+    opt = None
+    if not args.no_optimizer_leg:
+        from icka_amd.optim import ArenaAdamW
+        # the reference's update (My_cross_attention.py:743-751, :831-844): two weight-decay groups, clip at 1.0, lr 3e-5
+        opt = ArenaAdamW(model, lr=3e-5, weight_decay=0.01, max_grad_norm=1.0)
 
     def sync():
         if use_dist:
@@ -463,29 +467,40 @@ def main():
     #      reference's loop does after backward (My_cross_attention.py:831-844).  Every optimizer step is seen by the arena
     #      (global post-step hook), so each of these steps re-casts the bf16 weight shadow once -- what the library's default
     #      "always" policy does per forward -- and the figure prices the "tracked" policy's exclusion from the headline number.
-    opt_ms, opt_steps = None, 0
+    opt_ms, opt_steps, opt_torch_ms = None, 0, None
     if opt is not None:
         params = [p for p in model.parameters()]
         opt_steps = max(1, min(args.steps, args.optimizer_steps))
 
-        def opt_step():
-            if mode == "eager":
-                model.zero_grad()
-            run_step()
+        def time_update(update):
+            def one():
+                if mode == "eager":
+                    model.zero_grad()
+                run_step()
+                update()
+            for _ in range(3):
+                one()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(opt_steps):
+                one()
+            sync()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1e3 * tt.item() / opt_steps
+        opt_ms = time_update(opt.step)       # clip + AdamW on the flat arena buffers: three launches (icka_amd/optim.py)
+        log("with clip + AdamW (ArenaAdamW): %.3f ms/step over %d steps" % (opt_ms, opt_steps))
+        # the same update through the stock per-tensor optimizer, for the record (what round 2's loop would have paid)
+        from icka_amd.optim import reference_param_groups
+        topt = torch.optim.AdamW(reference_param_groups(model, 0.01), lr=3e-5)
+
+        def torch_update():
             torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
-        for _ in range(3):
-            opt_step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(opt_steps):
-            opt_step()
-        sync()
-        topt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(topt, op=dist.ReduceOp.MAX)
-        opt_ms = 1e3 * topt.item() / opt_steps
-        log("with clip + AdamW: %.3f ms/step over %d steps" % (opt_ms, opt_steps))
+            topt.step()
+        opt_torch_ms = time_update(torch_update)
+        log("with clip_grad_norm_ + torch.optim.AdamW: %.3f ms/step" % opt_torch_ms)
+        del topt
 
     # ---- roofline of the dominant kernel class (MFMA GEMMs), instrumented pass, rank 0 only, N = 1 semantics
     roof = None
@@ -563,9 +578,13 @@ def main():
         }
         if opt_ms is not None:
             out["with_optimizer_ms_per_step"] = round(opt_ms, 3)
-            out["with_optimizer"] = {"update": "clip_grad_norm_(1.0) + torch.optim.AdamW(lr=3e-5).step() over %d nn.Parameters"
-                                               % len(params), "steps": opt_steps, "shadow_casts_per_step": 1,
-                                     "samples_per_s": round(args.batch * world / (opt_ms * 1e-3), 2)}
+            out["with_optimizer"] = {"update": "icka_amd.optim.ArenaAdamW: global-norm clip at 1.0 + AdamW (two weight-decay groups, "
+                                               "lr 3e-5) over %d nn.Parameters as 4 launches on the flat arena buffers; the update "
+                                               "kernel also writes the bf16 weight shadow" % len(params),
+                                     "steps": opt_steps, "shadow_casts_per_step": 0,
+                                     "samples_per_s": round(args.batch * world / (opt_ms * 1e-3), 2),
+                                     "torch_optim_ms_per_step": None if opt_torch_ms is None else round(opt_torch_ms, 3),
+                                     "torch_optim": "clip_grad_norm_(1.0) + torch.optim.AdamW, same groups (one shadow cast per step)"}
         if cpu is not None:
             out["gpu_over_cpu"] = round(samples_per_s / cpu["value"], 1)
         sys.stdout.flush()

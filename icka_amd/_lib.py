@@ -172,6 +172,12 @@ PROTOTYPES = {
     "icka_dp_step_bump": (c_i32, [c_vp, c_vp]),
     "icka_dp_flag_set": (c_i32, [c_vp, c_vp, c_vp]),
     "icka_dp_flag_wait": (c_i32, [c_vp, C.c_uint32, c_vp, c_i32, c_vp]),
+    # ---- parameter update (csrc/optim.hip)
+    "icka_optim_chunk_elems": (c_i64, []),
+    "icka_optim_sqnorm": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "icka_optim_clip": (c_i32, [c_vp, c_i32, c_f32, c_vp, c_vp]),
+    "icka_optim_adamw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                 c_i32, c_vp]),
     # ---- fp32 "exact" mode (csrc/exact.hip)
     "icka_x_gemm": (c_i32, [C.POINTER(XGemmDesc), c_vp]),
     "icka_x_ln_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64,

@@ -28,7 +28,7 @@ extern "C" {
  * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive).
  * 4: round 3 -- icka_lstm_clear_error, icka_lstm_set_reserved_cus, icka_lstm_test_hooks; a hand-off wait that gives up now
  *    NaN-poisons the recurrence and raises a host-visible error word; icka_gemm_desc.C3 may accompany an f32 main output
- *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h (additive). */
+ *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h, icka_optim_* (additive). */
 #define ICKA_ABI_VERSION 4
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -580,6 +580,25 @@ int icka_dp_clear_error(void);
 int icka_dp_step_bump(void* step_word, void* stream);
 int icka_dp_flag_set(void* flag_word, const void* step_word, void* stream);
 int icka_dp_flag_wait(const void* flag_word, uint32_t tag, void* poison_bf16, int32_t max_polls, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The parameter update that follows backward in the reference's loop (My_cross_attention.py:831-844: clip_grad_norm_(1.0),
+ * AdamW.step() over the two weight-decay groups of :743-751) as three launches over the flat parameter / gradient / state
+ * buffers (csrc/optim.hip; icka_amd/optim.py: ArenaAdamW).  Outside the fwd+bwd metric, reported beside it.  Chunk tables as
+ * for icka_dp_cast_chunks (int64 pairs {first element, count}, counts multiples of 8, at most icka_optim_chunk_elems()).
+ *   icka_optim_sqnorm: partials[b] = sum of squares of grads over chunk b.
+ *   icka_optim_clip:   out2[0] = sqrt(sum of the n partials) (fixed order), out2[1] = min(1, max_norm / (norm + 1e-6)) --
+ *                      torch.nn.utils.clip_grad_norm_'s coefficient, left on the device (max_norm <= 0: 1).
+ *   icka_optim_adamw:  torch.optim.AdamW arithmetic for the chunks of ONE weight-decay group: p *= 1 - lr * wd;
+ *                      m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t)
+ *                      + eps), with g = grads * clip_coef[0] (clip_coef may be NULL); also writes the bf16 (and fp16) weight
+ *                      shadow of every updated element when shadow pointers are given (same element offsets). */
+int64_t icka_optim_chunk_elems(void);
+int icka_optim_sqnorm(const float* grads, const int64_t* table_dev, int32_t n_chunks, float* partials, void* stream);
+int icka_optim_clip(const float* partials, int32_t n, float max_norm, float* out2, void* stream);
+int icka_optim_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, void* shadow_f16,
+                     const int64_t* table_dev, int32_t n_chunks, const float* clip_coef, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int32_t step, void* stream);
 
 #ifdef __cplusplus
 }
