@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line with the contract's keys plus
                    GEMM launches of one step / their duration, measured live after the timed region: the launches of one
                    step are recorded and re-issued back to back between ONE pair of HIP events on the launch stream;
                    peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH); traffic = PMC bytes per launch from the committed
-                   rocprofv3 passes (profiles/r02_gemm_traffic.json).
+                   rocprofv3 passes (profiles/r0N_gemm_traffic.json, the newest one).
   cpu_baseline  -- the CPU oracle (oracle/mner_oracle.py; PyTorch CPU eager fp32, same op sequence as the reference)
                    timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -523,11 +523,14 @@ def main():
         torch.cuda.synchronize()
         flops, ms, launches, abytes = K.profile_gemm(False, reps=nprof)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        tpath = None
+        for tag in ("r03", "r02", "r01"):      # the newest committed PMC passes
+            cand = os.path.join(ROOT, "profiles", "%s_gemm_traffic.json" % tag)
+            if os.path.exists(cand):
+                tpath = cand
+                break
         # PMC passes cannot run inside this process: taken from the committed rocprofv3 runs (measured on c2 only)
-        if os.path.exists(tpath) and workload_name(args) == "c2":
+        if tpath is not None and workload_name(args) == "c2":
             tj = json.load(open(tpath))
             traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/%s (%s)" % (os.path.basename(tpath), tj["method"])
         if ms > 0:
