@@ -656,9 +656,9 @@ def test_ffn_pair_probe_equals_the_two_launches():
         torch.cuda.synchronize()
         assert torch.equal(g1, g0) and torch.equal(z1, z0) and torch.equal(o1, o0), it
     assert lib.icka_gemm_ffn_pair_error() == 0
-    # not the one-tile-per-CU case: declined
-    xs = rnd(2048, H, seed=5)
-    gs, zs = torch.empty(2048, I, dtype=BF16, device="cuda"), torch.empty(2048, I, dtype=BF16, device="cuda")
-    os_ = torch.empty(2048, H, dtype=F32, device="cuda")
+    # more tiles than CUs (the blocks of a persistent launch must all be resident): declined, nothing launched
+    xs = rnd(8192, H, seed=5)
+    gs, zs = torch.empty(8192, I, dtype=BF16, device="cuda"), torch.empty(8192, I, dtype=BF16, device="cuda")
+    os_ = torch.empty(8192, H, dtype=F32, device="cuda")
     assert not k.gemm_ffn_pair(k.gemm_desc(k.GEMM_NT, xs, W1, gs, bias=b1, epilogue=k.EPI_GELU, out2=zs),
                                k.gemm_desc(k.GEMM_NT, gs, W2, os_))
