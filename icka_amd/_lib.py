@@ -70,8 +70,6 @@ PROTOTYPES = {
     "icka_gemm_set_big_tiles": (c_i32, [c_i32]),
     "icka_gemm_set_ablation": (c_i32, [c_i32]),
     "icka_gemm_set_warp_specialized": (c_i32, [c_i32]),
-    "icka_gemm_ffn_pair": (c_i32, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), c_vp]),
-    "icka_gemm_ffn_pair_error": (c_i32, []),
     "icka_gemm_set_stamp_buffer": (c_i32, [c_vp]),
     "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
                             c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),

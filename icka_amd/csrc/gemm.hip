@@ -1339,78 +1339,6 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     gemm_w3_body<B_KM, F16, BNW>(g, smem, blockIdx.x, gridDim.x);
 }
 
-// =====================================================================================================================
-// PROBE: the forward FFN half of a layer -- ffn-up (+bias, erf-GELU, pre-activation)
-// -> ffn-down -- as ONE persistent launch of 256 blocks whose 256-row stripes hand over through counters instead of a
-// kernel boundary.  Phase 1: block b computes its 256 x 192 tile of the ffn-up GEMM (the 12-wave body above), drains its
-// stores, one lane releases (agent scope) and adds 1 to the counter of its row stripe.  Phase 2: the same block takes its
-// 128 x 96 tile of the ffn-down GEMM (the 8-wave body; waves 8..11 walk the same barriers without staging anything), one
-// lane waits until the 16 ffn-up tiles of the 256-row stripe its rows belong to have been published (bounded spin),
-// acquires, and the block runs the tile.  The last of the 16 consumers of a stripe resets its counters for the next launch.
-// Every block must be resident (256 blocks x 768 threads x 160 KiB LDS = one per CU): the launcher checks the CU count.
-// In-kernel stamps (ICKA_GEMM_STAMP builds): [0] phase-1 body, [1] publish, [2] wait, [3] phase-2 body, cycles per block.
-struct PairSync { unsigned int* ready; unsigned int* done; unsigned int* err; int tiles_per_stripe; int consumers_per_stripe; };
-template <int DUMMY = 0>
-__global__ __launch_bounds__(768) void ffn_pair_kernel(const GemmArgs g1p, const GemmArgs g2p, const PairSync ps) {
-    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
-    const GemmArgs g1 = g1p;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x, nb = gridDim.x;
-#ifdef ICKA_GEMM_STAMP
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-    gemm_w3_body<false, false, 192>(g1, smem, bid, nb);
-#ifdef ICKA_GEMM_STAMP
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- publish the tile: every storing wave drains, the block joins, one lane releases and signals its stripe
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int m1, n1;
-    w3_origin(bid, nb, g1.N / 192, 192, m1, n1);
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ps.ready + (m1 >> 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#ifdef ICKA_GEMM_STAMP
-    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- phase 2: wait for the stripe this block's ffn-down rows read
-    const GemmArgs g2 = g2p;
-    int m2, n2;
-    tile_origin(bid, nb, g2.M / BM, g2.N / 96, m2, n2, 96);
-    if (tid == 0) {
-        const unsigned int need = (unsigned int)ps.tiles_per_stripe;
-        int polls = 0;
-        while (__hip_atomic_load(ps.ready + (m2 >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++polls > (1 << 22)) { __hip_atomic_store(ps.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the last consumer of a stripe re-arms its counters for the next launch (all of them have passed the wait by then)
-        if (__hip_atomic_fetch_add(ps.done + (m2 >> 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-            (unsigned int)ps.consumers_per_stripe - 1u) {
-            __hip_atomic_store(ps.ready + (m2 >> 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ps.done + (m2 >> 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-#ifdef ICKA_GEMM_STAMP
-    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-#endif
-    if (wave < 8) gemm_ws_body<false, false, 3, 0, 2, 96, false, false>(g2, smem, bid, nb);
-    else gemm_ws_body<false, false, 3, 2, 2, 96, false, false>(g2, smem, bid, nb);   // same barriers, no staging, no stores
-#ifdef ICKA_GEMM_STAMP
-    if (g1.stamp && tid == 0) {
-        unsigned long long* o = g1.stamp + (size_t)bid * 16;
-        o[8] = t1 - t0; o[9] = t2 - t1; o[10] = t3 - t2; o[11] = __builtin_amdgcn_s_memtime() - t3;
-    }
-#endif
-}
-
 template <bool A_KM, bool B_KM, bool F16 = false>
 int launch(GemmArgs g, bool aligned, hipStream_t st) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -1637,44 +1565,6 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
         case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
         default: return launch<true, true>(g, aligned, st);
     }
-}
-
-__device__ unsigned int g_pair_sync[64];   // ffn_pair_kernel: [0..15] ready, [16..31] done, [32] error word
-// PROBE launcher (see ffn_pair_kernel): `up` = the BertIntermediate GEMM (NT, bf16 out + GELU + pre-activation), `down` = the
-// BertOutput dense GEMM (NT, plain f32 out) whose A operand is up's main output.  Returns ICKA_E_SHAPE when the pair is not
-// the one-tile-per-CU case the kernel is written for (the caller then issues the two GEMMs as usual).
-extern "C" int icka_gemm_ffn_pair(const icka_gemm_desc* up, const icka_gemm_desc* down, void* stream) {
-    GemmArgs g1, g2;
-    bool al1 = false, al2 = false;
-    if (int rc = convert(up, g1, al1)) return rc;
-    if (int rc = convert(down, g2, al2)) return rc;
-    if (up->op != ICKA_GEMM_NT || down->op != ICKA_GEMM_NT || !al1 || !al2 || g1.f16 || g2.f16) return ICKA_E_SHAPE;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
-    }
-    const int nb1 = (g1.M / 256) * (g1.N / 192), nb2 = (g2.M / BM) * (g2.N / 96);
-    if (g1.M % 256 || g1.N % 192 || g1.K > 1024 || g1.K1 || g2.K1 || g2.N % 96 || nb1 != nb2 || nb1 % 8 || nb1 > cus) return ICKA_E_SHAPE;
-    if (g1.c_f32 || g1.c_f16 || g1.C != (void*)g2.A || g1.ldc != g2.lda || g1.M != g2.M || g1.N != g2.K) return ICKA_E_SHAPE;
-    if (!(g2.c_f32 && g2.epi == ICKA_EPI_NONE && g2.beta == 0.f && g2.direct) || g1.colsum || g2.colsum || g1.C3 || g2.C3)
-        return ICKA_E_SHAPE;
-    unsigned int* sync = nullptr;
-    if (hipGetSymbolAddress((void**)&sync, HIP_SYMBOL(g_pair_sync)) != hipSuccess || !sync) return ICKA_E_ARG;
-    g2.stamp = nullptr;   // (the phase-2 body would write its own stamps over the pair kernel's)
-    PairSync ps;
-    ps.ready = sync; ps.done = sync + 16; ps.err = sync + 32;
-    ps.tiles_per_stripe = g1.N / 192;
-    ps.consumers_per_stripe = 2 * (g2.N / 96);
-    if (g1.M / 256 > 16) return ICKA_E_SHAPE;
-    hipLaunchKernelGGL((ffn_pair_kernel<0>), dim3(nb1), dim3(768), 0, (hipStream_t)stream, g1, g2, ps);
-    ICKA_CHECK_LAUNCH();
-    return 0;
-}
-extern "C" int icka_gemm_ffn_pair_error(void) {
-    unsigned int v[64];
-    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_pair_sync), sizeof(v)) != hipSuccess) return -1;
-    return (int)v[32];
 }
 
 // 3x3 / pad 1 convolution (stride 1 or 2) of an NHWC bf16 activation as an implicit GEMM on the warp-specialised kernel:

@@ -178,20 +178,6 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> 
     return out
 
 
-def gemm_ffn_pair(up: GemmDesc, down: GemmDesc) -> bool:
-    """PROBE: the two forward FFN GEMMs as one persistent launch (icka_hip.h: icka_gemm_ffn_pair).  False when the shapes are
-    not the one-tile-per-CU case (nothing launched: issue the two GEMMs separately)."""
-    lib = _lib.load()
-    rc = lib.icka_gemm_ffn_pair(C.byref(up), C.byref(down), _stream())
-    if rc == -1:      # ICKA_E_SHAPE: not eligible
-        return False
-    check(rc, "icka_gemm_ffn_pair")
-    if _PROF is not None:
-        _PROF.append((0, up, 1, [up]))
-        _PROF.append((0, down, 1, [down]))
-    return True
-
-
 def slab_reduction(partials: torch.Tensor, nslab: int, H: int, outs, accumulate: bool, slab_stride: int = 0,
                    offset: int = 0):
     """Descriptor of  outs[slot][c] (+)= sum_b partials[offset + b*slab_stride + slot*H + c]  (c < H); rides on a

@@ -175,19 +175,16 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     return dx, dsrc
 
 
-def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool, h16=None, o=None):
+def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool, h16=None):
     """BertSelfOutput / BertOutput (:561-565, :532-536): LayerNorm(dropout(dense(h)) + res).  ``res`` is the residual
     input: bf16, its f32 twin, or (mixed16) its fp16 twin.  h16: fp16 copy of h -> the dense GEMM reads fp16 operands and
     the twin of the output is fp16.  Returns (y bf16, y twin, saved)."""
     M = h.shape[0]
     H = mod.dense.weight.shape[0]
-    if o is not None:                    # (the dense GEMM already ran: _ffn_block_fwd's paired launch)
-        pass
-    elif h16 is not None:
-        o = _empty(h, M, H, dtype=F32)  # GEMM -> LayerNorm intermediates stay f32 (no extra 16-bit rounding)
+    o = _empty(h, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra 16-bit rounding)
+    if h16 is not None:
         K.gemm(K.GEMM_NT, h16, A.w16(mod.dense.weight), o)
     else:
-        o = _empty(h, M, H, dtype=F32)
         K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
     y = _empty(h, M, H)
     yf = _empty(h, M, H, dtype=F16 if d.h16 else F32)
@@ -261,24 +258,9 @@ def _attn_block_bwd(A: ParamArena, att, x, kv_src, add_mask, d: Dims, Skv: int, 
     return _attn_core_bwd(A, att.self, x, kv_src, add_mask, d, Skv, s_core, ctx, dctx, dres, need_dkv_src)
 
 
-import os as _os
-FFN_PAIR = bool(int(_os.environ.get("ICKA_FFN_PAIR", "0")))   # PROBE knob: ffn-up + ffn-down as one persistent launch
-
-
 def _ffn_block_fwd(A: ParamArena, layer, x, xres, d: Dims, save: bool):
     """BertIntermediate + BertOutput.  Returns (y bf16, y twin, saved)."""
     xres = _fwd_twin(A, x, xres, d)
-    if FFN_PAIR and not d.h16:
-        # PROBE (icka_gemm_ffn_pair): both FFN GEMMs in one persistent launch, stripes handed over through counters
-        inter, out = layer.intermediate, layer.output
-        M, I = x.shape[0], inter.dense.weight.shape[0]
-        z, g = _empty(x, M, I), _empty(x, M, I)
-        o = _empty(x, M, out.dense.weight.shape[0], dtype=F32)
-        up = K.gemm_desc(K.GEMM_NT, x, A.w(inter.dense.weight), g, bias=inter.dense.bias, epilogue=K.EPI_GELU, out2=z)
-        down = K.gemm_desc(K.GEMM_NT, g, A.w(out.dense.weight), o)
-        if K.gemm_ffn_pair(up, down):
-            y, yf, s_out = _dense_norm_fwd(A, out, g, x if xres is None else xres, d, save, o=o)
-            return y, yf, ((z, g, s_out) if save else None)
     g, z, g16 = _inter_fwd(A, layer.intermediate, x, xres if d.h16 else None)
     y, yf, s_out = _dense_norm_fwd(A, layer.output, g, x if xres is None else xres, d, save, h16=g16)
     return y, yf, ((z, g, s_out) if save else None)

@@ -122,15 +122,6 @@ int icka_gemm_set_big_tiles(int on);
 int icka_gemm_set_ablation(int mode);
 /* 1 (default): 512-thread warp-specialised fast path (4 loader + 4 compute waves); 0: 256-thread single-role path. */
 int icka_gemm_set_warp_specialized(int on);
-/* PROBE (round 3): the forward FFN half of a layer (BertIntermediate.forward :548-551 -> the dense of
- * BertOutput.forward :532-536) as ONE persistent launch -- `up` (NT, bf16 main output + EPI_GELU + pre-activation C2) and `down`
- * (NT, plain f32 output, A = up's main output) run as two phases of 256 blocks whose 256-row stripes hand over through
- * counters instead of a kernel boundary.  Only the one-tile-per-CU case (M / 256 * N_up / 192 == M / 128 * N_down / 96 == a
- * multiple of 8 <= CUs) is implemented; anything else returns ICKA_E_SHAPE and the caller issues two icka_gemm calls.
- * icka_gemm_ffn_pair_error(): 1 if a stripe wait ever gave up (bounded spin), -1 if the query failed.  Same results as the
- * two separate launches, bit for bit. */
-int icka_gemm_ffn_pair(const icka_gemm_desc* up, const icka_gemm_desc* down, void* stream);
-int icka_gemm_ffn_pair_error(void);
 /* Diagnostic builds (-DICKA_GEMM_STAMP) only: device buffer of [blocks][8] u64 receiving per-segment cycle sums of
  * the fast-path k-loop (vmcnt wait, barrier, DMA issue, LDS reads+MFMA, total cycles, 100 MHz real-time ticks, nk). */
 int icka_gemm_set_stamp_buffer(void* p);
