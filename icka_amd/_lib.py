@@ -91,7 +91,8 @@ PROTOTYPES = {
     "icka_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_fwd_ex": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
-                                 c_i32, c_f32, c_f32, c_u64, c_i32, c_vp]),
+                                 c_i32, c_f32, c_f32, c_u64, c_i32, c_vp, c_vp]),
+    "icka_attn_keepbits_words": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "icka_attn_fwd_fp8": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_set_whole_head": (None, [c_i32]),
@@ -125,7 +126,7 @@ PROTOTYPES = {
     "icka_crf_decode": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
-                              c_vp]),
+                              c_vp, c_vp]),
     "icka_cast_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "icka_cast_to_f16": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp]),
     "icka_cast_f32_to_bf16_f16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),

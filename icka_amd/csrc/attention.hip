@@ -63,6 +63,10 @@ struct AttnArgs {
     _Float16* Ow16;   // optional fp16 copy of the context (same leading dimension): "mixed16" forward operand of out-proj
     bf16_t* dQ; int64_t lddq; bf16_t* dK; int64_t lddk; bf16_t* dV; int64_t lddv;
     int B, h, Sq, Skv; float scale; DropCfg drop;
+    // optional keep bits of the attention-probability dropout, written by the whole-head forward and read by the whole-head
+    // backward instead of hashing again (the hash is about half of the backward's vector work per element): per (batch*head,
+    // query, lane group g = (key % 16) / 4) WPL = ceil(Skv / 128) words, bit (key / 16) * 4 + key % 4 of the group's words
+    uint32_t* keepbits;
 #ifdef ICKA_ATTN_STAMP
     unsigned long long* stamp;   // diagnostic build: [block][wave][16] s_memtime / s_memrealtime stamps (tools/attn_stamp.py)
 #endif
@@ -510,6 +514,34 @@ __device__ __forceinline__ f32x4 mfma16_fp8(long a, long b, f32x4 c) {
 }
 constexpr float FP8_P_SCALE = 256.f;
 
+// keep decisions of the four in-lane keys 16 kt + 4 g .. + 3 as a nibble (bit r = key r kept): the two pair hashes of
+// drop_pair_x, x = (row * Skv / ... pair index) * C0 + s0 already formed by the caller for the first pair
+template <bool DROP>
+__device__ __forceinline__ uint32_t drop_nibble_x(const DropCfg& d, uint32_t x) {
+    if (!DROP) return 0xFu;
+    const uint32_t h0 = icka_hash_tail(x, d.s1), h1 = icka_hash_tail(x + ICKA_HASH_C0, d.s1), t = d.thr >> 16;
+    return ((h0 & 0xffffu) >= t ? 1u : 0u) | ((h0 >> 16) >= t ? 2u : 0u) | ((h1 & 0xffffu) >= t ? 4u : 0u) | ((h1 >> 16) >= t ? 8u : 0u);
+}
+__host__ __device__ __forceinline__ int keep_wpl(int Skv) { return (Skv + 127) >> 7; }
+// keep bits for a forward that did not take the whole-head kernel (tiled path): one thread per word
+__global__ void attn_keepbits_kernel(uint32_t* __restrict__ out, int64_t rows, int Skv, DropCfg d_) {
+    const DropCfg d = drop_resolve(d_);
+    const int wpl = keep_wpl(Skv);
+    const int64_t n = rows * 4 * wpl;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % wpl), g = (int)((i / wpl) & 3);
+        const int64_t row = i / (4 * wpl);
+        const uint32_t hx = ((uint32_t)row * (uint32_t)Skv + 2u * (uint32_t)g) * ICKA_HASH_C0 + d.s0;
+        uint32_t word = 0u;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int kt = 8 * w + k8;
+            word |= (d.thr ? drop_nibble_x<true>(d, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0) : 0xFu) << (4 * k8);
+        }
+        out[i] = word;
+    }
+}
+
 template <int QT, int KT, bool DROP, bool FP8 = false>
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) {
     AttnArgs a = a_;
@@ -582,16 +614,27 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float psum = 0.f;
+        uint32_t kbw[(KT * 4 + 31) / 32];
+#pragma unroll
+        for (int w = 0; w < (KT * 4 + 31) / 32; ++w) kbw[w] = 0u;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            float dm4[4];
-            drop_pair_x<DROP>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0, dm4[0], dm4[1]);
-            drop_pair_x<DROP>(a.drop, hx + (uint32_t)(8 * kt + 1) * ICKA_HASH_C0, dm4[2], dm4[3]);
+            const uint32_t nib = drop_nibble_x<DROP>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0);
+            if constexpr (DROP) kbw[(kt * 4) >> 5] |= nib << ((kt * 4) & 31);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __expf(s[qi][kt][r] - mx);
                 psum += pv;
-                s[qi][kt][r] = pv * dm4[r];
+                s[qi][kt][r] = (!DROP || ((nib >> r) & 1u)) ? pv * a.drop.scale : 0.f;
+            }
+        }
+        if constexpr (DROP) {
+            if (a.keepbits && q < a.Sq) {
+                const int wpl = keep_wpl(a.Skv);
+                uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + q) * 4 + g) * wpl;
+#pragma unroll
+                for (int w = 0; w < (KT * 4 + 31) / 32; ++w)
+                    if (w < wpl) kp[w] = kbw[w];
             }
         }
         psum += __shfl_xor(psum, 16, 64);
@@ -722,6 +765,9 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
     // hashes inside phase A the <4, 16> instance needed ~60 registers more than the 512 a wave can have (308 spilled,
     // 175 us instead of ~90 per launch at B32 x 16 heads).
     constexpr bool DROP_BITS = MASK_LDS && DROP;
+    constexpr int KBW = (KT * 4 + 31) / 32;             // words of keep bits per (query, lane group) this instance can hold
+    const bool usekb = DROP && a.keepbits != nullptr;   // the forward left its keep decisions: read them instead of hashing
+    const int wpl = keep_wpl(a.Skv);
     uint32_t dbits[DROP_BITS ? (QT * KT * 4 + 31) / 32 : 1];
     if constexpr (DROP_BITS) {
 #pragma unroll
@@ -731,16 +777,19 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
             const int q = 16 * (QT * wave + qi) + i15;
             const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
             const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
-            const uint32_t t16 = a.drop.thr >> 16;
+            uint32_t kbw[KBW];
+            if (usekb) {
+                const uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + (q < a.Sq ? q : 0)) * 4 + g) * wpl;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+                for (int w = 0; w < KBW; ++w) kbw[w] = (w < wpl && q < a.Sq) ? kp[w] : 0u;
+            }
 #pragma unroll
-                for (int rp = 0; rp < 2; ++rp) {   // one hash per pair of keys
-                    const int bit = (qi * KT + kt) * 4 + 2 * rp;
-                    const uint32_t h = icka_hash_tail(hx + (uint32_t)(8 * kt + rp) * ICKA_HASH_C0, a.drop.s1);
-                    const uint32_t keep = ((h & 0xffffu) >= t16 ? 1u : 0u) | ((h >> 16) >= t16 ? 2u : 0u);
-                    dbits[bit >> 5] |= keep << (bit & 31);
-                }
+            for (int kt = 0; kt < KT; ++kt) {
+                const int bit = (qi * KT + kt) * 4;
+                const uint32_t nib = usekb ? (kbw[(kt * 4) >> 5] >> ((kt * 4) & 31)) & 0xFu
+                                           : drop_nibble_x<true>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0);
+                dbits[bit >> 5] |= nib << (bit & 31);
+            }
         }
 #pragma unroll
         for (int w = 0; w < (QT * KT * 4 + 31) / 32; ++w) asm volatile("" : "+v"(dbits[w]));   // the hashes stay up here
@@ -757,6 +806,14 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
         const float lse_q = s_lse[q];
         const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
         const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;   // pair index base (see drop_pair)
+        uint32_t kbw[KBW];
+        if constexpr (DROP && !DROP_BITS) {
+            if (usekb) {
+                const uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + (q < a.Sq ? q : 0)) * 4 + g) * wpl;
+#pragma unroll
+                for (int w = 0; w < KBW; ++w) kbw[w] = (w < wpl && q < a.Sq) ? kp[w] : 0u;
+            }
+        }
         // P and dropout-masked dP of this query row block.  Large heads keep P bf16-packed (dS is rounded to bf16 for its
         // MFMA anyway; dP - delta, where the cancellation is, stays f32): 32 registers fewer at the 512-register cap
         f32x4 pr[MASK_LDS ? 1 : KT], dpm[KT];
@@ -777,8 +834,12 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
             if constexpr (MASK_LDS) __builtin_amdgcn_sched_barrier(0);
             float dm4[4];
             if constexpr (!DROP_BITS) {
-                drop_pair_x<DROP>(a.drop, hk, dm4[0], dm4[1]);
-                drop_pair_x<DROP>(a.drop, hk + ICKA_HASH_C0, dm4[2], dm4[3]);
+                uint32_t nib = 0xFu;
+                if constexpr (DROP) {
+                    nib = usekb ? (kbw[(kt * 4) >> 5] >> ((kt * 4) & 31)) & 0xFu : drop_nibble_x<true>(a.drop, hk);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dm4[r] = ((nib >> r) & 1u) ? a.drop.scale : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1041,7 +1102,7 @@ extern "C" int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int6
 extern "C" int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                                 const float* add_mask, void* O, void* O_f16, int64_t ldo, float* lse, int32_t B,
                                 int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed,
-                                int32_t fp8, void* stream) {
+                                int32_t fp8, void* keep_bits, void* stream) {
     if (!Q || !K || !V || !add_mask || !O) return ICKA_E_ARG;
     if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) return ICKA_E_SHAPE;
     if (fp8 && (Sq > 128 || Skv > 128)) return ICKA_E_SHAPE;
@@ -1051,6 +1112,7 @@ extern "C" int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64
     a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
     a.mask = add_mask; a.Ow = (bf16_t*)O; a.Ow16 = (_Float16*)O_f16; a.ldo = ldo; a.lse = lse;
     a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
+    a.keepbits = a.drop.thr ? (uint32_t*)keep_bits : nullptr;
     if (fp8) {
         try_small(a, 2, (hipStream_t)stream);
         ICKA_CHECK_LAUNCH();
@@ -1063,14 +1125,25 @@ extern "C" int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64
     const int grid = B * heads * ((Sq + TILE - 1) / TILE);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     ICKA_CHECK_LAUNCH();
+    if (a.keepbits) {   // the tiled forward keeps no bits: leave them for a whole-head backward with one extra launch
+        const int64_t rows = (int64_t)B * heads * Sq, n = rows * 4 * keep_wpl(Skv);
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(attn_keepbits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a.keepbits, rows, Skv, a.drop);
+        ICKA_CHECK_LAUNCH();
+    }
     return 0;
+}
+extern "C" int64_t icka_attn_keepbits_words(int32_t B, int32_t heads, int32_t Sq, int32_t Skv) {
+    if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) return 0;
+    return (int64_t)B * heads * Sq * 4 * ((Skv + 127) >> 7);
 }
 
 extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                              const float* add_mask, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                              const float* lse, float* delta, void* dQ, int64_t lddq, void* dK, int64_t lddk,
                              void* dV, int64_t lddv, int32_t B, int32_t heads, int32_t Sq, int32_t Skv, float scale,
-                             float p_drop, uint64_t seed, void* stream) {
+                             float p_drop, uint64_t seed, const void* keep_bits, void* stream) {
     if (!Q || !K || !V || !add_mask || !O || !dO || !lse || !delta || !dQ || !dK || !dV) return ICKA_E_ARG;
     if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) return ICKA_E_SHAPE;
     if ((int64_t)B * heads * Sq * Skv >= (1ll << 32)) return ICKA_E_SHAPE;
@@ -1083,6 +1156,7 @@ extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
     a.lse = const_cast<float*>(lse); a.delta = delta;
     a.dQ = (bf16_t*)dQ; a.lddq = lddq; a.dK = (bf16_t*)dK; a.lddk = lddk; a.dV = (bf16_t*)dV; a.lddv = lddv;
     a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
+    a.keepbits = a.drop.thr ? const_cast<uint32_t*>((const uint32_t*)keep_bits) : nullptr;   // (whole-head kernel only)
     hipStream_t st = (hipStream_t)stream;
 #ifdef ICKA_ATTN_STAMP
     a.stamp = g_attn_stamp;

@@ -401,7 +401,13 @@ def dgelu(dg, z, dz):
 
 
 # ------------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False, out16=None):
+def attn_keepbits(B, heads, Sq, Skv, device) -> torch.Tensor:
+    """Buffer for the keep bits of an attention-probability dropout site (attn_fwd fills it, attn_bwd reads it)."""
+    return torch.empty(_lib.load().icka_attn_keepbits_words(B, heads, Sq, Skv), dtype=torch.int32, device=device)
+
+
+def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False, out16=None,
+             keepbits=None):
     """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection).
     fp8=True: QK^T and PV on the fp8 matrix cores (Sq, Skv <= 128 only).  out16: optional fp16 copy of the context with
     the strides of ``out`` (the "mixed16" operand of the out-proj GEMM)."""
@@ -410,13 +416,17 @@ def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed
         _mat(t, n)
     if scale is None:
         scale = 1.0 / math.sqrt(64.0)
-    if out16 is not None:
-        _mat(out16, "out16", F16)
-        if tuple(out16.shape) != tuple(out.shape) or out16.stride(0) != out.stride(0):
-            raise ValueError("out16 must have the shape and row stride of out")
+    if out16 is not None or keepbits is not None:
+        if out16 is not None:
+            _mat(out16, "out16", F16)
+            if tuple(out16.shape) != tuple(out.shape) or out16.stride(0) != out.stride(0):
+                raise ValueError("out16 must have the shape and row stride of out")
+        if keepbits is not None and (not keepbits.is_cuda or keepbits.element_size() != 4 or not keepbits.is_contiguous()
+                                     or keepbits.numel() < lib.icka_attn_keepbits_words(B, heads, Sq, Skv)):
+            raise ValueError("keepbits: contiguous 32-bit device buffer of icka_attn_keepbits_words words (attn_keepbits)")
         check(lib.icka_attn_fwd_ex(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                   add_mask.data_ptr(), out.data_ptr(), out16.data_ptr(), out.stride(0), _ptr(lse), B, heads,
-                                   Sq, Skv, scale, p_drop, seed, int(bool(fp8)), _stream()), "icka_attn_fwd_ex")
+                                   add_mask.data_ptr(), out.data_ptr(), _ptr(out16), out.stride(0), _ptr(lse), B, heads,
+                                   Sq, Skv, scale, p_drop, seed, int(bool(fp8)), _ptr(keepbits), _stream()), "icka_attn_fwd_ex")
         return out
     fn = lib.icka_attn_fwd_fp8 if fp8 else lib.icka_attn_fwd
     check(fn(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), add_mask.data_ptr(),
@@ -426,7 +436,7 @@ def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed
 
 
 def attn_bwd(q, k, v, add_mask, out, dout, lse, delta, dq, dk, dv, B, heads, Sq, Skv, *, p_drop=0.0, seed=0,
-             scale=None):
+             scale=None, keepbits=None):
     lib = _lib.load()
     for n, t in (("q", q), ("k", k), ("v", v), ("out", out), ("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
         _mat(t, n)
@@ -436,7 +446,7 @@ def attn_bwd(q, k, v, add_mask, out, dout, lse, delta, dq, dk, dv, B, heads, Sq,
                             add_mask.data_ptr(), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0),
                             lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
                             dk.stride(0), dv.data_ptr(), dv.stride(0), B, heads, Sq, Skv, scale, p_drop, seed,
-                            _stream()), "icka_attn_bwd")
+                            _ptr(keepbits), _stream()), "icka_attn_bwd")
 
 
 def attn_set_whole_head(on: bool) -> None:

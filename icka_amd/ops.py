@@ -19,6 +19,8 @@ from . import kernels as K
 from .arena import ParamArena
 
 BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
+import os as _os
+ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "1") != "0"   # A/B switch: 0 = the attention backward hashes again
 
 
 def _empty(ref: torch.Tensor, *shape, dtype=BF16) -> torch.Tensor:
@@ -135,13 +137,17 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     seed_a = A.next_seed() if d.p_attn > 0 else 0
     # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
-    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8, out16=ctx16)
-    return ctx, ctx16, ((qkv, kvbuf, lse, seed_a) if save else None)
+    # the forward leaves the keep decisions of its probability dropout as bits: the backward reads them instead of hashing
+    # every (query, key) element a second time
+    kb = K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if (save and d.p_attn > 0 and ATTN_KEEPBITS) else None
+    K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8, out16=ctx16,
+               keepbits=kb)
+    return ctx, ctx16, ((qkv, kvbuf, lse, seed_a, kb) if save else None)
 
 
 def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, saved, ctx, dctx, dres, need_dkv_src: bool):
     """Returns (dx, dkv_src); ``dres`` (optional) is added to dx in the last GEMM's epilogue (residual fan-in)."""
-    qkv, kvbuf, lse, seed_a = saved
+    qkv, kvbuf, lse, seed_a, kb = saved
     M, H = x.shape
     delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
     epi = dict(epilogue=K.EPI_ADD, aux=dres) if dres is not None else {}
@@ -149,7 +155,7 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         dqkv = _empty(x, M, 3 * H)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
         K.attn_bwd(q, k, v, add_mask, ctx, dctx, lse, delta, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], d.B,
-                   d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
+                   d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, keepbits=kb)
         wg = (sa.query.weight, sa.key.weight, sa.value.weight)
         bg = (sa.query.bias, sa.key.bias, sa.value.bias)
         _wgrad(A, dqkv, x, A.g_cat(wg), A.grad_beta(wg), bias=bg)
@@ -161,7 +167,7 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     if kv_src.shape[0] > d.B * Skv:     # row-padded key/value source (region tokens): the attention writes real rows only
         K.zero_rows_(dkv, d.B * Skv)
     K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
-               d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a)
+               d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, keepbits=kb)
     _wgrad(A, dq, x, A.g(sa.query.weight), A.grad_beta(sa.query.weight), bias=sa.query.bias)
     wg = (sa.key.weight, sa.value.weight)
     bg = (sa.key.bias, sa.value.bias)

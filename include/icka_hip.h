@@ -225,19 +225,28 @@ int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int64_t ldk, co
                       int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
 /* icka_attn_fwd / icka_attn_fwd_fp8 (fp8 != 0) with an additional fp16 copy O_f16 (may be NULL; same leading dimension
  * ldo) of the context: the "mixed16" mode feeds it to the out-proj GEMM as fp16 operand, O (bf16) stays the operand of
- * the bf16 weight-gradient GEMM and of icka_attn_bwd. */
+ * the bf16 weight-gradient GEMM and of icka_attn_bwd.
+ * keep_bits (may be NULL; used when p_drop > 0): icka_attn_keepbits_words(B, heads, Sq, Skv) 32-bit words that receive the
+ * keep decisions of the attention-probability dropout (nn.Dropout on the probabilities, :500 / :616) -- the same decisions
+ * icka_attn_dropout_mask materialises -- so that icka_attn_bwd, given the same buffer, reads bits instead of hashing every
+ * element again (about half of the backward's vector work).  Layout: per (batch*head, query, g = (key % 16) / 4)
+ * ceil(Skv / 128) words, bit (key / 16) * 4 + key % 4.  Round 3: ABI version 4 added this parameter. */
 int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                      const float* add_mask, void* O, void* O_f16, int64_t ldo, float* lse, int32_t B, int32_t heads,
-                     int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, int32_t fp8, void* stream);
+                     int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, int32_t fp8, void* keep_bits,
+                     void* stream);
+int64_t icka_attn_keepbits_words(int32_t B, int32_t heads, int32_t Sq, int32_t Skv);
 /* Heads with Sq <= 128 and Skv <= 128 (the reference's max_seq_length 128 and 36/49 regions) take the whole-head
  * kernels: one block per (batch, head), forward without online-softmax rescaling, backward (dQ, dK, dV, delta) in
  * one launch.  icka_attn_set_whole_head(0) forces the tiled flash-style kernels for every shape (default 1). */
 void icka_attn_set_whole_head(int32_t on);
-/* delta f32 [B,heads,Sq] is workspace (rowsum(dO*O) = rowsum(P.dP)); it is written by the call. */
+/* delta f32 [B,heads,Sq] is workspace (rowsum(dO*O) = rowsum(P.dP)); it is written by the call.  keep_bits: NULL, or the
+ * buffer the forward (icka_attn_fwd_ex) filled for the same shape, seed and replay nonce (whole-head kernels read it, the tiled
+ * ones hash). */
 int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const float* add_mask, const void* O, int64_t ldo, const void* dO, int64_t lddo, const float* lse,
                   float* delta, void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int32_t B,
-                  int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, void* stream);
+                  int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, const void* keep_bits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Element-wise / layout helpers.

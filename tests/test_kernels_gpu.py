@@ -475,6 +475,25 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
     assert rel_err(dkv[:, H:], vf.grad) < 3e-2
     dref = (oref.detach() * dout.float()).view(B, Sq, h, 64).sum(-1).permute(0, 2, 1)
     assert (delta - dref).abs().max().item() < 3e-2 * max(dref.abs().max().item(), 1.0)
+    if p > 0:
+        # keep bits: the forward leaves the dropout decisions of every (query, key) as bits -- the very decisions of the exported
+        # mask -- and a backward that reads them (instead of hashing again) gives bitwise the gradients of the hashing one
+        kb = k.attn_keepbits(B, h, Sq, Skv, "cuda")
+        kb.fill_(-1)
+        out2, lse2 = torch.empty_like(out), torch.empty_like(lse)
+        k.attn_fwd(q, kk, v, add_mask, out2, lse2, B, h, Sq, Skv, p_drop=p, seed=seed, keepbits=kb)
+        assert torch.equal(out2, out) and torch.equal(lse2, lse)
+        wpl = (Skv + 127) // 128
+        words = kb.view(B * h * Sq, 4, wpl).cpu().numpy().astype("uint32")
+        import numpy as np
+        key = np.arange(Skv)
+        gi, wi, bi = (key % 16) // 4, ((key // 16) * 4 + key % 4) // 32, ((key // 16) * 4 + key % 4) % 32
+        bits = (words[:, gi, wi] >> bi.astype("uint32")) & 1            # [rows, Skv]
+        assert np.array_equal(bits.astype(bool), dmask.view(B * h * Sq, Skv).cpu().numpy() > 0)
+        dq2, dkv2, delta2 = torch.empty_like(dq), torch.empty_like(dkv), torch.empty_like(delta)
+        k.attn_bwd(q, kk, v, add_mask, out, dout, lse, delta2, dq2, dkv2[:, :H], dkv2[:, H:], B, h, Sq, Skv, p_drop=p, seed=seed,
+                   keepbits=kb)
+        assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv) and torch.equal(delta2, delta)
 
 
 def test_attention_fully_masked_row_matches_reference_softmax():
