@@ -52,6 +52,7 @@ struct GemmArgs {
                                 // the "mixed16" mode), or of an f32 weight gradient (the data-parallel wire copy: the value
                                 // AFTER beta-accumulation, written by the same epilogue -- dp.GradReducer)
     int aux_f16;       // the epilogue operand aux is fp16 (read through load8_aux / load4_aux)
+    int w3grid;        // 12-wave kernel: rows of the pm x pn cut of its tile grid over the 8 XCDs (gemm_w3_grid; 8 = row runs)
     int c3_only;       // f32 C + C3 + beta == 0: write ONLY the bf16 wire copy C3 (the f32 value is produced later, from the
                        // reduced wire buffer, by icka_dp_cast_back_scaled): the epilogue stores 2 bytes per element, not 4 + 2
     // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
@@ -1221,12 +1222,18 @@ __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) 
 // straight from the accumulators through the general 4-column epilogue.  A is k-contiguous (NT and NN).
 constexpr int W3_A = 2 * TILE_BYTES, W3_B = 2 * TILE_BYTES;   // one k-tile of A (2 x 128 rows) / of B (2 x 96 columns)
 constexpr int W3_NA = 3, W3_NB = 2;                           // ring depths: 3 x 32 KiB + 2 x 32 KiB = 160 KiB = the whole LDS
-// tile of block ``bid`` of the 12-wave kernel: blocks b and b+8 share an XCD, each XCD takes a contiguous row-major run of
-// tiles (nb % 8 == 0, host-checked)
-__device__ __forceinline__ void w3_origin(int bid, int nb, int nbn, int bnw, int& m0, int& n0) {
-    const int sw = (bid & 7) * (nb >> 3) + (bid >> 3);
-    m0 = (sw / nbn) * 256;
-    n0 = (sw % nbn) * bnw;
+// tile of block ``bid`` of the 12-wave kernel.  Blocks b and b+8 share an XCD (and its private 4 MiB L2), and the nb / 8
+// tiles an XCD works on at the same time decide what it has to fetch: a pm x pn cut of the tile grid over the XCDs makes the
+// chip fetch pn * |A| + pm * |B| (every XCD needs the A row panels and the B column panels of its patch).  ``grid`` = pm chosen
+// on the host (gemm_w3_grid: the cut with the smallest pn * M + pm * N that divides the tile grid; 8 = the row-major runs of
+// rounds 1-2): ffn-up 4 x 2 (31.5 MB instead of 44 MB at c2), the M = 8192 x N = 1024 shapes of c4 stay 8 x 1.
+__device__ __forceinline__ void w3_origin(int bid, int nb, int nbm, int nbn, int bnw, int grid, int& m0, int& n0) {
+    const int pm = grid, pn = 8 / grid;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sm = nbm / pm, sn = nbn / pn;
+    const int xi = xcd / pn, xj = xcd - xi * pn;
+    m0 = (xi * sm + li / sn) * 256;
+    n0 = (xj * sn + li % sn) * bnw;
 }
 template <bool B_KM, bool F16 = false, int BNW = 192>
 __device__ __forceinline__ void gemm_w3_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
@@ -1239,7 +1246,7 @@ __device__ __forceinline__ void gemm_w3_body(const GemmArgs& g, char* smem, cons
     static_assert(BNW == 192 || BNW == 128, "tile width");
     const int nbn = g.N / BNW;
     int m0, n0;
-    w3_origin(bid, nb, nbn, BNW, m0, n0);
+    w3_origin(bid, nb, g.M / 256, nbn, BNW, g.w3grid, m0, n0);
     const int nk = g.K / BK;
     if (wave >= 8) {
         // ------------------------------------------------------------------------------------------- loader waves
@@ -1339,6 +1346,30 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     gemm_w3_body<B_KM, F16, BNW>(g, smem, blockIdx.x, gridDim.x);
 }
 
+int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
+// rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
+static int gemm_w3_grid(int M, int N, int bnw) {
+    const int nbm = M / 256, nbn = N / bnw;
+    int best = 8;
+    long cost = -1;
+    for (int pm = 8; pm >= 1; pm >>= 1) {
+        const int pn = 8 / pm;
+        if (nbm % pm || nbn % pn) continue;
+        if (g_w3grid && pm != g_w3grid) continue;
+        const long c = (long)pn * M + (long)pm * N;
+        if (cost < 0 || c < cost) { cost = c; best = pm; }
+    }
+    if (cost < 0) {   // forced cut does not divide: fall back to the free choice
+        for (int pm = 8; pm >= 1; pm >>= 1) {
+            const int pn = 8 / pm;
+            if (nbm % pm || nbn % pn) continue;
+            const long c = (long)pn * M + (long)pm * N;
+            if (cost < 0 || c < cost) { cost = c; best = pm; }
+        }
+    }
+    return best;
+}
+
 template <bool A_KM, bool B_KM, bool F16 = false>
 int launch(GemmArgs g, bool aligned, hipStream_t st) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -1376,6 +1407,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     const int rounds3 = (nb3 + 255) / 256;
                     if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
                         nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
+                        g.w3grid = gemm_w3_grid(g.M, g.N, 192);
                         hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
@@ -1387,6 +1419,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                         !(g.n96ok && g_bn == 96) && !(g.K <= 1024 && g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f)) {
                         // (short reductions with a plain f32 output stay on the 128-wide kernel: its direct epilogue beats
                         //  the two staged passes here, 25.9 vs 28.3 us at 8192 x 1024 x 1024)
+                        g.w3grid = gemm_w3_grid(g.M, g.N, 128);
                         hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
@@ -1457,6 +1490,11 @@ inline bool vec_ok(const void* p, int64_t ld) { return (ld % 8 == 0) && ((reinte
 
 }  // namespace
 
+extern "C" int icka_gemm_set_w3_grid(int pm) {
+    if (pm != 0 && pm != 1 && pm != 2 && pm != 4 && pm != 8) return ICKA_E_ARG;
+    g_w3grid = pm;
+    return 0;
+}
 extern "C" int icka_gemm_set_warp_specialized(int on) {
     g_ws = on;   // 0: single-role kernel, 1: warp-specialised (two blocks per CU for large grids), 2: force two blocks, 3: never
     return 0;

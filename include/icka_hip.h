@@ -122,6 +122,11 @@ int icka_gemm_set_big_tiles(int on);
 int icka_gemm_set_ablation(int mode);
 /* 1 (default): 512-thread warp-specialised fast path (4 loader + 4 compute waves); 0: 256-thread single-role path. */
 int icka_gemm_set_warp_specialized(int on);
+/* XCD cut of the 12-wave kernel's tile grid (256 x 192 / 256 x 128 tiles): the 8 XCDs (private L2s) take a pm x pn patch grid of
+ * the tiles, the chip then fetches pn * |A| + pm * |B|.  0 (default): per shape, the dividing cut with the smallest
+ * pn * M + pm * N; 8 / 4 / 2 / 1: force pm where it divides the tile grid (8 = the row-major runs of rounds 1-2).  Results
+ * do not depend on it. */
+int icka_gemm_set_w3_grid(int pm);
 /* Diagnostic builds (-DICKA_GEMM_STAMP) only: device buffer of [blocks][8] u64 receiving per-segment cycle sums of
  * the fast-path k-loop (vmcnt wait, barrier, DMA issue, LDS reads+MFMA, total cycles, 100 MHz real-time ticks, nk). */
 int icka_gemm_set_stamp_buffer(void* p);
