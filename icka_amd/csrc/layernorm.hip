@@ -174,6 +174,24 @@ __device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int n
     for (int row = wid; row < a.M; row += nw) {
         float xh[NCH][8], gd[NCH][8];
         float s1 = 0.f, s2 = 0.f;
+        // the keep decisions of the row's dropout mask FIRST (one bit each), while the loads below are in flight: left next to
+        // their use after the row reductions, the 8 hashes per chunk sat on the critical path of a latency-bound kernel
+        // (+1.1 us per launch at 4096 x 768, tools/ln_bench.py)
+        uint32_t kb[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            kb[i] = 0xffu;
+            const int c = lane + 64 * i;
+            if (a.drop.thr && c < nchunk) {
+                const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bits |= (icka_hash(a.drop.s0, a.drop.s1, base + e) >= a.drop.thr ? 1u : 0u) << e;
+                kb[i] = bits;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(kb[i]));   // (keep the hashes up here)
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -208,9 +226,8 @@ __device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int n
                 for (int e = 0; e < 8; ++e) ds[e] = rstd * (gd[i][e] - c1 - xh[i][e] * c2);
                 if (a.dres) store8(a.dres + (int64_t)row * a.lddres + c * 8, ds);
                 if (a.drop.thr) {  // gradient of the dense output: through the (re-generated) dropout mask
-                    const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ds[e] *= drop_mul(a.drop, base + e);
+                    for (int e = 0; e < 8; ++e) ds[e] *= ((kb[i] >> e) & 1u) ? a.drop.scale : 0.f;
                 }
                 if (a.dx) store8(a.dx + (int64_t)row * a.lddx + c * 8, ds);
             }
