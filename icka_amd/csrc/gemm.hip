@@ -515,7 +515,10 @@ __device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, i
 // (t >> 4) + RSTEP*i; 16 lanes cover a whole 128-column row -> 16-byte row-contiguous global accesses.
 // WIDE: 0 = a 128-row tile of the 8-wave kernels; 1 / 2 = one 128-row pass of gemm_w3_kernel's 192- / 128-column tile (the
 // staged rows are 32-row slabs of four 64-row wave tiles; 192 columns use the off_cw image)
-template <int RSTEP, int NC8 = 16, int WIDE = 0>
+// WIRE: the instance may be asked for the data-parallel wire copy of an f32 output (C3 / c3_only): weight-gradient (TN)
+// instances only -- compiled out everywhere else (as a run-time test in every instance it cost the 12-wave kernels, which run
+// at their register cap, 5 % and showed up in kernels that never see a wire copy)
+template <int RSTEP, int NC8 = 16, int WIDE = 0, bool WIRE = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
     // NC8 = 8-column groups per tile row: 16 (128-wide tile), 12 (96-wide: 384 of 512 threads) or 24 (192-wide, 768 threads)
     if (tid >= RSTEP * NC8) return;
@@ -593,13 +596,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 o0 += g.beta * ld_once(reinterpret_cast<const f32x4*>(p));
                 o1 += g.beta * ld_once(reinterpret_cast<const f32x4*>(p + 4));
             }
-            if (!g.c3_only) {
+            if (!WIRE || !g.c3_only) {
                 st_out(reinterpret_cast<f32x4*>(p), o0);
                 st_out(reinterpret_cast<f32x4*>(p + 4), o1);
             }
-            if (g.C3) {
-                const float w[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-                store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, w);
+            if constexpr (WIRE) {
+                if (g.C3) {
+                    const float w[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+                    store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, w);
+                }
             }
         } else if (g.c_f16) {   // fp16 main output (+ optional bf16 copy); beta is rejected on the host
             store8_f16(reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n, v);
@@ -797,7 +802,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, char* smem, con
         }
     }
     __syncthreads();
-    epilogue_rows<16>(g, smem, m0, n0, tid);
+    epilogue_rows<16, 16, 0, A_KM>(g, smem, m0, n0, tid);
 }
 
 __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
@@ -1110,8 +1115,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                     const int m = m0 + wr + 16 * mi + (lane & 15);
                     const f32x4 v = acc[mi][ni] * g.alpha + b4;
                     if (g.c_f32) {
-                        if (!g.c3_only) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
-                        if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+                        if (!A_KM || !g.c3_only) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
+                        if constexpr (A_KM) {   // weight-gradient instances only: the data-parallel wire copy
+                            if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+                        }
                     } else st_out(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
                                 pack4(v[0], v[1], v[2], v[3]));
                 }
@@ -1141,7 +1148,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         }
     }
     __syncthreads();
-    epilogue_rows<32, BNT / 8>(g, smem, m0, n0, tid);
+    epilogue_rows<32, BNT / 8, 0, A_KM>(g, smem, m0, n0, tid);
 #ifdef ICKA_GEMM_STAMP
     if (g.stamp && lane == 0 && wave == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1708,6 +1715,7 @@ __global__ __launch_bounds__(512) void slab_reduce_kernel(const SlabRed r) {
     slab_reduce_block(r, smem, blockIdx.x);
 }
 
+template <bool WIRE>
 __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, const int m0, const int n0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1823,8 +1831,10 @@ __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, 
             f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
             f32x4 v = acc[mi][ni] * g.alpha;
             if (g.beta != 0.f) v += g.beta * ld_once(dst);   // gradient accumulation across micro-batches
-            if (!g.c3_only) st_out(dst, v);
-            if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+            if (!WIRE || !g.c3_only) st_out(dst, v);
+            if constexpr (WIRE) {
+                if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+            }
         }
     }
 }
@@ -1876,6 +1886,7 @@ __device__ __forceinline__ void big_colsum_block(const GemmArgs& g, char* smem, 
 // 12-wave form of the same tile (8 compute waves of 64 x 64, two per SIMD, + 4 loader waves): fragments are read per
 // 32-deep step right before their MFMAs and the second compute wave of the SIMD covers the LDS (ds_read_b64_tr_b16)
 // latency, instead of one wave per SIMD with software-pipelined register sets.
+template <bool WIRE>
 __device__ __forceinline__ void gemm_big12_tn_body(const GemmArgs& g, char* smem, const int m0, const int n0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1953,13 +1964,15 @@ __device__ __forceinline__ void gemm_big12_tn_body(const GemmArgs& g, char* smem
             f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
             f32x4 v = acc[mi][ni] * g.alpha;
             if (g.beta != 0.f) v += g.beta * ld_once(dst);
-            if (!g.c3_only) st_out(dst, v);
-            if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+            if (!WIRE || !g.c3_only) st_out(dst, v);
+            if constexpr (WIRE) {
+                if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
+            }
         }
     }
 }
 
-template <bool W12>
+template <bool W12, bool WIRE = false>   // WIRE: some problem of the group writes the data-parallel wire copy (C3)
 __global__ __launch_bounds__(W12 ? 768 : 512) void gemm_big_group_kernel(const BigGroupArgs ga) {
     __shared__ __attribute__((aligned(16))) char smem[BIG_NBUF * BIG_STAGE];
     const int bid = blockIdx.x;
@@ -1999,8 +2012,8 @@ __global__ __launch_bounds__(W12 ? 768 : 512) void gemm_big_group_kernel(const B
     int tm, tn;
     if (nbn > nbm) { tm = local % nbm; tn = local / nbm; }
     else { tm = local / nbn; tn = local % nbn; }
-    if constexpr (W12) gemm_big12_tn_body(g, smem, tm * 256, tn * BN);
-    else gemm_big_tn_body(g, smem, tm * 256, tn * BN);
+    if constexpr (W12) gemm_big12_tn_body<WIRE>(g, smem, tm * 256, tn * BN);
+    else gemm_big_tn_body<WIRE>(g, smem, tm * 256, tn * BN);
 }
 
 int g_big = 2;   // icka_gemm_set_big_tiles: 256x128 tiles for eligible grouped TN launches (2: 12-wave form, +0.9 % on the c2 step)
@@ -2090,8 +2103,16 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
                 }
                 ba.red_start[MAX_RED] = red_total;
                 reds_done = true;
-                if (g_big == 2) hipLaunchKernelGGL(gemm_big_group_kernel<true>, dim3(total + cs_total + red_total), dim3(768), 0, st, ba);
-                else hipLaunchKernelGGL(gemm_big_group_kernel<false>, dim3(total + cs_total + red_total), dim3(512), 0, st, ba);
+                bool wire = false;
+                for (int k = 0; k < cnt; ++k) wire = wire || ba.p[k].C3 != nullptr;
+                const dim3 grid(total + cs_total + red_total);
+                if (g_big == 2) {
+                    if (wire) hipLaunchKernelGGL((gemm_big_group_kernel<true, true>), grid, dim3(768), 0, st, ba);
+                    else hipLaunchKernelGGL((gemm_big_group_kernel<true, false>), grid, dim3(768), 0, st, ba);
+                } else {
+                    if (wire) hipLaunchKernelGGL((gemm_big_group_kernel<false, true>), grid, dim3(512), 0, st, ba);
+                    else hipLaunchKernelGGL((gemm_big_group_kernel<false, false>), grid, dim3(512), 0, st, ba);
+                }
                 ICKA_CHECK_LAUNCH();
                 i += cnt;
                 continue;
