@@ -542,8 +542,9 @@ __global__ void attn_keepbits_kernel(uint32_t* __restrict__ out, int64_t rows, i
     }
 }
 
-template <int QT, int KT, bool DROP, bool FP8 = false>
+template <int QT, int KT, bool DROP, bool FP8 = false, bool KB = false>
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) {
+    static_assert(DROP || !KB, "keep bits exist with dropout only");
     AttnArgs a = a_;
     a.drop = drop_resolve(a.drop);
     constexpr int QR = 64 * QT, KR = 16 * KT;
@@ -614,22 +615,32 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float psum = 0.f;
-        uint32_t kbw[(KT * 4 + 31) / 32];
+        uint32_t kbw[KB ? (KT * 4 + 31) / 32 : 1];
+        if constexpr (KB) {
 #pragma unroll
-        for (int w = 0; w < (KT * 4 + 31) / 32; ++w) kbw[w] = 0u;
+            for (int w = 0; w < (KT * 4 + 31) / 32; ++w) kbw[w] = 0u;
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const uint32_t nib = drop_nibble_x<DROP>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0);
-            if constexpr (DROP) kbw[(kt * 4) >> 5] |= nib << ((kt * 4) & 31);
+            float dm4[4];
+            if constexpr (KB) {   // the same two pair hashes, kept as bits for the backward as well
+                const uint32_t nib = drop_nibble_x<true>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0);
+                kbw[(kt * 4) >> 5] |= nib << ((kt * 4) & 31);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dm4[r] = ((nib >> r) & 1u) ? a.drop.scale : 0.f;
+            } else {
+                drop_pair_x<DROP>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0, dm4[0], dm4[1]);
+                drop_pair_x<DROP>(a.drop, hx + (uint32_t)(8 * kt + 1) * ICKA_HASH_C0, dm4[2], dm4[3]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __expf(s[qi][kt][r] - mx);
                 psum += pv;
-                s[qi][kt][r] = (!DROP || ((nib >> r) & 1u)) ? pv * a.drop.scale : 0.f;
+                s[qi][kt][r] = pv * dm4[r];
             }
         }
-        if constexpr (DROP) {
-            if (a.keepbits && q < a.Sq) {
+        if constexpr (KB) {
+            if (q < a.Sq) {
                 const int wpl = keep_wpl(a.Skv);
                 uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + q) * 4 + g) * wpl;
 #pragma unroll
@@ -696,8 +707,9 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnArgs a_) 
 // the whole 512-register file per wave (Pd and dS of a wave's 64 queries x 256 keys stay packed in 256 registers), the
 // mask read from LDS instead of registers, and the phase-B exchange done in groups of NCH 64-key chunks that fit the
 // dead K/V region (the [QR x KR] matrix no longer does).
-template <int QT, int KT, bool DROP>
+template <int QT, int KT, bool DROP, bool KB = false>
 __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_bwd_small_kernel(const AttnArgs a_) {
+    static_assert(DROP || !KB, "keep bits exist with dropout only");
     AttnArgs a = a_;
     a.drop = drop_resolve(a.drop);
     constexpr int QR = 64 * QT, KR = 16 * KT, KW = KT / 4;
@@ -765,8 +777,8 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
     // hashes inside phase A the <4, 16> instance needed ~60 registers more than the 512 a wave can have (308 spilled,
     // 175 us instead of ~90 per launch at B32 x 16 heads).
     constexpr bool DROP_BITS = MASK_LDS && DROP;
+    // KB: the forward left its keep decisions (AttnArgs::keepbits): read them instead of hashing again
     constexpr int KBW = (KT * 4 + 31) / 32;             // words of keep bits per (query, lane group) this instance can hold
-    const bool usekb = DROP && a.keepbits != nullptr;   // the forward left its keep decisions: read them instead of hashing
     const int wpl = keep_wpl(a.Skv);
     uint32_t dbits[DROP_BITS ? (QT * KT * 4 + 31) / 32 : 1];
     if constexpr (DROP_BITS) {
@@ -778,7 +790,7 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
             const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
             const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;
             uint32_t kbw[KBW];
-            if (usekb) {
+            if constexpr (KB) {
                 const uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + (q < a.Sq ? q : 0)) * 4 + g) * wpl;
 #pragma unroll
                 for (int w = 0; w < KBW; ++w) kbw[w] = (w < wpl && q < a.Sq) ? kp[w] : 0u;
@@ -786,8 +798,9 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const int bit = (qi * KT + kt) * 4;
-                const uint32_t nib = usekb ? (kbw[(kt * 4) >> 5] >> ((kt * 4) & 31)) & 0xFu
-                                           : drop_nibble_x<true>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0);
+                uint32_t nib;
+                if constexpr (KB) nib = (kbw[(kt * 4) >> 5] >> ((kt * 4) & 31)) & 0xFu;
+                else nib = drop_nibble_x<true>(a.drop, hx + (uint32_t)(8 * kt) * ICKA_HASH_C0);
                 dbits[bit >> 5] |= nib << (bit & 31);
             }
         }
@@ -807,12 +820,10 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
         const uint32_t idx_row = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Skv;
         const uint32_t hx = (idx_row + 2u * (uint32_t)g) * ICKA_HASH_C0 + a.drop.s0;   // pair index base (see drop_pair)
         uint32_t kbw[KBW];
-        if constexpr (DROP && !DROP_BITS) {
-            if (usekb) {
-                const uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + (q < a.Sq ? q : 0)) * 4 + g) * wpl;
+        if constexpr (KB && !DROP_BITS) {
+            const uint32_t* kp = a.keepbits + (((int64_t)bh * a.Sq + (q < a.Sq ? q : 0)) * 4 + g) * wpl;
 #pragma unroll
-                for (int w = 0; w < KBW; ++w) kbw[w] = (w < wpl && q < a.Sq) ? kp[w] : 0u;
-            }
+            for (int w = 0; w < KBW; ++w) kbw[w] = (w < wpl && q < a.Sq) ? kp[w] : 0u;
         }
         // P and dropout-masked dP of this query row block.  Large heads keep P bf16-packed (dS is rounded to bf16 for its
         // MFMA anyway; dP - delta, where the cancellation is, stays f32): 32 registers fewer at the 512-register cap
@@ -834,12 +845,16 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
             if constexpr (MASK_LDS) __builtin_amdgcn_sched_barrier(0);
             float dm4[4];
             if constexpr (!DROP_BITS) {
-                uint32_t nib = 0xFu;
-                if constexpr (DROP) {
-                    nib = usekb ? (kbw[(kt * 4) >> 5] >> ((kt * 4) & 31)) & 0xFu : drop_nibble_x<true>(a.drop, hk);
-                }
+                if constexpr (KB) {
+                    // bit -> all-ones / zero (one signed bit-field extract) -> and with the bits of the scale
+                    const uint32_t w = kbw[(kt * 4) >> 5], sb = __float_as_uint(a.drop.scale);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dm4[r] = ((nib >> r) & 1u) ? a.drop.scale : 0.f;
+                    for (int r = 0; r < 4; ++r)
+                        dm4[r] = __uint_as_float(sb & (uint32_t)__builtin_amdgcn_sbfe((int)w, ((kt * 4) & 31) + r, 1));
+                } else {
+                    drop_pair_x<DROP>(a.drop, hk, dm4[0], dm4[1]);
+                    drop_pair_x<DROP>(a.drop, hk + ICKA_HASH_C0, dm4[2], dm4[3]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -984,10 +999,10 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
     ATTN_RSTAMP(9);
 }
 
-template <int QT, int KT, bool DROP>
+template <int QT, int KT, bool DROP, bool KB>
 static void launch_small2(const AttnArgs& a, int mode, hipStream_t st) {
     if (mode == 1) {
-        hipLaunchKernelGGL((attn_bwd_small_kernel<QT, KT, DROP>), dim3(a.B * a.h), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_bwd_small_kernel<QT, KT, DROP, KB>), dim3(a.B * a.h), dim3(256), 0, st, a);
         return;
     }
     // forward: heads of more than 64 queries run as two 64-query blocks (grid.y = 2, K/V staged twice) when that
@@ -995,19 +1010,20 @@ static void launch_small2(const AttnArgs& a, int mode, hipStream_t st) {
     // put 3 on each
     if constexpr (QT > 2) return;   // (QT = 4 exists for the backward only; the forward takes 64-query blocks)
     else if (QT == 2 && (a.B * a.h) % 256 != 0) {
-        if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, true>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, false>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
+        if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, true, KB>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, DROP, false, KB>), dim3(a.B * a.h, 2), dim3(256), 0, st, a);
         return;
     }
     if constexpr (QT <= 2) {
-        if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true>), dim3(a.B * a.h), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, false>), dim3(a.B * a.h), dim3(256), 0, st, a);
+        if (mode == 2) hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, true, KB>), dim3(a.B * a.h), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_small_kernel<QT, KT, DROP, false, KB>), dim3(a.B * a.h), dim3(256), 0, st, a);
     }
 }
 template <int QT, int KT>
 static void launch_small(const AttnArgs& a, int mode, hipStream_t st) {
-    if (a.drop.thr) launch_small2<QT, KT, true>(a, mode, st);
-    else launch_small2<QT, KT, false>(a, mode, st);
+    if (a.drop.thr && a.keepbits) launch_small2<QT, KT, true, true>(a, mode, st);
+    else if (a.drop.thr) launch_small2<QT, KT, true, false>(a, mode, st);
+    else launch_small2<QT, KT, false, false>(a, mode, st);
 }
 // whole-head path when the head fits (returns false -> caller uses the tiled kernels).
 // mode 0: forward, 1: backward, 2: forward with fp8 QK^T / PV
@@ -1017,8 +1033,9 @@ static void launch_small(const AttnArgs& a, int mode, hipStream_t st) {
 template <int KT>
 static void launch_small_fwd_blocks(const AttnArgs& a, hipStream_t st) {
     const dim3 grid(a.B * a.h, (a.Sq + 63) / 64);
-    if (a.drop.thr) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, true, false>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, false, false>), grid, dim3(256), 0, st, a);
+    if (a.drop.thr && a.keepbits) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, true, false, true>), grid, dim3(256), 0, st, a);
+    else if (a.drop.thr) hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, true, false, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_small_kernel<1, KT, false, false, false>), grid, dim3(256), 0, st, a);
 }
 static bool try_small(const AttnArgs& a, int mode, hipStream_t st) {
     if (mode == 0 && a.Skv <= 256 && (a.Sq > 128 || a.Skv > 128)) {

@@ -52,7 +52,7 @@ struct GemmArgs {
                                 // the "mixed16" mode), or of an f32 weight gradient (the data-parallel wire copy: the value
                                 // AFTER beta-accumulation, written by the same epilogue -- dp.GradReducer)
     int aux_f16;       // the epilogue operand aux is fp16 (read through load8_aux / load4_aux)
-    int w3grid;        // 12-wave kernel: rows of the pm x pn cut of its tile grid over the 8 XCDs (gemm_w3_grid; 8 = row runs)
+    int w3_sn, w3_pnlog;   // 12-wave kernel: column tiles per XCD patch and log2(pn) of the pm x pn XCD cut (gemm_w3_grid)
     int c3_only;       // f32 C + C3 + beta == 0: write ONLY the bf16 wire copy C3 (the f32 value is produced later, from the
                        // reduced wire buffer, by icka_dp_cast_back_scaled): the epilogue stores 2 bytes per element, not 4 + 2
     // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
@@ -1231,19 +1231,22 @@ constexpr int W3_A = 2 * TILE_BYTES, W3_B = 2 * TILE_BYTES;   // one k-tile of A
 constexpr int W3_NA = 3, W3_NB = 2;                           // ring depths: 3 x 32 KiB + 2 x 32 KiB = 160 KiB = the whole LDS
 // tile of block ``bid`` of the 12-wave kernel.  Blocks b and b+8 share an XCD (and its private 4 MiB L2), and the nb / 8
 // tiles an XCD works on at the same time decide what it has to fetch: a pm x pn cut of the tile grid over the XCDs makes the
-// chip fetch pn * |A| + pm * |B| (every XCD needs the A row panels and the B column panels of its patch).  ``grid`` = pm chosen
-// on the host (gemm_w3_grid: the cut with the smallest pn * M + pm * N that divides the tile grid; 8 = the row-major runs of
-// rounds 1-2): ffn-up 4 x 2 (31.5 MB instead of 44 MB at c2), the M = 8192 x N = 1024 shapes of c4 stay 8 x 1.
-__device__ __forceinline__ void w3_origin(int bid, int nb, int nbm, int nbn, int bnw, int grid, int& m0, int& n0) {
-    const int pm = grid, pn = 8 / grid;
+// chip fetch pn * |A| + pm * |B| (every XCD needs the A row panels and the B column panels of its patch).  The host picks the
+// cut (gemm_w3_grid: the dividing one with the smallest pn * M + pm * N; 8 x 1 = the row-major runs of rounds 1-2) and passes
+// sn = column tiles per patch and log2(pn): ffn-up 4 x 2 (31.5 MB instead of 44 MB at c2), the M = 8192 x N = 1024 shapes of
+// c4 stay 8 x 1.
+__device__ __forceinline__ void w3_origin(int bid, int sn, int pnlog, int bnw, int& m0, int& n0) {
     const int xcd = bid & 7, li = bid >> 3;
-    const int sm = nbm / pm, sn = nbn / pn;
-    const int xi = xcd / pn, xj = xcd - xi * pn;
-    m0 = (xi * sm + li / sn) * 256;
-    n0 = (xj * sn + li % sn) * bnw;
+    const int xi = xcd >> pnlog, xj = xcd & ((1 << pnlog) - 1);
+    const int r = li / sn, c = li - r * sn;
+    // sm = rows of tiles per patch = (nb / 8) / sn, implied: patch xi starts at row xi * sm
+    m0 = (xi * ((int)(gridDim.x >> 3) / sn) + r) * 256;
+    n0 = (xj * sn + c) * bnw;
 }
 template <bool B_KM, bool F16 = false, int BNW = 192>
-__device__ __forceinline__ void gemm_w3_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
+__global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
@@ -1251,9 +1254,8 @@ __device__ __forceinline__ void gemm_w3_body(const GemmArgs& g, char* smem, cons
     // round where 128x128 tiles take two); the B images keep their 16 KiB slots either way
     constexpr int BH = BNW / 2, NB16 = BH / 16;
     static_assert(BNW == 192 || BNW == 128, "tile width");
-    const int nbn = g.N / BNW;
     int m0, n0;
-    w3_origin(bid, nb, g.M / 256, nbn, BNW, g.w3grid, m0, n0);
+    w3_origin(blockIdx.x, g.w3_sn, g.w3_pnlog, BNW, m0, n0);
     const int nk = g.K / BK;
     if (wave >= 8) {
         // ------------------------------------------------------------------------------------------- loader waves
@@ -1346,12 +1348,6 @@ __device__ __forceinline__ void gemm_w3_body(const GemmArgs& g, char* smem, cons
         epilogue_rows<32, BNW / 8, BNW == 192 ? 1 : 2>(g, smem, m0 + 32 * pass, n0, tid);
     }
 }
-template <bool B_KM, bool F16 = false, int BNW = 192>
-__global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
-    const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
-    gemm_w3_body<B_KM, F16, BNW>(g, smem, blockIdx.x, gridDim.x);
-}
 
 int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
@@ -1414,7 +1410,8 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     const int rounds3 = (nb3 + 255) / 256;
                     if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
                         nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
-                        g.w3grid = gemm_w3_grid(g.M, g.N, 192);
+                        { const int pm = gemm_w3_grid(g.M, g.N, 192), pn = 8 / pm;
+                          g.w3_sn = (g.N / 192) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
                         hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
@@ -1426,7 +1423,8 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                         !(g.n96ok && g_bn == 96) && !(g.K <= 1024 && g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f)) {
                         // (short reductions with a plain f32 output stay on the 128-wide kernel: its direct epilogue beats
                         //  the two staged passes here, 25.9 vs 28.3 us at 8192 x 1024 x 1024)
-                        g.w3grid = gemm_w3_grid(g.M, g.N, 128);
+                        { const int pm = gemm_w3_grid(g.M, g.N, 128), pn = 8 / pm;
+                          g.w3_sn = (g.N / 128) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
                         hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;

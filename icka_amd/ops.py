@@ -20,7 +20,9 @@ from .arena import ParamArena
 
 BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
 import os as _os
-ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "1") != "0"   # A/B switch: 0 = the attention backward hashes again
+# 1 = the attention forward leaves its dropout keep bits for the backward (off: same-box the c2 step is 0.4 % slower with
+# them -- the forward pays for packing and storing the bits, the backward's hashes were hidden behind its MFMA / LDS waits)
+ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "0") == "1"
 
 
 def _empty(ref: torch.Tensor, *shape, dtype=BF16) -> torch.Tensor:
@@ -137,8 +139,8 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     seed_a = A.next_seed() if d.p_attn > 0 else 0
     # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
-    # the forward leaves the keep decisions of its probability dropout as bits: the backward reads them instead of hashing
-    # every (query, key) element a second time
+    # optional (ATTN_KEEPBITS): the forward leaves the keep decisions of its probability dropout as bits and the backward reads
+    # them instead of hashing every (query, key) element a second time
     kb = K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if (save and d.p_attn > 0 and ATTN_KEEPBITS) else None
     K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8, out16=ctx16,
                keepbits=kb)

@@ -22,9 +22,11 @@ def main():
     ap.add_argument("--whole", type=int, default=1)
     ap.add_argument("--c4", action="store_true", help="bert-large geometry: 16 heads, 256 x 256 (tiled kernels)")
     ap.add_argument("--shape", default=None, help="Sq,Skv,heads: one explicit shape (batch 32)")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--keepbits", type=int, default=0, help="1: the forward leaves its keep bits, the backward reads them")
     args = ap.parse_args()
     K.attn_set_whole_head(bool(args.whole))
-    B, h, H = (32, 16, 1024) if args.c4 else (32, 12, 768)
+    B, h, H = (args.batch, 16, 1024) if args.c4 else (args.batch, 12, 768)
     torch.manual_seed(0)
     shapes = ((256, 256), (256, 50)) if args.c4 else ((128, 128), (128, 36))
     if args.shape:
@@ -41,19 +43,20 @@ def main():
         dqkv = torch.empty(B * Sq, 3 * H, dtype=BF16, device="cuda")
         dkv = torch.empty(B * Skv, 2 * H, dtype=BF16, device="cuda") if Skv != Sq else dqkv[:, H:]
         delta = torch.empty(B, h, Sq, dtype=F32, device="cuda")
+        kb = K.attn_keepbits(B, h, Sq, Skv, "cuda") if (args.keepbits and args.p > 0) else None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         for it in range(args.iters + 3):
             if it == 3:
                 ev[0].record()
-            K.attn_fwd(q, k, v, mask, out, lse, B, h, Sq, Skv, p_drop=args.p, seed=1234)
+            K.attn_fwd(q, k, v, mask, out, lse, B, h, Sq, Skv, p_drop=args.p, seed=1234, keepbits=kb)
         ev[1].record()
         for it in range(args.iters):
             K.attn_bwd(q, k, v, mask, out, dout, lse, delta, dqkv[:, :H], dkv[:, :H], dkv[:, H:2 * H], B, h, Sq, Skv,
-                       p_drop=args.p, seed=1234)
+                       p_drop=args.p, seed=1234, keepbits=kb)
         ev[2].record()
         torch.cuda.synchronize()
-        print("Sq %d Skv %d p %.2f whole %d: fwd %.1f us, bwd %.1f us (HIP events, back-to-back launches)"
-              % (Sq, Skv, args.p, args.whole, 1e3 * ev[0].elapsed_time(ev[1]) / args.iters,
+        print("B %d heads %d Sq %d Skv %d p %.2f whole %d keepbits %d: fwd %.1f us, bwd %.1f us (HIP events, back-to-back launches)"
+              % (B, h, Sq, Skv, args.p, args.whole, args.keepbits, 1e3 * ev[0].elapsed_time(ev[1]) / args.iters,
                  1e3 * ev[1].elapsed_time(ev[2]) / args.iters))
 
 
