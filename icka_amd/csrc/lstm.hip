@@ -833,6 +833,30 @@ static unsigned int* lstm_err_word(hipStream_t st) {
     g_lstm_fallback_used = true;
     return base ? base + 4 : nullptr;
 }
+// The word / ticket buffers of the persistent forms (g_lstm_ll, lstm_rs_words, g_lstm_sync) are process-global: two such
+// launches must never overlap.  One stream orders its own launches; a launch on ANOTHER stream first waits for an event
+// recorded behind the previous persistent launch (LstmTurn below).  Inside a stream capture no event is recorded or waited
+// for: the nodes of one graph are ordered by the capture, and graphs that contain these kernels have to be replayed on one
+// stream (GraphedStep / SegmentedStep / FlaggedStep replay on the stream they were captured on).
+struct LstmTurn {
+    hipStream_t st;
+    bool eager;
+    explicit LstmTurn(hipStream_t s) : st(s), eager(false) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+        eager = cs == hipStreamCaptureStatusNone;
+        if (eager && s_event && s_last != st) (void)hipStreamWaitEvent(st, s_event, 0);
+    }
+    ~LstmTurn() {
+        if (!eager) return;
+        if (!s_event && hipEventCreateWithFlags(&s_event, hipEventDisableTiming) != hipSuccess) { s_event = nullptr; (void)hipGetLastError(); return; }
+        if (hipEventRecord(s_event, st) == hipSuccess) s_last = st; else (void)hipGetLastError();
+    }
+    static hipEvent_t s_event;
+    static hipStream_t s_last;
+};
+hipEvent_t LstmTurn::s_event = nullptr;
+hipStream_t LstmTurn::s_last = nullptr;
 int g_lstm_poll_limit = 0;    // icka_lstm_test_hooks: 0 = the per-form defaults below
 int g_lstm_test_drop = -1;    // icka_lstm_test_hooks
 static int lstm_poll_limit(int dflt) { return g_lstm_poll_limit > 0 ? g_lstm_poll_limit : dflt; }
@@ -929,6 +953,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
         unsigned int* errw = lstm_err_word(st);
         unsigned long long* ll = lstm_ll_words();
         if (!errw || !ll) return ICKA_E_ARG;
+        LstmTurn turn(st);
         a.poll_limit = lstm_poll_limit(1 << 20);
         if (hipMemsetAsync(ll, 0, sizeof(unsigned long long) * 2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2), st) != hipSuccess) return ICKA_E_ARG;
         // batch rows are independent recurrences: two tiles of 16 rows run as separate blocks (grid.z) where all of them
@@ -956,6 +981,7 @@ ticket_form:
         unsigned int* errw = lstm_err_word((hipStream_t)stream);
         if (!base || !errw) return ICKA_E_ARG;
         ps.tickets = base; ps.err = errw;
+        LstmTurn turn((hipStream_t)stream);
         a.poll_limit = lstm_poll_limit(1 << 22);
         if (hipMemsetAsync(base, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
         // KS = resident W_hh fragments per wave (32 hidden units each): 24 up to H = 768, 32 up to H = 1024
@@ -995,6 +1021,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
         unsigned long long* llr = lstm_rs_words((hipStream_t)stream);
         if (errw && llr) {
             hipStream_t st = (hipStream_t)stream;
+            LstmTurn turn(st);
             a.poll_limit = lstm_poll_limit(1 << 17);
             const int nblk = H / 16;
             if (hipMemsetAsync(llr, 0, sizeof(unsigned long long) * 4 * nblk * nblk * 256, st) != hipSuccess) return ICKA_E_ARG;
@@ -1015,6 +1042,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
         unsigned int* errw = lstm_err_word((hipStream_t)stream);
         if (!base || !errw) return ICKA_E_ARG;
         ps.tickets = base; ps.err = errw;
+        LstmTurn turn((hipStream_t)stream);
         a.poll_limit = lstm_poll_limit(1 << 22);
         if (hipMemsetAsync(base, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) return ICKA_E_ARG;
         // (batch tiles as separate blocks, as in the forward launch, are slower here: 9.3 vs 8.9 us per step at H = 768 --

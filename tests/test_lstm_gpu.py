@@ -232,3 +232,43 @@ def test_reserved_cus_take_the_per_step_launches_when_the_grid_no_longer_fits(re
     torch.cuda.synchronize()
     assert (out.float() - ref.float()).abs().max().item() < 1e-2
     assert lib.icka_lstm_barrier_error() == 0
+
+
+def test_persistent_launches_on_two_streams_take_turns():
+    """The tagged-word / ticket buffers of the persistent recurrences are process-global (csrc/lstm.hip: LstmTurn): launches
+    from two streams must be serialised by the library, not overlap and read each other's words."""
+    from icka_amd import _lib
+    from icka_amd.lstm import BiLSTM
+    lib = _lib.load()
+    torch.manual_seed(5)
+    B, S, H = 32, 96, 768
+    mods = [BiLSTM(H, H).cuda() for _ in range(2)]
+    xs = [(torch.randn(B, S, H, device="cuda") * 0.5) for _ in range(2)]
+    want = []
+    for m, x in zip(mods, xs):                       # one after the other on the current stream
+        xx = x.clone().requires_grad_(True)
+        out, _ = m(xx)
+        out.float().sum().backward()
+        want.append((out.detach().clone(), xx.grad.clone()))
+        m.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    got = [None, None]
+    for rep in range(3):
+        xg = [x.clone().requires_grad_(True) for x in xs]
+        for i in (0, 1):
+            streams[i].wait_stream(torch.cuda.current_stream())
+        outs = [None, None]
+        for i in (0, 1):                             # both forwards enqueued before either backward
+            with torch.cuda.stream(streams[i]):
+                outs[i] = mods[i](xg[i])[0]
+        for i in (1, 0):
+            with torch.cuda.stream(streams[i]):
+                outs[i].float().sum().backward()
+                got[i] = (outs[i].detach(), xg[i].grad)
+        torch.cuda.synchronize()
+        assert lib.icka_lstm_barrier_error() == 0
+        for i in (0, 1):
+            assert torch.equal(got[i][0], want[i][0]), (rep, i)
+            assert torch.equal(got[i][1], want[i][1]), (rep, i)
+            mods[i].zero_grad(set_to_none=True)
