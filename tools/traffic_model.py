@@ -44,6 +44,28 @@ G = [
 ]
 
 
+def big_group_fetch():
+    """Fetch of the grouped weight-gradient launch under its own tile order (csrc/gemm.hip gemm_big_group_kernel: XCD x takes
+    the contiguous run x of the problems' concatenated lists of 256 x 128 tiles, each list ordered along its shorter side):
+    every XCD fetches the distinct dY (256 x M x 2 B) and X (128 x M x 2 B) panels of its run.  Returns (tile panels, the
+    second read of dY by the column-sum blocks of the same launch) in bytes."""
+    probs = [(3 * H, H), (H, H), (I, H), (H, I)]            # dW[out, in] of qkv, out-proj, ffn-up, ffn-down
+    tiles = []
+    for pi, (mo, ni) in enumerate(probs):
+        nbm, nbn = mo // 256, ni // 128
+        for local in range(nbm * nbn):
+            tm, tn = (local % nbm, local // nbm) if nbn > nbm else (local // nbn, local % nbn)
+            tiles.append((pi, tm, tn))
+    q, r = divmod(len(tiles), 8)
+    pos, tot = 0, 0
+    for x in range(8):
+        n = q + (1 if x < r else 0)
+        run = tiles[pos:pos + n]
+        pos += n
+        tot += len({(p, tm) for p, tm, _ in run}) * 256 * M * bf + len({(p, tn) for p, _, tn in run}) * 128 * M * bf
+    return tot, sum(mo for mo, _ in probs) * M * bf
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02_gemm_traffic.json"
     meas = json.load(open(path))["per_kernel"]
@@ -68,8 +90,11 @@ def main():
               % (key, n, f_meas, mb(alg) / n, mb(fl) / n, f_meas / (mb(fl) / n), w_meas, mb(w) / n))
     g = [k for k in meas if "big_group" in k][0]
     ops = (2 * M * H + (M * H + M * I) * 2 + (3 * M * H + M * H)) * bf
-    print("| `gemm_big_group_kernel` (4 weight gradients of a layer) | 13 | %.1f | %.1f | (tile-order dependent) | - | %.1f | %.1f |"
-          % (meas[g]["fetch_MB_corrected"] / meas[g]["launches"], mb(ops), meas[g]["write_MB"] / meas[g]["launches"],
+    panels, colsum = big_group_fetch()
+    f_meas = meas[g]["fetch_MB_corrected"] / meas[g]["launches"]
+    print("| `gemm_big_group_kernel` (4 weight gradients of a layer + their column-sum blocks) | 13 | %.1f | %.1f | %.1f panels of "
+          "its tile order + %.1f second read of dY by the column sums | %.2f | %.1f | %.1f |"
+          % (f_meas, mb(ops), mb(panels), mb(colsum), f_meas / mb(panels + colsum), meas[g]["write_MB"] / meas[g]["launches"],
              mb((H * H + 2 * H * I + 3 * H * H) * f4)))
 
 
