@@ -818,8 +818,17 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false>
+// KSP ("k-split pairs", 96-wide NT / NN instances): the two compute waves of a 64-row half do not split the tile's COLUMNS
+// (64 x 48 each, both 32-deep steps of a k-tile: 4 + 3 fragments per step = 14 KiB of LDS reads per wave and k-tile) but its
+// REDUCTION: wave (half, kh) multiplies the 64 x 96 half against step kh of every k-tile (4 + 6 fragments = 10 KiB), with twice
+// the accumulators, and the pair exchanges column halves through the retired ring once, after the loop -- each wave ends up
+// with the 64 x 48 block it owns in the column-split form, so both epilogues are unchanged.  The loop of these kernels is bound
+// by the LDS port (fragment reads + LDS-DMA writes: 56 + 28 KiB per k-tile at 128 B/clk = 656 of its 759 cycles,
+// profiles/r03_l2_path_probe.txt); this form moves 40 + 28 KiB.
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false,
+          bool KSP = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
+    static_assert(!KSP || (BNT == 96 && !A_KM && !CONV && ABL == 0 && DIST == 2), "k-split pairs: 96-wide NT / NN only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
@@ -937,7 +946,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[0] += tB - tA; tA = tB;
 #endif
-            __builtin_amdgcn_s_barrier();
+            if (ABL != 3) __builtin_amdgcn_s_barrier();   // (ABL 3, diagnostic: both roles free-running, garbage results)
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[1] += tB - tA; tA = tB;
 #endif
@@ -961,6 +970,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         }
 #endif
 #undef ICKA_WS_STAGE
+        if constexpr (KSP) {   // the two block barriers of the compute waves' column exchange
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
         // Fragments are software-pipelined in registers with a prefetch distance of TWO 16-MFMA halves: while tile
@@ -994,6 +1007,102 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                     }
                 }
                 cur = cur + 1 == NBUF ? 0 : cur + 1;
+            }
+        } else if constexpr (KSP) {
+            constexpr int NT6 = BNT / 16;              // all 16-column tiles of the block
+            const int kh = wave & 1;                   // this wave's 32-deep step of every k-tile
+            f32x4 acc2[4][NT6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT6; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 pa[4], pb[NT6], qa[4], qb[NT6];
+#define ICKA_KREAD(FA, FB, BUFI)                                                                     \
+    do {                                                                                             \
+        const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) FA[t] = read_frag<A_KM>(b_, wr + 16 * t, kh, lane);   \
+        _Pragma("unroll") for (int t = 0; t < NT6; ++t) FB[t] = read_frag<B_KM>(b_ + TILE_BYTES, 16 * t, kh, lane); \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+#define ICKA_KMMA(FA, FB)                                                                            \
+    do {                                                                                             \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
+            _Pragma("unroll") for (int ni = 0; ni < NT6; ++ni) acc2[mi][ni] = mfma16t<F16>(FB[ni], FA[mi], acc2[mi][ni]); \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+// one region = fragment reads of the NEXT k-tile's step (idle register set) spread between the MFMAs of this one
+#define ICKA_KRM(RA, RB, BUFI, MA, MB)                                                               \
+    do {                                                                                             \
+        constexpr int NR_ = 4 + NT6 * (B_KM ? 2 : 1), NM_ = 4 * NT6;                                 \
+        const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) RA[t] = read_frag<A_KM>(b_, wr + 16 * t, kh, lane);   \
+        _Pragma("unroll") for (int t = 0; t < NT6; ++t) RB[t] = read_frag<B_KM>(b_ + TILE_BYTES, 16 * t, kh, lane); \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
+            _Pragma("unroll") for (int ni = 0; ni < NT6; ++ni) acc2[mi][ni] = mfma16t<F16>(MB[ni], MA[mi], acc2[mi][ni]); \
+        static_assert(NR_ <= NM_, "reads per MFMA");                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < NR_; ++i_) {                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+        }                                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM_ - NR_, 0);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+#define ICKA_KSYNC()                                         \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+        asm volatile("" ::: "memory");                       \
+    } while (0)
+            __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
+            asm volatile("" ::: "memory");
+            ICKA_KREAD(pa, pb, 0);
+            int nxt = NBUF > 1 ? 1 : 0;     // ring slot of tile kt+1
+            int kt = 0;
+            for (; kt + 2 <= nk - 1; kt += 2) {
+                ICKA_KSYNC();                        // barrier kt+1
+                ICKA_KRM(qa, qb, nxt, pa, pb);
+                nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+                ICKA_KSYNC();                        // barrier kt+2
+                ICKA_KRM(pa, pb, nxt, qa, qb);
+                nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+            }
+            if (kt + 1 <= nk - 1) {
+                ICKA_KSYNC();
+                ICKA_KRM(qa, qb, nxt, pa, pb);
+                ICKA_KMMA(qa, qb);
+            } else {
+                ICKA_KMMA(pa, pb);
+            }
+#undef ICKA_KREAD
+#undef ICKA_KMMA
+#undef ICKA_KRM
+#undef ICKA_KSYNC
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (MFMA -> VALU wait states, see below)
+            // hand the partner the column half it owns, take ours from it: lane-private 16-byte slots in the retired ring
+            // (the two block barriers around it are below, taken by all eight waves)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int j = 0; j < NTN; ++j) acc[mi][j] = kh ? acc2[mi][NTN + j] : acc2[mi][j];
+            __builtin_amdgcn_s_barrier();   // every wave is done reading operand fragments
+            asm volatile("" ::: "memory");
+            {
+                char* mine = smem + ((wave * 4 * NTN) * 64 + lane) * 16;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j)
+                        *reinterpret_cast<f32x4*>(mine + (mi * NTN + j) * 1024) = kh ? acc2[mi][j] : acc2[mi][NTN + j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const char* theirs = smem + (((wave ^ 1) * 4 * NTN) * 64 + lane) * 16;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j) acc[mi][j] += *reinterpret_cast<const f32x4*>(theirs + (mi * NTN + j) * 1024);
             }
         } else {
         bf16x8 pa0[4], pb0[4], pa1[4], pb1[4], qa0[4], qb0[4], qa1[4], qb1[4];
@@ -1038,10 +1147,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #define ICKA_SYNC()                                          \
     do {                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-        __builtin_amdgcn_s_barrier();                        \
+        if (ABL != 3) __builtin_amdgcn_s_barrier();          \
         asm volatile("" ::: "memory");                       \
     } while (0)
-        __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
+        if (ABL != 3) __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
         asm volatile("" ::: "memory");
 #ifdef ICKA_GEMM_STAMP
         ph1 = __builtin_amdgcn_s_memtime();
@@ -1159,11 +1268,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false, bool KSP = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV>(g, smem, blockIdx.x, gridDim.x);
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV, KSP>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1349,6 +1458,7 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
+int g_kpairs = 0;   // icka_gemm_set_k_pairs: the 96-wide NT / NN kernel's compute waves split the reduction, not the columns
 int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
 static int gemm_w3_grid(int M, int N, int bnw) {
@@ -1399,6 +1509,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                     const int nb96 = (g.M / BM) * (g.N / 96);
                     if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                     if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                    if (g_abl == 3) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 3, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 }
                 if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
@@ -1443,7 +1554,10 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else if (g_nbuf == 5 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else
+                        else if (g_kpairs && !A_KM) {
+                            if constexpr (!A_KM)
+                                hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
+                        } else
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
@@ -2033,6 +2147,11 @@ static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
     else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 4>), dim3(total), dim3(256), 0, st, ga);
     ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_gemm_set_k_pairs(int on) {
+    g_kpairs = on ? 1 : 0;
     return 0;
 }
 

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic (library built with -DICKA_GEMM_STAMP -DICKA_GEMM_ABLATE, selected by ICKA_HIP_LIB): loop cycles per k-tile of
-the 128x96-tile kernel with the compute side (abl 1) or the DMA staging (abl 2) removed, for 4 and 8 loader waves."""
+the 128x96-tile kernel with the compute side (abl 1) or the DMA staging (abl 2) removed, or with both sides complete but the
+per-k-tile barrier removed (abl 3: the contention floor of any synchronisation scheme).
+build: make -C icka_amd/csrc EXTRA="-DICKA_GEMM_STAMP -DICKA_GEMM_ABLATE" OBJDIR=build_diag TARGET=../libicka_hip_diag.so
+run:   ICKA_HIP_LIB=icka_amd/libicka_hip_diag.so python tools/gemm_ablate.py"""
 import os
 import sys
 
@@ -12,13 +15,14 @@ from icka_amd import _lib, kernels as K  # noqa: E402
 BF16 = torch.bfloat16
 lib = _lib.load()
 lib.icka_gemm_set_tile_n(96)
+lib.icka_gemm_set_k_pairs(0)   # the ablation instances are the column-split form
 for name, op, M, N, Kd in (("ffndn NT", K.GEMM_NT, 4096, 768, 3072), ("dffnup NN", K.GEMM_NN, 4096, 768, 3072)):
     A = torch.randn(M, Kd, device="cuda").to(BF16)
     B = (torch.randn(N, Kd, device="cuda") if op == K.GEMM_NT else torch.randn(Kd, N, device="cuda")).to(BF16)
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
     buf = torch.zeros(4096, 16, dtype=torch.int64, device="cuda")
     for nlw in (4,):
-        for abl in (0, 1, 2):
+        for abl in (0, 1, 2, 3):   # 3: both roles with all their work but no barriers (free-running, garbage results)
             lib.icka_gemm_set_ablation(abl)
             for _ in range(20):
                 K.gemm(op, A, B, out)
