@@ -818,21 +818,52 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-// KSP ("k-split pairs", 96-wide NT / NN instances): the two compute waves of a 64-row half do not split the tile's COLUMNS
-// (64 x 48 each, both 32-deep steps of a k-tile: 4 + 3 fragments per step = 14 KiB of LDS reads per wave and k-tile) but its
-// REDUCTION: wave (half, kh) multiplies the 64 x 96 half against step kh of every k-tile (4 + 6 fragments = 10 KiB), with twice
-// the accumulators, and the pair exchanges column halves through the retired ring once, after the loop -- each wave ends up
-// with the 64 x 48 block it owns in the column-split form, so both epilogues are unchanged.  The loop of these kernels is bound
-// by the LDS port (fragment reads + LDS-DMA writes: 56 + 28 KiB per k-tile at 128 B/clk = 656 of its 759 cycles,
-// profiles/r03_l2_path_probe.txt); this form moves 40 + 28 KiB.
+// FLG: the two roles hand k-tiles over through counters in LDS instead of one s_barrier per k-tile.  With the barrier every
+// wave of the block stops once per k-tile: the loaders stop issuing while they wait for their tile and for the compute waves,
+// the L1 -> LDS path drains and refills after the barrier -- the stamped build (profiles/r03_gemm_kpairs.txt) measures 380 ns
+// per k-tile for the pair against 261 ns for the compute side and ~250 ns for the staging path when neither waits for the other.
+//   full[s]   += 1 by each loader wave once its pieces of the tile in ring slot s have landed (counted vmcnt, then ds_add)
+//   empty[s]  += 1 by each compute wave once the tile in slot s is in its registers (lgkmcnt(0), then ds_add)
+// The u-th use (u = 0, 1, ..) of a slot is readable when full[s] >= 4 (u + 1) and refillable when empty[s] >= 4 (u + 1).  Both
+// sides read the counter they will need one k-tile ahead of needing it, so a hand-over that is already done costs no LDS round
+// trip; every spin is bounded, and a compute wave that gives up poisons its accumulators (NaN outputs, never silent).
+constexpr int FLG_SPIN = 1 << 16;   // polls of ~0.1 us: milliseconds, against hand-overs that take under a microsecond
+// (plain volatile / atomic LDS accesses: hipcc tracks their lgkmcnt itself -- a value produced by an inline-asm ds_read is
+//  "ready" to the compiler the moment the asm ends and may be copied before the data has arrived)
+__device__ __forceinline__ void flg_add(char* cnt, int lane) {
+    if (lane == 0) __hip_atomic_fetch_add(LDS_PTR(uint32_t, cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t flg_read(const char* cnt) { return *LDS_PTR(const volatile uint32_t, cnt); }
+// every LDS operation of this wave has completed; the wave-uniform value of a counter read earlier
+__device__ __forceinline__ uint32_t flg_settle(uint32_t v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// true when the counter reached ``target`` (``seen`` = a value read earlier, possibly stale)
+__device__ __forceinline__ bool flg_wait(const char* cnt, uint32_t seen, uint32_t target) {
+    if (seen >= target) return true;
+    for (int i = 0; i < FLG_SPIN; ++i) {
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)flg_read(cnt)) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false,
-          bool KSP = false>
+          bool FLG = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
-    static_assert(!KSP || (BNT == 96 && !A_KM && !CONV && ABL == 0 && DIST == 2), "k-split pairs: 96-wide NT / NN only");
+    static_assert(!FLG || (DIST == 2 && ABL == 0), "flag hand-over: one block per CU, no ablation");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
     int m0, n0;
+    char* const fl_full = smem + NBUF * 2 * TILE_BYTES;   // (FLG) counters behind the ring: landed / in registers, per slot
+    char* const fl_empty = fl_full + 32;
+    if constexpr (FLG) {
+        static_assert(NBUF <= 8, "counter block");
+        if (tid < 16) *reinterpret_cast<uint32_t*>(smem + NBUF * 2 * TILE_BYTES + 4 * tid) = 0u;
+        __syncthreads();
+    }
     // BNT = tile width: 128, or 96 when that fills the 256 CUs better (N = 768 -> 256 tiles instead of 192)
     constexpr int NTN = BNT / 32;                  // 16-column MFMA tiles per compute wave (4 or 3)
     constexpr int NJB = B_KM ? 4 : BNT / 32;       // LDS-DMA pieces of the B tile per loader wave
@@ -924,6 +955,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         for (int t = 0; t < NBUF - 1; ++t)
             if (t < nk) ICKA_WS_STAGE(t, t * 2 * TILE_BYTES);
         int cur = 0;
+        uint32_t e_seen = 0u;   // (FLG) empty-counter value read one k-tile ahead of its use
 #ifdef ICKA_GEMM_STAMP
         unsigned long long seg[4] = {0, 0, 0, 0}, tA, tB;
         const unsigned long long real0 = __builtin_amdgcn_s_memrealtime(), cyc0 = __builtin_amdgcn_s_memtime();
@@ -946,13 +978,23 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[0] += tB - tA; tA = tB;
 #endif
-            if (ABL != 3) __builtin_amdgcn_s_barrier();   // (ABL 3, diagnostic: both roles free-running, garbage results)
+            if constexpr (FLG) flg_add(fl_full + 4 * cur, lane);   // this wave's pieces of tile kt are in LDS
+            else if (ABL != 3) __builtin_amdgcn_s_barrier();   // (ABL 3, diagnostic: both roles free-running, garbage results)
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[1] += tB - tA; tA = tB;
 #endif
             if (kt + NBUF - 1 < nk) {
                 int nx = cur + NBUF - 1;
                 nx = nx >= NBUF ? nx - NBUF : nx;
+                if constexpr (FLG) {
+                    // slot nx held tile kt-1 (its (kt-1)/NBUF-th use): refill once all four compute waves have it in registers
+                    if (kt >= 1) {
+                        const uint32_t need = 4u * (uint32_t)((kt - 1) / NBUF + 1);
+                        (void)flg_wait(fl_empty + 4 * nx, flg_settle(e_seen), need);
+                    }
+                    // the counter of the slot the NEXT iteration refills (that of tile kt), read now, used after this burst
+                    e_seen = flg_read(fl_empty + 4 * cur);
+                }
                 ICKA_WS_STAGE(kt + NBUF - 1, nx * 2 * TILE_BYTES);
             }
             cur = cur + 1 == NBUF ? 0 : cur + 1;
@@ -970,12 +1012,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         }
 #endif
 #undef ICKA_WS_STAGE
-        if constexpr (KSP) {   // the two block barriers of the compute waves' column exchange
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-        }
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
+        bool flg_failed = false;
         // Fragments are software-pipelined in registers with a prefetch distance of TWO 16-MFMA halves: while tile
         // kt is multiplied out of one register set (P), both halves of tile kt+1 are read into the other (Q).  Measured
         // (tools/probe/mfma_probe): LDS read latency at one wave per SIMD is hundreds of cycles once LDS-DMA writes
@@ -1007,102 +1046,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                     }
                 }
                 cur = cur + 1 == NBUF ? 0 : cur + 1;
-            }
-        } else if constexpr (KSP) {
-            constexpr int NT6 = BNT / 16;              // all 16-column tiles of the block
-            const int kh = wave & 1;                   // this wave's 32-deep step of every k-tile
-            f32x4 acc2[4][NT6];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NT6; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 pa[4], pb[NT6], qa[4], qb[NT6];
-#define ICKA_KREAD(FA, FB, BUFI)                                                                     \
-    do {                                                                                             \
-        const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) FA[t] = read_frag<A_KM>(b_, wr + 16 * t, kh, lane);   \
-        _Pragma("unroll") for (int t = 0; t < NT6; ++t) FB[t] = read_frag<B_KM>(b_ + TILE_BYTES, 16 * t, kh, lane); \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-    } while (0)
-#define ICKA_KMMA(FA, FB)                                                                            \
-    do {                                                                                             \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-            _Pragma("unroll") for (int ni = 0; ni < NT6; ++ni) acc2[mi][ni] = mfma16t<F16>(FB[ni], FA[mi], acc2[mi][ni]); \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-    } while (0)
-// one region = fragment reads of the NEXT k-tile's step (idle register set) spread between the MFMAs of this one
-#define ICKA_KRM(RA, RB, BUFI, MA, MB)                                                               \
-    do {                                                                                             \
-        constexpr int NR_ = 4 + NT6 * (B_KM ? 2 : 1), NM_ = 4 * NT6;                                 \
-        const char* b_ = smem + (BUFI) * 2 * TILE_BYTES;                                             \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) RA[t] = read_frag<A_KM>(b_, wr + 16 * t, kh, lane);   \
-        _Pragma("unroll") for (int t = 0; t < NT6; ++t) RB[t] = read_frag<B_KM>(b_ + TILE_BYTES, 16 * t, kh, lane); \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                             \
-            _Pragma("unroll") for (int ni = 0; ni < NT6; ++ni) acc2[mi][ni] = mfma16t<F16>(MB[ni], MA[mi], acc2[mi][ni]); \
-        static_assert(NR_ <= NM_, "reads per MFMA");                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < NR_; ++i_) {                                         \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
-        }                                                                                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, NM_ - NR_, 0);                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-    } while (0)
-#define ICKA_KSYNC()                                         \
-    do {                                                     \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-        __builtin_amdgcn_s_barrier();                        \
-        asm volatile("" ::: "memory");                       \
-    } while (0)
-            __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
-            asm volatile("" ::: "memory");
-            ICKA_KREAD(pa, pb, 0);
-            int nxt = NBUF > 1 ? 1 : 0;     // ring slot of tile kt+1
-            int kt = 0;
-            for (; kt + 2 <= nk - 1; kt += 2) {
-                ICKA_KSYNC();                        // barrier kt+1
-                ICKA_KRM(qa, qb, nxt, pa, pb);
-                nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
-                ICKA_KSYNC();                        // barrier kt+2
-                ICKA_KRM(pa, pb, nxt, qa, qb);
-                nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
-            }
-            if (kt + 1 <= nk - 1) {
-                ICKA_KSYNC();
-                ICKA_KRM(qa, qb, nxt, pa, pb);
-                ICKA_KMMA(qa, qb);
-            } else {
-                ICKA_KMMA(pa, pb);
-            }
-#undef ICKA_KREAD
-#undef ICKA_KMMA
-#undef ICKA_KRM
-#undef ICKA_KSYNC
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (MFMA -> VALU wait states, see below)
-            // hand the partner the column half it owns, take ours from it: lane-private 16-byte slots in the retired ring
-            // (the two block barriers around it are below, taken by all eight waves)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int j = 0; j < NTN; ++j) acc[mi][j] = kh ? acc2[mi][NTN + j] : acc2[mi][j];
-            __builtin_amdgcn_s_barrier();   // every wave is done reading operand fragments
-            asm volatile("" ::: "memory");
-            {
-                char* mine = smem + ((wave * 4 * NTN) * 64 + lane) * 16;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int j = 0; j < NTN; ++j)
-                        *reinterpret_cast<f32x4*>(mine + (mi * NTN + j) * 1024) = kh ? acc2[mi][j] : acc2[mi][NTN + j];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            {
-                const char* theirs = smem + (((wave ^ 1) * 4 * NTN) * 64 + lane) * 16;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int j = 0; j < NTN; ++j) acc[mi][j] += *reinterpret_cast<const f32x4*>(theirs + (mi * NTN + j) * 1024);
             }
         } else {
         bf16x8 pa0[4], pb0[4], pa1[4], pb1[4], qa0[4], qb0[4], qa1[4], qb1[4];
@@ -1144,13 +1087,32 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, MA[mi], cs[mi]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
+        // (FLG) ring position of the tile in the multiplying register set and of the one to read next: slot, use count
+        int f_cs = 0, f_cu = 0, f_ns = NBUF > 1 ? 1 : 0, f_nu = NBUF > 1 ? 0 : 1;
+        uint32_t f_seen = 0u;
+        bool f_ok = true;
 #define ICKA_SYNC()                                          \
     do {                                                     \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-        if (ABL != 3) __builtin_amdgcn_s_barrier();          \
-        asm volatile("" ::: "memory");                       \
+        if constexpr (FLG) {                                 \
+            /* the tile being multiplied is fully in registers: its slot may be refilled; the next one must have landed */ \
+            const uint32_t v_ = flg_settle(f_seen);          \
+            flg_add(fl_empty + 4 * f_cs, lane);              \
+            f_ok &= flg_wait(fl_full + 4 * f_ns, v_, 4u * (uint32_t)(f_nu + 1)); \
+            f_cs = f_ns; f_cu = f_nu;                        \
+            if (++f_ns == NBUF) { f_ns = 0; ++f_nu; }        \
+            f_seen = flg_read(fl_full + 4 * f_ns);           \
+            asm volatile("" ::: "memory"); /* the fragment reads below stay behind the hand-over */ \
+            __builtin_amdgcn_sched_barrier(0);               \
+        } else {                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+            if (ABL != 3) __builtin_amdgcn_s_barrier();      \
+            asm volatile("" ::: "memory");                   \
+        }                                                    \
     } while (0)
-        if (ABL != 3) __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
+        if constexpr (FLG) {
+            f_ok &= flg_wait(fl_full, 0u, 4u);               // tile 0 published
+            f_seen = flg_read(fl_full + 4 * f_ns);
+        } else if (ABL != 3) __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
         asm volatile("" ::: "memory");
 #ifdef ICKA_GEMM_STAMP
         ph1 = __builtin_amdgcn_s_memtime();
@@ -1184,12 +1146,20 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #undef ICKA_MMA
 #undef ICKA_RM
 #undef ICKA_SYNC
+        flg_failed = FLG && !f_ok;
+        (void)f_cu;
         }
         // MFMA -> VALU read-after-write needs software wait states on gfx950 (8-pass MFMA: ~11).  hipcc's hazard
         // recognizer missed one across a block boundary here (<TN, 96-wide>, odd k-tile count: a v_mov of the last
         // accumulator element right behind the branch that follows the last MFMA -> one stale element per lane, found
         // by tools/gemm_tile_check.py), so the compute waves always idle 16 states before anything reads acc.
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        if (flg_failed) {   // (FLG) a hand-over never came within the bounded spin: NaN outputs instead of silently wrong ones
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        }
 #ifdef ICKA_GEMM_STAMP
         ph2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1268,11 +1238,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false, bool KSP = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false, bool FLG = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV, KSP>(g, smem, blockIdx.x, gridDim.x);
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES + (FLG ? 64 : 0)];
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV, FLG>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1458,7 +1428,7 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
-int g_kpairs = 0;   // icka_gemm_set_k_pairs: the 96-wide NT / NN kernel's compute waves split the reduction, not the columns
+int g_flagsync = 0;   // icka_gemm_set_flag_sync: LDS-counter hand-over instead of one s_barrier per k-tile (128 x 96 NT / NN kernel)
 int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
 static int gemm_w3_grid(int M, int N, int bnw) {
@@ -1554,9 +1524,11 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else if (g_nbuf == 5 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_kpairs && !A_KM) {
-                            if constexpr (!A_KM)
-                                hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
+                        else if (g_flagsync && !A_KM) {
+                            if constexpr (!A_KM) {
+                                if (g_flagsync == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
+                                else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
+                            }
                         } else
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
                         ICKA_CHECK_LAUNCH();
@@ -2150,8 +2122,8 @@ static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
     return 0;
 }
 
-extern "C" int icka_gemm_set_k_pairs(int on) {
-    g_kpairs = on ? 1 : 0;
+extern "C" int icka_gemm_set_flag_sync(int on) {
+    g_flagsync = on == 4 ? 4 : (on ? 1 : 0);   // (4: with a ring of 4 k-tiles)
     return 0;
 }
 

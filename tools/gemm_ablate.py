@@ -15,7 +15,6 @@ from icka_amd import _lib, kernels as K  # noqa: E402
 BF16 = torch.bfloat16
 lib = _lib.load()
 lib.icka_gemm_set_tile_n(96)
-lib.icka_gemm_set_k_pairs(0)   # the ablation instances are the column-split form
 for name, op, M, N, Kd in (("ffndn NT", K.GEMM_NT, 4096, 768, 3072), ("dffnup NN", K.GEMM_NN, 4096, 768, 3072)):
     A = torch.randn(M, Kd, device="cuda").to(BF16)
     B = (torch.randn(N, Kd, device="cuda") if op == K.GEMM_NT else torch.randn(Kd, N, device="cuda")).to(BF16)
