@@ -818,52 +818,12 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-// FLG: the two roles hand k-tiles over through counters in LDS instead of one s_barrier per k-tile.  With the barrier every
-// wave of the block stops once per k-tile: the loaders stop issuing while they wait for their tile and for the compute waves,
-// the L1 -> LDS path drains and refills after the barrier -- the stamped build (profiles/r03_gemm_kpairs.txt) measures 380 ns
-// per k-tile for the pair against 261 ns for the compute side and ~250 ns for the staging path when neither waits for the other.
-//   full[s]   += 1 by each loader wave once its pieces of the tile in ring slot s have landed (counted vmcnt, then ds_add)
-//   empty[s]  += 1 by each compute wave once the tile in slot s is in its registers (lgkmcnt(0), then ds_add)
-// The u-th use (u = 0, 1, ..) of a slot is readable when full[s] >= 4 (u + 1) and refillable when empty[s] >= 4 (u + 1).  Both
-// sides read the counter they will need one k-tile ahead of needing it, so a hand-over that is already done costs no LDS round
-// trip; every spin is bounded, and a compute wave that gives up poisons its accumulators (NaN outputs, never silent).
-constexpr int FLG_SPIN = 1 << 16;   // polls of ~0.1 us: milliseconds, against hand-overs that take under a microsecond
-// (plain volatile / atomic LDS accesses: hipcc tracks their lgkmcnt itself -- a value produced by an inline-asm ds_read is
-//  "ready" to the compiler the moment the asm ends and may be copied before the data has arrived)
-__device__ __forceinline__ void flg_add(char* cnt, int lane) {
-    if (lane == 0) __hip_atomic_fetch_add(LDS_PTR(uint32_t, cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ uint32_t flg_read(const char* cnt) { return *LDS_PTR(const volatile uint32_t, cnt); }
-// every LDS operation of this wave has completed; the wave-uniform value of a counter read earlier
-__device__ __forceinline__ uint32_t flg_settle(uint32_t v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-// true when the counter reached ``target`` (``seen`` = a value read earlier, possibly stale)
-__device__ __forceinline__ bool flg_wait(const char* cnt, uint32_t seen, uint32_t target) {
-    if (seen >= target) return true;
-    for (int i = 0; i < FLG_SPIN; ++i) {
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)flg_read(cnt)) >= target) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false,
-          bool FLG = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
-    static_assert(!FLG || (DIST == 2 && ABL == 0), "flag hand-over: one block per CU, no ablation");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
     int m0, n0;
-    char* const fl_full = smem + NBUF * 2 * TILE_BYTES;   // (FLG) counters behind the ring: landed / in registers, per slot
-    char* const fl_empty = fl_full + 32;
-    if constexpr (FLG) {
-        static_assert(NBUF <= 8, "counter block");
-        if (tid < 16) *reinterpret_cast<uint32_t*>(smem + NBUF * 2 * TILE_BYTES + 4 * tid) = 0u;
-        __syncthreads();
-    }
     // BNT = tile width: 128, or 96 when that fills the 256 CUs better (N = 768 -> 256 tiles instead of 192)
     constexpr int NTN = BNT / 32;                  // 16-column MFMA tiles per compute wave (4 or 3)
     constexpr int NJB = B_KM ? 4 : BNT / 32;       // LDS-DMA pieces of the B tile per loader wave
@@ -955,7 +915,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         for (int t = 0; t < NBUF - 1; ++t)
             if (t < nk) ICKA_WS_STAGE(t, t * 2 * TILE_BYTES);
         int cur = 0;
-        uint32_t e_seen = 0u;   // (FLG) empty-counter value read one k-tile ahead of its use
 #ifdef ICKA_GEMM_STAMP
         unsigned long long seg[4] = {0, 0, 0, 0}, tA, tB;
         const unsigned long long real0 = __builtin_amdgcn_s_memrealtime(), cyc0 = __builtin_amdgcn_s_memtime();
@@ -978,23 +937,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[0] += tB - tA; tA = tB;
 #endif
-            if constexpr (FLG) flg_add(fl_full + 4 * cur, lane);   // this wave's pieces of tile kt are in LDS
-            else if (ABL != 3) __builtin_amdgcn_s_barrier();   // (ABL 3, diagnostic: both roles free-running, garbage results)
+            if (ABL != 3) __builtin_amdgcn_s_barrier();   // (ABL 3, diagnostic: both roles free-running, garbage results)
 #ifdef ICKA_GEMM_STAMP
             WSTAMP(tB); seg[1] += tB - tA; tA = tB;
 #endif
             if (kt + NBUF - 1 < nk) {
                 int nx = cur + NBUF - 1;
                 nx = nx >= NBUF ? nx - NBUF : nx;
-                if constexpr (FLG) {
-                    // slot nx held tile kt-1 (its (kt-1)/NBUF-th use): refill once all four compute waves have it in registers
-                    if (kt >= 1) {
-                        const uint32_t need = 4u * (uint32_t)((kt - 1) / NBUF + 1);
-                        (void)flg_wait(fl_empty + 4 * nx, flg_settle(e_seen), need);
-                    }
-                    // the counter of the slot the NEXT iteration refills (that of tile kt), read now, used after this burst
-                    e_seen = flg_read(fl_empty + 4 * cur);
-                }
                 ICKA_WS_STAGE(kt + NBUF - 1, nx * 2 * TILE_BYTES);
             }
             cur = cur + 1 == NBUF ? 0 : cur + 1;
@@ -1014,7 +963,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #undef ICKA_WS_STAGE
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
-        bool flg_failed = false;
         // Fragments are software-pipelined in registers with a prefetch distance of TWO 16-MFMA halves: while tile
         // kt is multiplied out of one register set (P), both halves of tile kt+1 are read into the other (Q).  Measured
         // (tools/probe/mfma_probe): LDS read latency at one wave per SIMD is hundreds of cycles once LDS-DMA writes
@@ -1087,32 +1035,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         if (do_cs) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) cs[mi] = mfma16(ones, MA[mi], cs[mi]); }  \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
-        // (FLG) ring position of the tile in the multiplying register set and of the one to read next: slot, use count
-        int f_cs = 0, f_cu = 0, f_ns = NBUF > 1 ? 1 : 0, f_nu = NBUF > 1 ? 0 : 1;
-        uint32_t f_seen = 0u;
-        bool f_ok = true;
 #define ICKA_SYNC()                                          \
     do {                                                     \
-        if constexpr (FLG) {                                 \
-            /* the tile being multiplied is fully in registers: its slot may be refilled; the next one must have landed */ \
-            const uint32_t v_ = flg_settle(f_seen);          \
-            flg_add(fl_empty + 4 * f_cs, lane);              \
-            f_ok &= flg_wait(fl_full + 4 * f_ns, v_, 4u * (uint32_t)(f_nu + 1)); \
-            f_cs = f_ns; f_cu = f_nu;                        \
-            if (++f_ns == NBUF) { f_ns = 0; ++f_nu; }        \
-            f_seen = flg_read(fl_full + 4 * f_ns);           \
-            asm volatile("" ::: "memory"); /* the fragment reads below stay behind the hand-over */ \
-            __builtin_amdgcn_sched_barrier(0);               \
-        } else {                                             \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-            if (ABL != 3) __builtin_amdgcn_s_barrier();      \
-            asm volatile("" ::: "memory");                   \
-        }                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        if (ABL != 3) __builtin_amdgcn_s_barrier();          \
+        asm volatile("" ::: "memory");                       \
     } while (0)
-        if constexpr (FLG) {
-            f_ok &= flg_wait(fl_full, 0u, 4u);               // tile 0 published
-            f_seen = flg_read(fl_full + 4 * f_ns);
-        } else if (ABL != 3) __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
+        if (ABL != 3) __builtin_amdgcn_s_barrier();   // barrier #0: tile 0 published
         asm volatile("" ::: "memory");
 #ifdef ICKA_GEMM_STAMP
         ph1 = __builtin_amdgcn_s_memtime();
@@ -1146,20 +1075,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #undef ICKA_MMA
 #undef ICKA_RM
 #undef ICKA_SYNC
-        flg_failed = FLG && !f_ok;
-        (void)f_cu;
         }
         // MFMA -> VALU read-after-write needs software wait states on gfx950 (8-pass MFMA: ~11).  hipcc's hazard
         // recognizer missed one across a block boundary here (<TN, 96-wide>, odd k-tile count: a v_mov of the last
         // accumulator element right behind the branch that follows the last MFMA -> one stale element per lane, found
         // by tools/gemm_tile_check.py), so the compute waves always idle 16 states before anything reads acc.
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        if (flg_failed) {   // (FLG) a hand-over never came within the bounded spin: NaN outputs instead of silently wrong ones
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-        }
 #ifdef ICKA_GEMM_STAMP
         ph2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1238,11 +1159,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false, bool FLG = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES + (FLG ? 64 : 0)];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV, FLG>(g, smem, blockIdx.x, gridDim.x);
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1428,7 +1349,6 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
-int g_flagsync = 0;   // icka_gemm_set_flag_sync: LDS-counter hand-over instead of one s_barrier per k-tile (128 x 96 NT / NN kernel)
 int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
 static int gemm_w3_grid(int M, int N, int bnw) {
@@ -1524,12 +1444,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else if (g_nbuf == 5 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_flagsync && !A_KM) {
-                            if constexpr (!A_KM) {
-                                if (g_flagsync == 4) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
-                                else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
-                            }
-                        } else
+                        else
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
@@ -2119,11 +2034,6 @@ static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
     else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 4>), dim3(total), dim3(256), 0, st, ga);
     ICKA_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int icka_gemm_set_flag_sync(int on) {
-    g_flagsync = on == 4 ? 4 : (on ? 1 : 0);   // (4: with a ring of 4 k-tiles)
     return 0;
 }
 

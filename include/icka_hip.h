@@ -127,10 +127,6 @@ int icka_gemm_set_warp_specialized(int on);
  * pn * M + pm * N; 8 / 4 / 2 / 1: force pm where it divides the tile grid (8 = the row-major runs of rounds 1-2).  Results
  * do not depend on it. */
 int icka_gemm_set_w3_grid(int pm);
-/* 1 (default 0: measured, no gain -- profiles/r03_gemm_flagsync.txt): the loader and compute waves of the 128 x 96-tile NT / NN kernel hand k-tiles over through counters in LDS
- * (per ring slot: "landed" and "in registers"), so neither role stops for the other once per k-tile; 0: one s_barrier per
- * k-tile (rounds 1-2).  Bitwise the same results. */
-int icka_gemm_set_flag_sync(int on);
 /* Diagnostic builds (-DICKA_GEMM_STAMP) only: device buffer of [blocks][8] u64 receiving per-segment cycle sums of
  * the fast-path k-loop (vmcnt wait, barrier, DMA issue, LDS reads+MFMA, total cycles, 100 MHz real-time ticks, nk). */
 int icka_gemm_set_stamp_buffer(void* p);

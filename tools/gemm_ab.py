@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of one library knob on the N = 768 GEMM shapes of the c2 step, COLD operands (12 buffer sets), variants
 interleaved round by round in one process (median over rounds).  usage: gemm_ab.py knob v0 v1 [...]
-knob: wide | ring | tile_n | direct | flagsync"""
+knob: wide | ring | tile_n | direct"""
 import os
 import sys
 
@@ -15,8 +15,7 @@ lib = _lib.load()
 knob = sys.argv[1]
 vals = [int(v) for v in sys.argv[2:]]
 setter = {"wide": lib.icka_gemm_set_wide_tiles, "ring": lib.icka_gemm_set_ring,
-          "tile_n": lib.icka_gemm_set_tile_n, "direct": lib.icka_gemm_set_direct_epilogue,
-          "flagsync": lib.icka_gemm_set_flag_sync}[knob]
+          "tile_n": lib.icka_gemm_set_tile_n, "direct": lib.icka_gemm_set_direct_epilogue}[knob]
 
 
 def timed(fn, sets, reps=3):
