@@ -220,6 +220,31 @@ def test_gemm_wide_tiles(M, N, K, op, wide, request):
     assert rel_err(ov, 0.5 * ref) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,op", [(4096, 3072, 768, "NT"), (4096, 2304, 768, "NT"), (4096, 3072, 768, "NN"), (2048, 3072, 192, "NT"),
+                                      (8192, 1024, 1024, "NN"), (6144, 1024, 192, "NT")])
+def test_gemm_wide_tiles_xcd_cut_does_not_change_results(M, N, K, op, request):
+    """The 12-wave kernel cuts its tile grid over the 8 XCDs per shape (icka_gemm_set_w3_grid: 0 = pick the cut, 8 / 4 / 2 / 1 =
+    force the number of patch rows where it divides the grid): every forced cut covers every tile exactly once -- bitwise the
+    result of the default."""
+    k = _k()
+    lib = k._lib.load()
+    request.addfinalizer(lambda: lib.icka_gemm_set_w3_grid(0))
+    A = rnd(M, K, seed=11, scale=0.5)
+    B = rnd(N, K, seed=12, scale=0.5) if op == "NT" else rnd(K, N, seed=12, scale=0.5)
+    kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
+    ref = A.float() @ (B.float().t() if op == "NT" else B.float())
+    outs = []
+    for pm in (0, 8, 4, 2, 1):
+        assert lib.icka_gemm_set_w3_grid(pm) == 0
+        o = torch.full((M, N), float("nan"), dtype=BF16, device="cuda")
+        k.gemm(kop, A, B, o)
+        assert torch.isfinite(o.float()).all(), pm          # no tile left out
+        outs.append(o)
+    assert rel_err(outs[0], ref) < 1e-2
+    for pm, o in zip((8, 4, 2, 1), outs[1:]):
+        assert torch.equal(o, outs[0]), pm
+
+
 @pytest.mark.parametrize("tile_n", [96, 128])
 @pytest.mark.parametrize("M,N,K", [(128, 384, 64), (4096, 768, 768), (512, 2304, 768), (256, 768, 3072)])
 def test_gemm_tile_widths(M, N, K, tile_n, request):

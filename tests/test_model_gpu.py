@@ -167,6 +167,30 @@ def test_train_mode_dropout_statistics_and_determinism():
     assert abs(eval_loss - outs[0][0]) < 1.0
 
 
+def test_attention_keep_bits_option_gives_the_same_step(monkeypatch):
+    """ICKA_ATTN_KEEPBITS=1 (icka_amd.ops.ATTN_KEEPBITS): the attention forward leaves its dropout decisions as bits and the
+    backward reads them instead of hashing again -- same masks, so a seeded train-mode step is bitwise the default one."""
+    from icka_amd import ops
+    case = load_case("tiny_cl_r49")
+    model = _build(case["cfg"]).train()
+    _run(model, case["batch"]).backward()                  # builds the arena
+    outs = []
+    for keep in (False, True):
+        monkeypatch.setattr(ops, "ATTN_KEEPBITS", keep)
+        model._icka_arena.set_seed(4321)
+        model.zero_grad()
+        loss = _run(model, case["batch"])
+        loss.backward()
+        outs.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1].keys() == outs[1][1].keys()
+    for n, g in outs[0][1].items():
+        if "word_embeddings" in n:                          # (f32 atomics: order-dependent in the last bits)
+            assert torch.allclose(g, outs[1][1][n], rtol=1e-4, atol=1e-7), n
+        else:
+            assert torch.equal(g, outs[1][1][n]), n
+
+
 def test_grad_accumulation_and_zero_grad():
     case = load_case("tiny_cl_r49")
     model = _build(case["cfg"]).eval()
