@@ -468,6 +468,18 @@ __device__ __forceinline__ void load8_aux(const bf16_t* p, int f16, float (&o)[8
         load8_bf16(p, o);
     }
 }
+// the same in two steps: the 16 raw bytes (issued early), converted where they are used
+__device__ __forceinline__ void cvt8_aux(const u32x4 raw, int f16, float (&o)[8]) {
+    if (f16) {
+        const f16x8 v = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    } else {
+        const bf16x8 v = as_bf16x8(raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+    }
+}
 __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     bf16x8 o;
 #pragma unroll
@@ -538,6 +550,20 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
     }
+    // The epilogue operand (fan-in gradient, GELU' input, gate factor) of ALL of this thread's rows is requested here, before
+    // the first staged row is read: inside the row loop (behind the switch on the epilogue kind) every row's load waited for
+    // the previous row's store to issue -- 128 / RSTEP global-load latencies in series per thread, twice that in the two
+    // passes of the 12-wave kernel.
+    constexpr int NROW = 128 / RSTEP;
+    const bool use_aux = g.epi == ICKA_EPI_DGELU || g.epi == ICKA_EPI_ADD || g.epi == ICKA_EPI_GATE || g.epi == ICKA_EPI_ADD_RELU;
+    u32x4 araw[NROW];
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const int row = rb + RSTEP * i;
+        const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
+        araw[i] = u32x4{0u, 0u, 0u, 0u};
+        if (use_aux) araw[i] = ld_once(reinterpret_cast<const u32x4*>(g.aux + (int64_t)m * g.ldaux + n));
+    }
     // (the 12-wave kernel runs at a 168-register cap with accumulators of the other pass alive: keep its row loop rolled)
     constexpr int UNR = WIDE ? 1 : 128 / RSTEP;
 #pragma unroll UNR
@@ -545,6 +571,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
         const int row = rb + RSTEP * i;
         // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
         const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
+        const u32x4 acur = araw[0];   // (constant indices: the queue stays in registers when the loop is rolled)
+#pragma unroll
+        for (int q = 0; q + 1 < NROW; ++q) araw[q] = araw[q + 1];
         const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
         float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
@@ -557,12 +586,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
                 break;
             case ICKA_EPI_DGELU:
-                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
+                cvt8_aux(acur, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(a[e]);
                 break;
             case ICKA_EPI_ADD:
-                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
+                cvt8_aux(acur, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += a[e];
                 break;
@@ -570,7 +599,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
                 if (g.C2) store8_bf16(g.C2 + (int64_t)m * g.ldc2 + n, v);
-                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
+                cvt8_aux(acur, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= a[e];
                 break;
@@ -579,7 +608,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
                 break;
             case ICKA_EPI_ADD_RELU:
-                load8_aux(g.aux + (int64_t)m * g.ldaux + n, g.aux_f16, a);
+                cvt8_aux(acur, g.aux_f16, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + a[e], 0.f);
                 break;
