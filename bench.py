@@ -183,8 +183,33 @@ def self_launch(n: int, json_fd: int) -> int:
     env.setdefault("OMP_NUM_THREADS", "4")
     env.pop("MASTER_PORT", None)
     log("self-launch: %s" % " ".join(cmd))
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env)   # stderr inherited: progress lines stream
+    # the launcher and its ranks get a process group of their own, so that a run that never ends (a collective waiting for a
+    # rank that died, a hung device) can be stopped as a whole -- by exactly the group started here -- once the deadline passes
+    import signal
+    import threading
+    deadline = float(os.environ.get("ICKA_BENCH_LAUNCH_TIMEOUT", "1500"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, start_new_session=True)   # stderr inherited
+    timed_out = []
+
+    def stop_group(sig):
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_deadline():
+        timed_out.append(True)
+        log("self-launch: no result after %.0f s (ICKA_BENCH_LAUNCH_TIMEOUT): stopping the ranks" % deadline)
+        stop_group(signal.SIGTERM)
+        t2 = threading.Timer(20.0, stop_group, args=(signal.SIGKILL,))
+        t2.daemon = True
+        t2.start()
+
+    timer = threading.Timer(deadline, on_deadline)
+    timer.daemon = True
+    timer.start()
     line = None
+    rc = 1
     try:
         for raw in p.stdout:
             txt = raw.decode("utf-8", "replace").rstrip("\n")
@@ -200,12 +225,15 @@ def self_launch(n: int, json_fd: int) -> int:
                 print(txt, file=sys.stderr, flush=True)
         rc = p.wait()
     finally:
-        if p.poll() is None:     # our own child (exact PID), e.g. on KeyboardInterrupt
-            p.terminate()
+        timer.cancel()
+        if p.poll() is None:     # our own child (its process group), e.g. on KeyboardInterrupt
+            stop_group(signal.SIGTERM)
             try:
                 p.wait(timeout=30)
             except subprocess.TimeoutExpired:
-                p.kill()
+                stop_group(signal.SIGKILL)
+    if timed_out:
+        return 124
     if line is not None:
         os.write(json_fd, (line + "\n").encode())
     elif rc == 0:
