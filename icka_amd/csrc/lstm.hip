@@ -843,7 +843,8 @@ struct LstmTurn {
     bool eager;
     explicit LstmTurn(hipStream_t s) : st(s), eager(false) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+        // (the legacy default stream cannot be captured)
+        if (st != nullptr && hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
         eager = cs == hipStreamCaptureStatusNone;
         if (eager && s_event && s_last != st) (void)hipStreamWaitEvent(st, s_event, 0);
     }
