@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(const LstmArgs
                 lstm_store_wt(a.y + ((int64_t)b * S + tt) * 2 * H + (int64_t)d * H + u0 + 4 * part,
                               *reinterpret_cast<const unsigned long long*>(&s_h[b][4 * part]));
         }
-        if (step + 1 < S && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0)) lstm_grid_signal(ps.tickets + d);
+        // (a block that gave up publishes its NaN slice but takes no more tickets: tickets of a block that runs ahead without
+        //  waiting would lift the count over the target of blocks still waiting and release them with finite, stale operands)
+        if (step + 1 < S && s_poison == 0 && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0)) lstm_grid_signal(ps.tickets + d);
     }
 }
 
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(const LstmArgs
                                   4 * part,
                               *reinterpret_cast<const unsigned long long*>(&s_dg[gate][b][4 * part]));
         }
-        if (step > 0 && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0)) lstm_grid_signal(ps.tickets + d);
+        if (step > 0 && s_poison == 0 && !(a.test_drop == step && blockIdx.x == 0 && blockIdx.y == 0)) lstm_grid_signal(ps.tickets + d);
     }
 }
 
