@@ -71,7 +71,6 @@ PROTOTYPES = {
     "icka_gemm_set_ablation": (c_i32, [c_i32]),
     "icka_gemm_set_warp_specialized": (c_i32, [c_i32]),
     "icka_gemm_set_w3_grid": (c_i32, [c_i32]),
-    "icka_gemm_set_l2_touch": (c_i32, [c_i32]),
     "icka_gemm_set_stamp_buffer": (c_i32, [c_vp]),
     "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
                             c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),

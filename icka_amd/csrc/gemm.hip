@@ -40,7 +40,6 @@ struct GemmArgs {
     int epi, c_f32;
     int a_vec, b_vec;  // operand rows may be read with 16-byte loads (ld % 8 == 0, base 16-B aligned)
     int abl;           // diagnostic ablation of the fast path: 1 = no MFMA/LDS reads, 2 = no DMA staging
-    int touch;         // 128 x 96 NT / NN kernel: k-tiles of L2 touch-ahead (0 = off), see gemm_ws_body
     float* colsum; int colsum_acc;  // TN fast path: colsum[m] (+)= sum_k A[k,m] (bias gradient fused into dW = dY^T.X)
     int n96ok;                  // fast path + N % 96 == 0: the 128x96 tile is an option
     int n64ok;                  // everything aligned except N % 128: N % 64 == 0 -> the 128x64 tile (NT only)
@@ -848,17 +847,8 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-// PF ("touch-ahead", the M = 4096 x N = 768 grids of 256 tiles of 128 x 96): in the step the operands of these GEMMs are not in
-// the L2s when the kernel starts (activations were written by other XCDs, weights were evicted long ago), and the stamped
-// in-step loop runs at 1050 - 1250 cycles per k-tile against 759 with L2-resident operands (profiles/r03_gemm_touch.txt).
-// One compute wave per block reads one dword of each of "its share" of the lines of the k-tile g.touch tiles ahead -- the
-// XCD's 32 blocks hold 4 row tiles x 8 column tiles, so an A line is needed by 8 blocks and a B line by 4: each block touches
-// 1/8 of its A tile's lines and 1/4 of its B tile's (40 lines, one load instruction) -- so that the LDS-DMA loads issued two
-// tiles later find the lines in L2.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false,
-          bool PF = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
-    static_assert(!PF || (BNT == 96 && !A_KM && !CONV && DIST == 2), "touch-ahead: 96-wide NT / NN");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
@@ -871,23 +861,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
     tile_origin(bid, nb, g.M / BM, g.N / BNT, m0, n0, BNT);
     const int nk = g.K / BK;
     const int wr = ((wave & 3) >> 1) * 64, wc = (wave & 1) * (BNT / 2);
-    // (PF) this lane's line of the k-tile 0 images and its advance per k-tile, in elements; nullptr = lane not used
-    const bf16_t* pf_ptr = nullptr;
-    int64_t pf_step = 0;
-    // the touched dwords land in 256 scratch bytes behind the ring (LDS-DMA: no destination register, nothing ever waits for them)
-    const uint32_t pf_lds = lds0 + NBUF * 2 * TILE_BYTES;
-    if constexpr (PF) {
-        if (wave == 0) {
-            const int a_share = (n0 / BNT) & 7, b_share = (m0 / BM) & 3;
-            if (lane < 16) { pf_ptr = g.A + (int64_t)(m0 + 16 * a_share + lane) * g.lda; pf_step = BK; }
-            else if (!B_KM && lane < 40) { pf_ptr = g.B + (int64_t)(n0 + 24 * b_share + (lane - 16)) * g.ldb; pf_step = BK; }
-            else if (B_KM && lane < 48) {
-                const int j = (lane - 16) + 32 * b_share;          // 64 k-rows x 2 lines of 64 columns
-                pf_ptr = g.B + (int64_t)(j >> 1) * g.ldb + n0 + (j & 1) * 64;
-                pf_step = (int64_t)BK * g.ldb;
-            }
-        }
-    }
 #ifdef ICKA_GEMM_STAMP
     const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
     unsigned long long ph1 = 0, ph2 = 0;
@@ -1102,36 +1075,16 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #ifdef ICKA_GEMM_STAMP
         ph1 = __builtin_amdgcn_s_memtime();
 #endif
-// (PF) touch this block's share of the lines of k-tile TT
-#define ICKA_TOUCH(TT)                                                                               \
-    do {                                                                                             \
-        if constexpr (PF) {                                                                          \
-            if (wave == 0) {                                                                         \
-                const int tt_ = (TT);                                                                \
-                if (pf_ptr != nullptr && tt_ < nk) {                                                 \
-                    uint32_t keep_;                                                                  \
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"             \
-                                 "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"                 \
-                                 : "=&s"(keep_) : "v"(pf_ptr + (int64_t)tt_ * pf_step), "s"(pf_lds) : "memory"); \
-                }                                                                                    \
-            }                                                                                        \
-        }                                                                                            \
-    } while (0)
-        if constexpr (PF) {   // the first tiles ahead of the loop's own touches
-            for (int t = NBUF - 1; t < g.touch; ++t) ICKA_TOUCH(t);
-        }
         ICKA_READ(pa0, pb0, 0, 0);
         ICKA_READ(pa1, pb1, 0, 1);
         int nxt = NBUF > 1 ? 1 : 0;     // ring slot of tile kt+1
         int kt = 0;
         for (; kt + 2 <= nk - 1; kt += 2) {
             ICKA_SYNC();                         // barrier kt+1
-            ICKA_TOUCH(kt + g.touch);
             ICKA_RM(qa0, qb0, nxt, 0, pa0, pb0);
             ICKA_RM(qa1, qb1, nxt, 1, pa1, pb1);
             nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
             ICKA_SYNC();                         // barrier kt+2
-            ICKA_TOUCH(kt + 1 + g.touch);
             ICKA_RM(pa0, pb0, nxt, 0, qa0, qb0);
             ICKA_RM(pa1, pb1, nxt, 1, qa1, qb1);
             nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
@@ -1151,10 +1104,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #undef ICKA_MMA
 #undef ICKA_RM
 #undef ICKA_SYNC
-#undef ICKA_TOUCH
-        if constexpr (PF) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (long arrived) nothing of this wave is in flight when the ring is reused
-        }
         }
         // MFMA -> VALU read-after-write needs software wait states on gfx950 (8-pass MFMA: ~11).  hipcc's hazard
         // recognizer missed one across a block boundary here (<TN, 96-wide>, odd k-tile count: a v_mov of the last
@@ -1239,11 +1188,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
 #endif
 }
 
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false, bool PF = false>
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int BNT = 128, bool F16 = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES + (PF ? 256 : 0)];
-    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV, PF>(g, smem, blockIdx.x, gridDim.x);
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV>(g, smem, blockIdx.x, gridDim.x);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1429,7 +1378,6 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
-int g_touch = 5;   // icka_gemm_set_l2_touch: k-tiles of L2 touch-ahead in the 128 x 96 NT / NN kernel (0 = off)
 int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
 static int gemm_w3_grid(int M, int N, int bnw) {
@@ -1525,14 +1473,7 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else if (g_nbuf == 5 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_touch > 0 && !A_KM && nb96 == 256 && g.N / 96 == 8 && g.K1 == 0 && g.K / BK > g_touch &&
-                                 g.lda % 64 == 0 && g.ldb % 64 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 127) == 0 &&
-                                 (reinterpret_cast<uintptr_t>(g.B) & 127) == 0) {
-                            if constexpr (!A_KM) {
-                                g.touch = g_touch;
-                                hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16, false, true>), dim3(nb96), dim3(512), 0, st, g);
-                            }
-                        } else
+                        else
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
@@ -2122,11 +2063,6 @@ static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
     else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 4>), dim3(total), dim3(256), 0, st, ga);
     ICKA_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int icka_gemm_set_l2_touch(int tiles) {
-    g_touch = tiles < 0 ? 0 : (tiles > 16 ? 16 : tiles);
     return 0;
 }
 

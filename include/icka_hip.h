@@ -127,10 +127,6 @@ int icka_gemm_set_warp_specialized(int on);
  * pn * M + pm * N; 8 / 4 / 2 / 1: force pm where it divides the tile grid (8 = the row-major runs of rounds 1-2).  Results
  * do not depend on it. */
 int icka_gemm_set_w3_grid(int pm);
-/* L2 touch-ahead of the 128 x 96-tile NT / NN kernel on grids of 32 x 8 tiles (M = 4096 x N = 768): one wave per block reads one
- * dword of its share of the lines of the k-tile ``tiles`` ahead, so that the operand loads issued later hit the L2.
- * 0 = off; default 5.  Results do not depend on it. */
-int icka_gemm_set_l2_touch(int tiles);
 /* Diagnostic builds (-DICKA_GEMM_STAMP) only: device buffer of [blocks][8] u64 receiving per-segment cycle sums of
  * the fast-path k-loop (vmcnt wait, barrier, DMA issue, LDS reads+MFMA, total cycles, 100 MHz real-time ticks, nk). */
 int icka_gemm_set_stamp_buffer(void* p);

@@ -20,7 +20,7 @@ for kv in args[:cut]:
         continue
     rc = getattr(lib, {"ring": "icka_gemm_set_ring", "tile_n": "icka_gemm_set_tile_n", "ws": "icka_gemm_set_warp_specialized",
                        "direct": "icka_gemm_set_direct_epilogue", "big": "icka_gemm_set_big_tiles",
-                       "w3grid": "icka_gemm_set_w3_grid", "touch": "icka_gemm_set_l2_touch"}[k])(int(v))
+                       "w3grid": "icka_gemm_set_w3_grid"}[k])(int(v))
     assert rc == 0, (k, v, rc)
 sys.argv = ["bench.py"] + args[cut + 1:]
 import bench  # noqa: E402
