@@ -442,7 +442,11 @@ __device__ __forceinline__ uint32_t off_cw(int row, int ch) { return row * 768 +
 // fetched over the fabric).  Measured on the c2 step: GEMM class 559 -> 593 TFLOP/s.
 template <typename T>
 __device__ __forceinline__ void st_out(T* p, const T v) {
+#ifdef ICKA_ST_TEMPORAL
+    *p = v;   // (diagnostic build: plain stores)
+#else
     __builtin_nontemporal_store(v, p);
+#endif
 }
 // epilogue operands that are read exactly once (GELU' input, residual / fan-in addend, accumulate-into output)
 template <typename T>
