@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
-ABI_VERSION = 4   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
+ABI_VERSION = 5   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
 GEMM_NT, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -174,6 +174,8 @@ PROTOTYPES = {
     "icka_dp_step_bump": (c_i32, [c_vp, c_vp]),
     "icka_dp_flag_set": (c_i32, [c_vp, c_vp, c_vp]),
     "icka_dp_flag_wait": (c_i32, [c_vp, C.c_uint32, c_vp, c_i32, c_vp]),
+    "icka_dp_poison_if": (c_i32, [c_vp, C.c_uint32, c_vp, c_i32, c_i32, c_vp]),
+    "icka_dp_poison_final": (c_i32, [c_vp, c_i32, C.c_uint32, c_vp, c_vp, c_i32, c_vp]),
     # ---- parameter update (csrc/optim.hip)
     "icka_optim_chunk_elems": (c_i64, []),
     "icka_optim_sqnorm": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),

@@ -13,8 +13,12 @@
 //     captured: per bucket the host enqueues, on the communication stream, a one-wave kernel that waits for the flag
 //     (icka_dp_flag_wait; bounded spin with s_sleep) ahead of the eager collective.  No graph cut, no cross-stream event
 //     inside the graph, no captured collective.  A wait that gives up raises a host-visible error word (host memory mapped
-//     into the device: the host polls it without a synchronisation) and poisons the bucket with a NaN, so an all-reduce of
-//     unfinished gradients can never pass for a result.
+//     into the device: the host polls it without a synchronisation) and stores the step number into the bucket's BAD WORD
+//     (device memory).  The poison is applied by kernels that RUN AFTER whatever could overwrite it: icka_dp_poison_if on the
+//     communication stream between the bucket's chunk cast and its all-reduce (the NaN travels to every rank) and again after
+//     the cast-back, and icka_dp_poison_final on the compute stream after the join at the end of the step, when the graph's
+//     late gradient stores are over -- so an all-reduce of unfinished gradients can never pass for a result (round 3 wrote the
+//     NaN from the wait kernel itself, and the chunk cast / a late GEMM epilogue overwrote it: ADVICE r03).
 #include "common.h"
 
 namespace {
@@ -54,7 +58,7 @@ __global__ void dp_flag_set_kernel(unsigned int* flag, const unsigned int* step)
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, step[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one wave on the communication stream, ahead of the bucket's all-reduce: returns once flag >= tag (wrap-safe)
-__global__ void dp_flag_wait_kernel(const unsigned int* flag, unsigned int tag, unsigned int* err, unsigned short* poison,
+__global__ void dp_flag_wait_kernel(const unsigned int* flag, unsigned int tag, unsigned int* err, unsigned int* bad,
                                     int max_polls) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int polls = 0;
@@ -62,10 +66,26 @@ __global__ void dp_flag_wait_kernel(const unsigned int* flag, unsigned int tag, 
         __builtin_amdgcn_s_sleep(64);
         if (++polls > max_polls) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (poison) *poison = (unsigned short)0x7fc0;   // bf16 NaN: reaches every rank through the all-reduce
+            if (bad) __hip_atomic_store(bad, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
     }
+}
+// one wave: NaN into the first n (<= 64) elements of a bucket whose wait gave up in step `tag`
+__global__ void dp_poison_if_kernel(const unsigned int* bad, unsigned int tag, void* target, int is_bf16, int n) {
+    if (blockIdx.x != 0 || (int)threadIdx.x >= n) return;
+    if (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) return;
+    if (is_bf16) reinterpret_cast<unsigned short*>(target)[threadIdx.x] = (unsigned short)0x7fc0;
+    else reinterpret_cast<unsigned int*>(target)[threadIdx.x] = 0x7fc00000u;
+}
+// end of the step, compute stream: every bucket whose bad word carries this step's number gets NaN in the first n elements of
+// its f32 gradients (starts[b] = first element of bucket b in the flat gradient buffer)
+__global__ void dp_poison_final_kernel(const unsigned int* bad, int n_buckets, unsigned int tag, float* gflat,
+                                       const int64_t* starts, int n) {
+    const int b = blockIdx.x;
+    if (b >= n_buckets || (int)threadIdx.x >= n) return;
+    if (__hip_atomic_load(bad + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) return;
+    reinterpret_cast<unsigned int*>(gflat + starts[b])[threadIdx.x] = 0x7fc00000u;
 }
 
 volatile unsigned int* g_dp_err_host = nullptr;
@@ -129,11 +149,27 @@ extern "C" int icka_dp_flag_set(void* flag_word, const void* step_word, void* st
     ICKA_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int icka_dp_flag_wait(const void* flag_word, uint32_t tag, void* poison_bf16, int32_t max_polls, void* stream) {
+extern "C" int icka_dp_flag_wait(const void* flag_word, uint32_t tag, void* bad_word, int32_t max_polls, void* stream) {
     if (!flag_word || max_polls <= 0) return ICKA_E_ARG;
     if (!g_dp_err_dev && icka_dp_init() != 0) return ICKA_E_ARG;
     hipLaunchKernelGGL(dp_flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned int*)flag_word, tag,
-                       g_dp_err_dev, (unsigned short*)poison_bf16, max_polls);
+                       g_dp_err_dev, (unsigned int*)bad_word, max_polls);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_dp_poison_if(const void* bad_word, uint32_t tag, void* target, int32_t target_is_bf16, int32_t n,
+                                 void* stream) {
+    if (!bad_word || !target || n <= 0 || n > 64) return ICKA_E_ARG;
+    hipLaunchKernelGGL(dp_poison_if_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned int*)bad_word, tag, target,
+                       target_is_bf16, n);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int icka_dp_poison_final(const void* bad_words, int32_t n_buckets, uint32_t tag, float* gflat,
+                                    const int64_t* starts_dev, int32_t n, void* stream) {
+    if (!bad_words || !gflat || !starts_dev || n_buckets <= 0 || n <= 0 || n > 64) return ICKA_E_ARG;
+    hipLaunchKernelGGL(dp_poison_final_kernel, dim3(n_buckets), dim3(64), 0, (hipStream_t)stream, (const unsigned int*)bad_words,
+                       n_buckets, tag, gflat, starts_dev, n);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -1592,6 +1592,9 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     if (g.f16 && d->op != ICKA_GEMM_NT) return ICKA_E_ARG;       // fp16 operands: forward (NT) GEMMs only
     if (g.c_f16 && d->beta != 0.f) return ICKA_E_ARG;              // fp16 outputs are never accumulated into
     if (g.C3 && !g.c_f16 && !g.c_f32) return ICKA_E_ARG;           // C3 = bf16 twin of an fp16 or an f32 main output
+    // the wire copy of an f32 output is compiled into the weight-gradient (TN) instances of the fast paths only: any other
+    // op would return 0 and leave the wire buffer stale
+    if (g.C3 && g.c_f32 && d->op != ICKA_GEMM_TN) return ICKA_E_ARG;
     g.c3_only = d->c3_only != 0;
     if (g.c3_only && !(g.C3 && g.c_f32 && d->beta == 0.f && d->epilogue == ICKA_EPI_NONE)) return ICKA_E_ARG;
     if (g.c_f16 && d->colsum_out) return ICKA_E_ARG;

@@ -98,9 +98,28 @@ class GradReducer(object):
             K._lib.load().icka_dp_init()
             for bi in range(len(self.buckets)):   # until the calibration step has shown who writes wire copies: cast all
                 self._tables[bi] = K.dp_chunk_table([self.buckets[bi]], arena.device)
-        if self.is_cuda and self.backend == "nccl" and self.world > 1 or lstm_reserved_cus is not None:
+        # persistent BiLSTM grids must stay co-resident beside RCCL's workgroups: reserve CUs for as long as this reducer
+        # lives (close() / __del__ restore what was reserved before)
+        self._prev_reserved = None
+        if (self.is_cuda and self.backend == "nccl" and self.world > 1) or lstm_reserved_cus is not None:
             from . import kernels as K
-            K.lstm_set_reserved_cus(LSTM_RESERVED_CUS if lstm_reserved_cus is None else lstm_reserved_cus)
+            self._prev_reserved = K.lstm_set_reserved_cus(LSTM_RESERVED_CUS if lstm_reserved_cus is None else lstm_reserved_cus)
+
+    def close(self) -> None:
+        """Detach from the arena and give back the CU reservation taken for the persistent BiLSTM kernels."""
+        if getattr(self, "_prev_reserved", None) is not None:
+            try:
+                from . import kernels as K
+                K.lstm_set_reserved_cus(self._prev_reserved)
+            except Exception:      # interpreter shutdown
+                pass
+            self._prev_reserved = None
+        a = getattr(self, "arena", None)
+        if a is not None and getattr(a, "reducer", None) is self:
+            a.reducer = None
+
+    def __del__(self):
+        self.close()
 
     # -------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -172,26 +191,33 @@ class GradReducer(object):
 
     def launch_now(self, idx: int, wait=None) -> None:
         """Issue bucket ``idx``'s all-reduce: on the side stream on devices, ordered after everything on the current
-        stream -- or, with ``wait = (device address of the flag word, tag, poll budget)`` (graph.FlaggedStep), after a
-        flag-wait kernel on the side stream and NOT after the current stream (which already holds the whole step's graph)."""
+        stream -- or, with ``wait = (device address of the flag word, tag, poll budget, device address of the bucket's bad
+        word)`` (graph.FlaggedStep), after a flag-wait kernel on the side stream and NOT after the current stream (which
+        already holds the whole step's graph).  A wait that gives up stores ``tag`` into the bad word; ``_allreduce`` then
+        poisons the bucket AFTER its chunk cast (so the NaN is what travels) and again after the cast-back."""
         s, e = self.buckets[idx]
         if self.is_cuda and self.backend == "nccl":
             if wait is None:
                 self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
+                bad = None
                 if wait is not None:
                     from . import kernels as K
-                    flag, tag, polls = wait
-                    # poison target of a wait that gives up: the bucket's first wire element, or the upper half of its
-                    # first f32 gradient (0x7fc0 there is a NaN as well)
-                    poison = self.gwire.data_ptr() + 2 * s if self.gwire is not None else self.arena.gflat.data_ptr() + 4 * s + 2
-                    K.check(K._lib.load().icka_dp_flag_wait(flag, tag & 0xFFFFFFFF, poison, polls, K._stream()),
+                    flag, tag, polls, bad_ptr = wait
+                    K.check(K._lib.load().icka_dp_flag_wait(flag, tag & 0xFFFFFFFF, bad_ptr, polls, K._stream()),
                             "icka_dp_flag_wait")
-                self._allreduce(idx)
+                    bad = (bad_ptr, tag & 0xFFFFFFFF)
+                self._allreduce(idx, bad)
         else:
             self._allreduce(idx)
 
-    def _allreduce(self, idx: int) -> None:
+    def _poison_if(self, bad, t: torch.Tensor) -> None:
+        """NaN into the first elements of ``t`` when the bucket's wait gave up in this step (icka_dp_poison_if)."""
+        from . import kernels as K
+        K.check(K._lib.load().icka_dp_poison_if(bad[0], bad[1], t.data_ptr(), int(t.dtype == torch.bfloat16), min(8, t.numel()),
+                                                K._stream()), "icka_dp_poison_if")
+
+    def _allreduce(self, idx: int, bad=None) -> None:
         s, e = self.buckets[idx]
         buf = self.arena.gflat[s:e]
         if self.diag:   # diagnostic only: leave out parts of the exchange to price them; wrong gradients (see __init__)
@@ -207,10 +233,17 @@ class GradReducer(object):
                 from . import kernels as K
                 K.dp_cast_chunks(self.arena.gflat, self.gwire, self._tables[idx])
                 w = self.gwire[s:e]
+                if bad is not None:
+                    self._poison_if(bad, w)      # after the cast (which rewrites un-wired slots), before the sum
                 dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
                 K.dp_cast_back_scaled(w, buf, 1.0 / self.world)
             else:
+                if bad is not None:
+                    self._poison_if(bad, buf)
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+            if bad is not None:
+                self._poison_if(bad, buf)        # (a late store of the graph may still land here: FlaggedStep poisons once
+                                                 # more on the compute stream after the join, icka_dp_poison_final)
             return
         # gloo has no AVG; device tensors go through the host (2-process tests on one GPU)
         if self.is_cuda:

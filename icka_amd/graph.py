@@ -1,29 +1,37 @@
 """Whole-step hipGraph capture (torch.cuda.CUDAGraph is a hipGraph on ROCm).
 
-A forward+backward step of the hot path is ~850 short kernel launches; issued eagerly from Python they cost ~10 us of
-host time each and the GPU starves once the kernels are fast.  The step is static (fixed shapes, no host sync, all
-scratch from the caching allocator, parameters/gradients in the ParamArena), so it is captured once and replayed.
-Dropout stays random across replays through the device-side nonce (icka_bump_dropout_nonce is the first node of the
-graph).
+A forward+backward step of the hot path is ~230 kernel launches at c2 (bert-base, 12 layers + 1 cross layer); issued eagerly
+from Python through ctypes + autograd they cost more host time than the kernels take on the GPU (bench.py reports both:
+``ms_per_step`` for the replayed graph, ``eager_ms_per_step`` for the same step launched eagerly).  The step is static
+(fixed shapes, no host sync, all scratch from the caching allocator, parameters/gradients in the ParamArena), so it is
+captured once and replayed.  Dropout stays random across replays through the device-side nonce (icka_bump_dropout_nonce is
+the first node of every graph).
 
-Contract
-  * Gradients are captured with beta = 0 (the capture happens right after zero_grad): every replay OVERWRITES the
-    gradient arena with this step's gradients -- a GraphedStep does not accumulate across calls.  After each replay
-    ``p.grad`` is re-attached to the arena views for every parameter that received a gradient at capture, so the
-    reference's loop (``model.zero_grad()`` / ``optimizer.zero_grad()`` after every step, My_cross_attention.py:843,
-    set_to_none or not) keeps working with ``optimizer.step()`` seeing this step's gradients.
-  * The optimizer runs outside the graph.  With the default shadow policy ("always") the bf16 re-cast of the
-    parameters is the first kernel inside the captured forward; with "tracked" it runs before the replay when a change
-    was seen.
+What the reference's loop does around a step (My_cross_attention.py:797-844) and how a step object follows it
+  * a NEW batch every step (``batch = tuple(t.to(device) for t in batch)``, :797-798): build the step with ``inputs=`` (the
+    first batch; a tuple / list / dict of tensors) and a ``step_fn`` that takes them; the tensors are cloned into STATIC
+    device buffers the captured kernels read, and ``gs(*batch)`` copies the new tensors into them (shape and dtype checked,
+    no reallocation, host or device sources) before the replay.  ``gs()`` replays on the buffers as they are.
+  * gradient accumulation over ``gradient_accumulation_steps`` micro-batches (:587-590, :821-822, :831): the step is
+    captured twice, lazily -- once with every gradient store as an overwrite (beta = 0) and once as an accumulation
+    (beta = 1).  Which one a call replays follows the same rule the eager kernels use per slot (ParamArena.grad_beta):
+    gradients the caller still holds (``p.grad`` is the arena view written earlier in this cycle) are accumulated into;
+    after ``model.zero_grad()`` / ``optimizer.zero_grad()`` (:843, set_to_none or not) the next call starts a new cycle.
+    The 1 / k of the loss (:821-822) stays in the caller's ``step_fn``, as in the reference.
+  * ``p.grad`` is re-attached to the arena views after every replay (a replay runs no Python), so ``clip_grad_norm_``,
+    ``optimizer.step()`` and ``scheduler.step()`` (:841-843) see this cycle's gradients.
+  * The optimizer runs outside the graph.  With the default shadow policy ("always") the bf16 re-cast of the parameters is
+    the first kernel inside the captured forward; with "tracked" it runs before the replay when a change was seen.
   * ``close()`` (also run by ``__del__``) unregisters the dropout nonce, whose device memory this object owns.
 
 Data parallel: ``FlaggedStep`` (one graph, bucket-ready flag words, eager all-reduces behind flag-wait kernels on the
-communication stream) is the default; ``SegmentedStep`` is the fallback it replaced: a captured graph with a side-stream branch per gradient bucket costs ~0.17 ms for the
-first fork and ~25 us for each further one on this runtime (tools/graph_fork_probe.py), and needs the collective library
-to be capturable.  ``SegmentedStep`` instead cuts the step into LINEAR graphs at the points where a gradient bucket
-becomes final and issues the bucket's all-reduce eagerly, on the communication stream, between two segment launches:
-the host enqueues everything ahead of the GPU, the compute stream sees the segments back to back, and RCCL is never
-captured.
+communication stream) is the default; with ``accumulate=k`` only the k-th micro-batch of a cycle exchanges gradients (apex
+DDP's delay_allreduce under accumulation; the first k-1 replay graphs captured without the reducer).  ``SegmentedStep`` is
+the fallback it replaced: a captured graph with a side-stream branch per gradient bucket costs ~0.17 ms for the first fork
+and ~25 us for each further one on this runtime (tools/graph_fork_probe.py), and needs the collective library to be
+capturable.  ``SegmentedStep`` instead cuts the step into LINEAR graphs at the points where a gradient bucket becomes final
+and issues the bucket's all-reduce eagerly, on the communication stream, between two segment launches: the host enqueues
+everything ahead of the GPU, the compute stream sees the segments back to back, and RCCL is never captured.
 """
 from __future__ import annotations
 
@@ -34,58 +42,174 @@ import torch
 from . import kernels as K
 
 
-class GraphedStep(object):
-    def __init__(self, model: torch.nn.Module, step_fn: Callable[[], torch.Tensor], warmup: int = 3):
-        """``step_fn`` runs forward + backward (+ gradient all-reduce launches) and returns the loss tensor.
-        (Replaying the grouped weight-gradient launches on a side stream behind flag waits, beside the dependent chain of
-        backward, was built and measured in round 3: -0.6 %, inside the noise -- profiles/r03_wgrad_side_stream.txt.)"""
+class StaticInputs(object):
+    """Static device copies of a step's input tensors: the addresses a captured graph reads, refreshed per call.
+
+    ``example``: tuple / list (positional arguments of ``step_fn``) or dict (keyword arguments) of tensors; entries that are
+    not tensors (None, numbers) are passed through unchanged and must not change between calls."""
+
+    def __init__(self, example, device):
+        if isinstance(example, torch.Tensor):
+            example = (example,)
+        self.is_dict = isinstance(example, dict)
+        items = list(example.items()) if self.is_dict else list(enumerate(example))
+        self.keys = [k for k, _ in items]
+        self.static = []
+        for _, v in items:
+            if isinstance(v, torch.Tensor):
+                self.static.append(torch.empty(v.shape, dtype=v.dtype, device=device).copy_(v))
+            else:
+                self.static.append(v)
+
+    def call(self, fn):
+        if self.is_dict:
+            return fn(**dict(zip(self.keys, self.static)))
+        return fn(*self.static)
+
+    def refresh(self, args, kwargs) -> None:
+        """Copy a new batch into the static buffers (asynchronous copies on the current stream, ahead of the replay)."""
+        if len(args) == 1 and not kwargs and isinstance(args[0], (tuple, list, dict)):
+            if isinstance(args[0], dict):
+                args, kwargs = (), args[0]
+            else:
+                args = tuple(args[0])
+        if self.is_dict:
+            if args or set(kwargs) != set(self.keys):
+                raise TypeError("step inputs: expected keyword tensors %s, got %d positional + %s"
+                                % (sorted(map(str, self.keys)), len(args), sorted(kwargs)))
+            new = [kwargs[k] for k in self.keys]
+        else:
+            if kwargs or len(args) != len(self.keys):
+                raise TypeError("step inputs: expected %d positional tensors, got %d (+ keywords %s)"
+                                % (len(self.keys), len(args), sorted(kwargs)))
+            new = list(args)
+        for k, dst, src in zip(self.keys, self.static, new):
+            if not isinstance(dst, torch.Tensor):
+                if isinstance(src, torch.Tensor) or src != dst:
+                    raise TypeError("step input %r was captured as the constant %r and cannot change per call" % (k, dst))
+                continue
+            if not isinstance(src, torch.Tensor):
+                raise TypeError("step input %r: expected a tensor, got %s" % (k, type(src).__name__))
+            if src.shape != dst.shape or src.dtype != dst.dtype:
+                raise ValueError("step input %r: captured as %s %s, got %s %s -- a captured step has static shapes (pad the "
+                                 "batch as the reference's loader does, My_cross_attention.py:375-379, or build another step)"
+                                 % (k, tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+
+
+class _StepBase(object):
+    """Shared by the step objects: the dropout nonce, the static inputs, warm-up, and which capture a call replays."""
+
+    def _setup(self, model, step_fn, inputs):
         dev = next(model.parameters()).device
         self.model = model
+        self.device = dev
+        self.inputs = StaticInputs(inputs, dev) if inputs is not None else None
+        self._user_fn = step_fn
         self.nonce = torch.zeros(2, dtype=torch.int32, device=dev)
         K.set_dropout_nonce(self.nonce)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # capture prerequisites: allocator / library warm-up off the default stream
-            for _ in range(warmup):
-                model.zero_grad()
+        self.side = torch.cuda.Stream(device=dev)
+
+    def _step(self):
+        return self.inputs.call(self._user_fn) if self.inputs is not None else self._user_fn()
+
+    def _warm(self, n):
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):     # capture prerequisites: allocator / library warm-up off the default stream
+            for _ in range(n):
+                self.model.zero_grad()
                 K.bump_dropout_nonce(self.nonce)
-                step_fn()
-        torch.cuda.current_stream().wait_stream(side)
+                self._step()
+        torch.cuda.current_stream().wait_stream(self.side)
         torch.cuda.synchronize()
-        self.arena = model._icka_arena
-        self.graph = torch.cuda.CUDAGraph()
-        model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
-        # thread_local: only this thread's calls are checked against the capture -- with a process group alive, RCCL's
-        # watchdog / heartbeat threads make runtime calls of their own that must not invalidate it
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            K.bump_dropout_nonce(self.nonce)
-            self.loss = step_fn()
-        self._grad_slots = [s for s in self.arena.order if s.live]
 
-    def __call__(self) -> torch.Tensor:
-        if self.graph is None:
-            raise RuntimeError("GraphedStep is closed")
-        if self.arena.shadow_policy != "always":   # "always": the cast is a node of the captured forward
-            self.arena.sync()
-        # a persistent LSTM launch of an EARLIER replay that gave up a hand-off (NaN-poisoned outputs): raise at this host
-        # touch-point (a host read of a mapped word, no synchronisation)
-        K.lstm_check_error("detected before a GraphedStep replay")
-        self.graph.replay()
-        self.arena.attach_grads(self._grad_slots)   # replay runs no Python: p.grad may have been dropped by zero_grad
-        return self.loss
+    def _refresh(self, args, kwargs):
+        if args or kwargs:
+            if self.inputs is None:
+                raise TypeError("this step was built without inputs=: it replays a closure over fixed tensors")
+            self.inputs.refresh(args, kwargs)
 
-    def close(self) -> None:
-        """Release the graph and unregister the dropout nonce (the kernels keep a raw pointer to it)."""
+    def _cycle_state(self):
+        """(accumulate, stale): accumulate = some gradient of this step is still held by the caller (ParamArena._is_live:
+        written earlier in this accumulation cycle, p.grad still the arena view); stale = the slots that are NOT, which an
+        accumulating replay must see as zeros (the eager path's 'mixed' rule, ParamArena.grad_beta)."""
+        A = self.arena
+        stale = [s for s in self._grad_slots if not A._is_live(s)]
+        if len(stale) == len(self._grad_slots):
+            return False, ()
+        return True, stale
+
+    def _zero(self, slots):
+        A = self.arena
+        for s in slots:
+            A.gflat[s.off:s.off + s.numel].zero_()
+
+    def _close_nonce(self):
         if getattr(self, "nonce", None) is not None:
             try:
                 K.clear_dropout_nonce_if(self.nonce)
             except Exception:      # interpreter shutdown: the library may already be gone
                 pass
             self.nonce = None
-        self.graph = None
 
     def __del__(self):
         self.close()
+
+
+class GraphedStep(_StepBase):
+    def __init__(self, model: torch.nn.Module, step_fn: Callable[..., torch.Tensor], warmup: int = 3, inputs=None):
+        """``step_fn`` runs forward + backward and returns the loss tensor; with ``inputs`` (tuple / list / dict of tensors:
+        the first batch) it is called with static copies of them and ``gs(*batch)`` refreshes those per call (module
+        docstring).  (Replaying the grouped weight-gradient launches on a side stream behind flag waits, beside the dependent
+        chain of backward, was built and measured in round 3: -0.6 %, inside the noise -- profiles/r03_wgrad_side_stream.txt.)"""
+        self._setup(model, step_fn, inputs)
+        self._warm(warmup)
+        self.arena = model._icka_arena
+        self._graphs = {}
+        self._loss = {}
+        model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
+        self._capture(False)
+        self._grad_slots = [s for s in self.arena.order if s.live]
+        self.loss = self._loss[False]
+
+    def _capture(self, accumulate: bool) -> None:
+        if accumulate:      # every gradient store of the capture must see its slot live: beta = 1, no 'mixed' memsets
+            self.arena.attach_grads(self._grad_slots)
+        g = torch.cuda.CUDAGraph()
+        # thread_local: only this thread's calls are checked against the capture -- with a process group alive, RCCL's
+        # watchdog / heartbeat threads make runtime calls of their own that must not invalidate it
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            K.bump_dropout_nonce(self.nonce)
+            self._loss[accumulate] = self._step()
+        self._graphs[accumulate] = g
+
+    @property
+    def graph(self):
+        return self._graphs.get(False) if self._graphs is not None else None
+
+    def __call__(self, *args, **kwargs) -> torch.Tensor:
+        if self._graphs is None:
+            raise RuntimeError("GraphedStep is closed")
+        self._refresh(args, kwargs)
+        if self.arena.shadow_policy != "always":   # "always": the cast is a node of the captured forward
+            self.arena.sync()
+        # a persistent LSTM launch of an EARLIER replay that gave up a hand-off (NaN-poisoned outputs): raise at this host
+        # touch-point (a host read of a mapped word, no synchronisation)
+        K.lstm_check_error("detected before a GraphedStep replay")
+        accumulate, stale = self._cycle_state()
+        if accumulate and True not in self._graphs:
+            self._capture(True)                 # (a capture executes nothing: the gradients held so far are untouched)
+        self._zero(stale)
+        self._graphs[accumulate].replay()
+        self.arena.attach_grads(self._grad_slots)   # replay runs no Python: p.grad may have been dropped by zero_grad
+        self.loss = self._loss[accumulate]
+        return self.loss
+
+    def close(self) -> None:
+        """Release the graphs and unregister the dropout nonce (the kernels keep a raw pointer to it)."""
+        self._close_nonce()
+        self._graphs = None
 
 
 class _Capture(object):
@@ -120,25 +244,17 @@ class _Capture(object):
         self.begin()
 
 
-class SegmentedStep(object):
+class SegmentedStep(_StepBase):
     """Data-parallel step as a chain of linear hipGraphs with eager bucket all-reduces between them (module docstring).
     ``step_fn`` runs forward + backward + ``reducer.finish()`` and returns the loss; ``reducer`` must already be
-    attached to the model's arena.  Same gradient contract as ``GraphedStep``."""
+    attached to the model's arena.  ``inputs`` / per-call refresh as ``GraphedStep``; every call overwrites the gradients
+    and exchanges them (no accumulation across calls: the fallback form -- ``FlaggedStep`` has ``accumulate=``)."""
 
-    def __init__(self, model: torch.nn.Module, step_fn: Callable[[], torch.Tensor], reducer, warmup: int = 3):
-        dev = next(model.parameters()).device
-        self.model, self.reducer = model, reducer
-        self.nonce = torch.zeros(2, dtype=torch.int32, device=dev)
-        K.set_dropout_nonce(self.nonce)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # warm-up (the first of these steps calibrates the reducer's write counts)
-            for _ in range(max(warmup, 2)):
-                model.zero_grad()
-                K.bump_dropout_nonce(self.nonce)
-                step_fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+    def __init__(self, model: torch.nn.Module, step_fn: Callable[..., torch.Tensor], reducer, warmup: int = 3, inputs=None):
+        self._setup(model, step_fn, inputs)
+        self.reducer = reducer
+        dev, side = self.device, self.side
+        self._warm(max(warmup, 2))              # (the first of these steps calibrates the reducer's write counts)
         self.arena = model._icka_arena
         model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
         cap = _Capture()
@@ -149,7 +265,7 @@ class SegmentedStep(object):
             with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
                 cap.begin()
                 K.bump_dropout_nonce(self.nonce)
-                self.loss = step_fn()           # its reducer.finish() reports the remaining buckets, without joining
+                self.loss = self._step()        # its reducer.finish() reports the remaining buckets, without joining
                 # the embedding backward is the last kernel of the step and makes the last bucket final: the segment
                 # opened by that cut would be empty -- give it one (no-op) node
                 self._pad = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -162,9 +278,10 @@ class SegmentedStep(object):
         self.segments = cap.segments
         self._grad_slots = [s for s in self.arena.order if s.live]
 
-    def __call__(self) -> torch.Tensor:
+    def __call__(self, *args, **kwargs) -> torch.Tensor:
         if self.segments is None:
             raise RuntimeError("SegmentedStep is closed")
+        self._refresh(args, kwargs)
         if self.arena.shadow_policy != "always":
             self.arena.sync()
         K.lstm_check_error("detected before a SegmentedStep replay")
@@ -177,16 +294,8 @@ class SegmentedStep(object):
         return self.loss
 
     def close(self) -> None:
-        if getattr(self, "nonce", None) is not None:
-            try:
-                K.clear_dropout_nonce_if(self.nonce)
-            except Exception:
-                pass
-            self.nonce = None
+        self._close_nonce()
         self.segments = None
-
-    def __del__(self):
-        self.close()
 
 
 class _FlagCapture(object):
@@ -206,7 +315,7 @@ class _FlagCapture(object):
         pass
 
 
-class FlaggedStep(object):
+class FlaggedStep(_StepBase):
     """Data-parallel step as ONE hipGraph with eager, overlapped all-reduces (the default of bench.py at N > 1).
 
     ``SegmentedStep`` pays for every cut (a hipGraph drains before the next one starts: +0.21 ms for 5 cuts at c2) and an
@@ -214,81 +323,137 @@ class FlaggedStep(object):
     where a gradient bucket becomes final, a one-thread node that stores the step number into the bucket's FLAG WORD
     (icka_dp_flag_set) -- is captured whole.  A replay launches the graph on the compute stream and then, per bucket in the
     order the flags will rise, enqueues on the reducer's communication stream a one-wave kernel that waits for that flag
-    (icka_dp_flag_wait: bounded spin with s_sleep; a wait that gives up raises a host-visible error word and poisons the
-    bucket with a NaN) followed by the bucket's eager all-reduce -- the tagged-word hand-off of csrc/lstm.hip between two
-    streams.  No collective is captured, no graph has a second branch, the compute stream never waits for the
-    communication stream before the end of the step.  Same gradient contract as ``GraphedStep``.
-    ``step_fn`` runs forward + backward + ``reducer.finish()`` and returns the loss; ``reducer`` is attached to the arena."""
+    (icka_dp_flag_wait: bounded spin with s_sleep; a wait that gives up raises a host-visible error word and the bucket's
+    cast / cast-back launches then fill it with NaN, dp.GradReducer._allreduce) followed by the bucket's eager all-reduce --
+    the tagged-word hand-off of csrc/lstm.hip between two streams.  No collective is captured, no graph has a second branch,
+    the compute stream never waits for the communication stream before the end of the step.
+    ``step_fn`` runs forward + backward + ``reducer.finish()`` and returns the loss; ``reducer`` is attached to the arena.
+
+    ``inputs`` / per-call refresh as ``GraphedStep``.  ``accumulate=k`` (the reference's gradient_accumulation_steps,
+    My_cross_attention.py:587-590, :831): a cycle is k calls; calls 1..k-1 replay graphs captured WITHOUT the reducer
+    (overwrite, then accumulate: no flags, no wire copies, nothing exchanged) and the k-th replays the flagged graph, whose
+    gradient stores accumulate (k > 1) and whose buckets carry the sum of the k micro-batches.  A cycle also restarts
+    whenever the caller dropped the gradients (``zero_grad``) before its k-th call."""
 
     FLAG0 = 16           # sync words: [0] step counter (bumped by the graph's first node), [FLAG0 + i] flag of bucket i
     WAIT_POLLS = 1 << 20   # ~3 s of s_sleep(64) polls before a wait gives up
 
-    def __init__(self, model: torch.nn.Module, step_fn: Callable[[], torch.Tensor], reducer, warmup: int = 3):
-        dev = next(model.parameters()).device
+    def __init__(self, model: torch.nn.Module, step_fn: Callable[..., torch.Tensor], reducer, warmup: int = 3, inputs=None,
+                 accumulate: int = 1):
         if not (reducer.is_cuda and reducer.backend == "nccl"):
             raise RuntimeError("FlaggedStep needs the nccl (= RCCL) backend on a ROCm device")
-        self.model, self.reducer = model, reducer
-        self.nonce = torch.zeros(2, dtype=torch.int32, device=dev)
-        K.set_dropout_nonce(self.nonce)
-        self.sync = torch.zeros(self.FLAG0 + len(reducer.buckets) + 16, dtype=torch.int32, device=dev)
+        if accumulate < 1:
+            raise ValueError("accumulate must be >= 1")
+        self._setup(model, step_fn, inputs)
+        self.reducer = reducer
+        self.accumulate = int(accumulate)
+        dev = self.device
+        nb = len(reducer.buckets)
+        # sync words: [0] step counter, [FLAG0 + i] flag of bucket i, [FLAG0 + nb + i] BAD word of bucket i (the step number
+        # of a wait that gave up)
+        self.sync = torch.zeros(self.FLAG0 + 2 * nb + 16, dtype=torch.int32, device=dev)
+        self._starts = torch.tensor([lo for lo, _ in reducer.buckets], dtype=torch.int64, device=dev)
         K.check(K._lib.load().icka_dp_init(), "icka_dp_init")
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # warm-up (the first of these steps calibrates the reducer's write counts)
-            for _ in range(max(warmup, 2)):
-                model.zero_grad()
-                K.bump_dropout_nonce(self.nonce)
-                step_fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        self._warm(max(warmup, 2))              # (the first of these steps calibrates the reducer's write counts)
         self.arena = model._icka_arena
-        model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
-        cap = _FlagCapture(self.sync)
-        self.graph = torch.cuda.CUDAGraph()
-        reducer.capture = cap
-        try:
-            # backward on THIS thread: the flag nodes are launched from inside backward (GradReducer.mark_final)
-            with torch.autograd.set_multithreading_enabled(False), \
-                    torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-                K.check(K._lib.load().icka_dp_step_bump(self.sync.data_ptr(), K._stream()), "icka_dp_step_bump")
-                K.bump_dropout_nonce(self.nonce)
-                self.loss = step_fn()           # its reducer.finish() reports the remaining buckets (flags at the end)
-        finally:
-            reducer.capture = None
-        torch.cuda.synchronize()
-        self.order = cap.order
-        if sorted(self.order) != list(range(len(reducer.buckets))):
-            raise RuntimeError("FlaggedStep: buckets flagged during capture %s != all %d buckets" % (self.order, len(reducer.buckets)))
-        self._tag = 0
-        self._grad_slots = [s for s in self.arena.order if s.live]
         import os
         self._polls = int(os.environ.get("ICKA_DP_WAIT_POLLS", self.WAIT_POLLS))
-        self._flag_ptr = [self.sync.data_ptr() + 4 * (self.FLAG0 + i) for i in range(len(reducer.buckets))]
+        self._flag_ptr = [self.sync.data_ptr() + 4 * (self.FLAG0 + i) for i in range(nb)]
+        self._bad_ptr = [self.sync.data_ptr() + 4 * (self.FLAG0 + nb + i) for i in range(nb)]
+        self._test_late = ()     # tests: buckets whose wait is made to give up (it polls a word that no node ever sets)
+        self._never_ptr = self.sync.data_ptr() + 4 * (self.FLAG0 + 2 * nb + 8)
+        self._tag = 0
+        self._micro = 0
+        self._graphs = {}        # (accumulate, exchange) -> CUDAGraph
+        self._loss = {}
+        self._order = {}         # exchange graphs: the order their flags rise in
+        model.zero_grad()                       # gradients dropped -> captured kernels overwrite (beta = 0)
+        first = (False, self.accumulate == 1)
+        self._capture(*first)
+        self._grad_slots = [s for s in self.arena.order if s.live]
+        self.loss = self._loss[first]
+        self.graph = self._graphs[first]
+        self.order = self._order.get(first, [])
 
-    def __call__(self) -> torch.Tensor:
-        if self.graph is None:
+    def _capture(self, accumulate: bool, exchange: bool) -> None:
+        reducer, arena = self.reducer, self.arena
+        if accumulate:
+            arena.attach_grads(self._grad_slots)
+        g = torch.cuda.CUDAGraph()
+        key = (accumulate, exchange)
+        if exchange:
+            cap = _FlagCapture(self.sync)
+            reducer.capture = cap
+            arena.reducer = reducer
+            try:
+                # backward on THIS thread: the flag nodes are launched from inside backward (GradReducer.mark_final)
+                with torch.autograd.set_multithreading_enabled(False), \
+                        torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
+                    K.check(K._lib.load().icka_dp_step_bump(self.sync.data_ptr(), K._stream()), "icka_dp_step_bump")
+                    K.bump_dropout_nonce(self.nonce)
+                    self._loss[key] = self._step()   # its reducer.finish() reports the remaining buckets (flags at the end)
+            finally:
+                reducer.capture = None
+            torch.cuda.synchronize()
+            if sorted(cap.order) != list(range(len(reducer.buckets))):
+                raise RuntimeError("FlaggedStep: buckets flagged during capture %s != all %d buckets"
+                                   % (cap.order, len(reducer.buckets)))
+            self._order[key] = cap.order
+        else:
+            # a micro-batch that is not the last of its cycle: the same step with the reducer detached (no wire copies, no
+            # flags; the step_fn's reducer.finish() is made a no-op for the duration of the capture)
+            arena.reducer = None
+            reducer.finish = lambda: None       # (instance attribute shadowing the method; removed below)
+            try:
+                with torch.autograd.set_multithreading_enabled(False), \
+                        torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
+                    K.bump_dropout_nonce(self.nonce)
+                    self._loss[key] = self._step()
+            finally:
+                arena.reducer = reducer
+                del reducer.finish
+            torch.cuda.synchronize()
+        self._graphs[key] = g
+
+    def __call__(self, *args, **kwargs) -> torch.Tensor:
+        if self._graphs is None:
             raise RuntimeError("FlaggedStep is closed")
+        self._refresh(args, kwargs)
         if self.arena.shadow_policy != "always":
             self.arena.sync()
         K.lstm_check_error("detected before a FlaggedStep replay")
         K.dp_check_error("detected before a FlaggedStep replay")
-        self._tag += 1                          # == the step counter the graph's first node is about to write
-        self.graph.replay()
-        r = self.reducer
-        for idx in self.order:
-            r.launch_now(idx, wait=(self._flag_ptr[idx], self._tag, self._polls))
-        r.join()
+        accumulate, stale = self._cycle_state()
+        if not accumulate:
+            self._micro = 0                     # the caller dropped the gradients: a new cycle starts here
+        exchange = self._micro == self.accumulate - 1
+        key = (accumulate, exchange)
+        if key not in self._graphs:
+            self._capture(*key)
+        self._zero(stale)
+        if exchange:
+            self._tag += 1                      # == the step counter the graph's first node is about to write
+        self._graphs[key].replay()
+        if exchange:
+            r = self.reducer
+            for idx in self._order[key]:
+                late = idx in self._test_late
+                r.launch_now(idx, wait=(self._never_ptr if late else self._flag_ptr[idx], self._tag,
+                                        64 if late else self._polls, self._bad_ptr[idx]))
+            r.join()
+            # after the join nothing of this step writes gradients any more: a bucket whose wait gave up gets its NaN here
+            # for good (one launch; the bad words carry the step number, so nothing is ever reset)
+            nb = len(r.buckets)
+            K.check(K._lib.load().icka_dp_poison_final(self._bad_ptr[0], nb, self._tag & 0xFFFFFFFF, self.arena.gflat.data_ptr(),
+                                                      self._starts.data_ptr(), 8, K._stream()), "icka_dp_poison_final")
+            self._micro = 0
+        else:
+            self._micro += 1
         self.arena.attach_grads(self._grad_slots)
+        self.loss = self._loss[key]
         return self.loss
 
     def close(self) -> None:
-        if getattr(self, "nonce", None) is not None:
-            try:
-                K.clear_dropout_nonce_if(self.nonce)
-            except Exception:
-                pass
-            self.nonce = None
+        self._close_nonce()
+        self._graphs = None
         self.graph = None
-
-    def __del__(self):
-        self.close()

@@ -99,7 +99,7 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
     """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched).
     Operands are bf16, or -- op NT only, the "mixed16" forward GEMMs -- both fp16; ``out`` may then be fp16 too, with
     ``out3`` an optional bf16 copy of it.  With an f32 ``out``, ``out3`` is the data-parallel wire copy (bf16 of the final,
-    beta-accumulated value) the weight-gradient GEMMs write for dp.GradReducer."""
+    beta-accumulated value) the weight-gradient GEMMs write for dp.GradReducer: op TN only."""
     odt = A.dtype if A.dtype == F16 else BF16     # operand dtype of this launch
     if odt == F16 and op != GEMM_NT:
         raise ValueError("fp16 operands: NT (forward) GEMMs only")
@@ -132,6 +132,8 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
         _mat(out3, "out3")
         if tuple(out3.shape) != (M, N):
             raise ValueError("out3 must be [%d,%d]" % (M, N))
+        if out.dtype == F32 and op != GEMM_TN:
+            raise ValueError("out3 beside an f32 output (the data-parallel wire copy) exists on weight-gradient (TN) GEMMs only")
     d = GemmDesc()
     d.op, d.M, d.N, d.K, d.K1 = op, M, N, K, K1
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
@@ -502,8 +504,15 @@ def lstm_check_error(where: str = "") -> None:
             % ((" (" + where + ")") if where else "", rc))
 
 
-def lstm_set_reserved_cus(n: int) -> None:
+_LSTM_RESERVED = [0]
+
+
+def lstm_set_reserved_cus(n: int) -> int:
+    """Set the CUs kept free of persistent BiLSTM blocks (process-global); returns the previous value so that the caller can
+    restore it (dp.GradReducer.close)."""
     check(_lib.load().icka_lstm_set_reserved_cus(int(n)), "icka_lstm_set_reserved_cus")
+    prev, _LSTM_RESERVED[0] = _LSTM_RESERVED[0], int(n)
+    return prev
 
 
 def linear_small_m(x, W, bias, y, act: int = 0):
@@ -818,8 +827,9 @@ def dp_check_error(where: str = "") -> None:
     if lib.icka_dp_error() != 0:
         lib.icka_dp_clear_error()
         raise DpFlagError("icka_amd data-parallel step%s: a bucket-ready wait on the communication stream gave up (the "
-                          "compute graph did not reach the bucket's flag in time); the gradients of that step are NaN-"
-                          "poisoned" % ((" (" + where + ")") if where else ""))
+                          "compute graph did not reach the bucket's flag in time); the first gradients of that bucket were "
+                          "set to NaN after the exchange (icka_dp_poison_if / icka_dp_poison_final), so a global-norm clip or "
+                          "an optimizer step that consumed them produced NaN" % ((" (" + where + ")") if where else ""))
 
 
 # ------------------------------------------------------------------------------------------------- per-sample gates

@@ -503,10 +503,14 @@ class LinearFn(torch.autograd.Function):
         fused = lin.bias is not None and N % 128 == 0 and x.shape[1] % 128 == 0 and M % 64 == 0
         gw = A.g(lin.weight)
         beta_w = A.grad_beta(lin.weight)
+        # + the data-parallel wire copy -- for outputs on the aligned fast path only: a skinny gradient (the classifier's
+        # 13 x 768 over K = 4096 tokens) keeps its split-K form, which a wire copy would switch off (gemm.hip: the copy needs
+        # the final value in one epilogue); the bucket's chunk cast covers such a slot
+        wire = A.wire_of(gw, beta_w) if (N % 128 == 0 and x.shape[1] % 128 == 0) else {}
         K.gemm(K.GEMM_TN, dyv, x, gw, beta=beta_w,
                colsum_out=A.g(lin.bias) if fused else None,
                colsum_accumulate=fused and A.grad_beta(lin.bias) > 0,   # bias gradient inside the wgrad GEMM
-               **A.wire_of(gw, beta_w))                                  # + the data-parallel wire copy
+               **wire)
         if lin.bias is not None and not fused:
             csw = A.workspace("colsum", K._lib.load().icka_colsum_workspace_floats(N))
             K.colsum(dyv, A.g(lin.bias), csw, accumulate=A.grad_beta(lin.bias) > 0)

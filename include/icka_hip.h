@@ -28,8 +28,10 @@ extern "C" {
  * 3: icka_lstm_set_handoff, icka_lstm_set_batch_split, icka_attn_dropout_mask (additive).
  * 4: round 3 -- icka_lstm_clear_error, icka_lstm_set_reserved_cus, icka_lstm_test_hooks; a hand-off wait that gives up now
  *    NaN-poisons the recurrence and raises a host-visible error word; icka_gemm_desc.C3 may accompany an f32 main output
- *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h, icka_optim_* (additive). */
-#define ICKA_ABI_VERSION 4
+ *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h, icka_optim_* (additive).
+ * 5: round 4 -- icka_dp_flag_wait's third argument is the bucket's BAD WORD (it no longer writes the NaN itself);
+ *    icka_dp_poison_if, icka_dp_poison_final; icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN. */
+#define ICKA_ABI_VERSION 5
 int icka_abi_version(void);
 const char* icka_build_arch(void);
 
@@ -75,7 +77,7 @@ typedef struct icka_gemm_desc {
     /* "mixed16" forward GEMMs (op NT only): operands A, B (A2, B2) are IEEE fp16 instead of bf16
      * (v_mfma_f32_16x16x32_f16, same rate); c_is_f32 == 2 makes the main output fp16 (saturating at +-65504, beta must
      * be 0) and C3, if not NULL, receives a bf16 copy of it (the operand the bf16 weight-gradient GEMM reads later).
-     * With an f32 main output (c_is_f32 == 1, any op) C3 is the DATA-PARALLEL WIRE COPY: a bf16 copy of the final value
+     * With an f32 main output (c_is_f32 == 1, op TN ONLY: other ops return ICKA_E_ARG) C3 is the DATA-PARALLEL WIRE COPY: a bf16 copy of the final value
      * (after beta-accumulation) written by the same epilogue -- the weight-gradient GEMMs fill the bf16 all-reduce buffer
      * of icka_amd/dp.py themselves instead of a separate cast pass over the gradients (see icka_dp_* below). */
     int32_t ab_f16;
@@ -580,11 +582,18 @@ int icka_x_scale_by_ratio(const float* x, float* y, const float* num, const floa
  *   icka_dp_step_bump(step_word): step_word[0] += 1 -- first node of the graph;
  *   icka_dp_flag_set(flag_word, step_word): flag_word[0] = step_word[0] -- a node right after the kernel that finishes the
  *     bucket's last gradient;
- *   icka_dp_flag_wait(flag_word, tag, poison_bf16, max_polls): a one-wave kernel for the COMMUNICATION stream that returns once
+ *   icka_dp_flag_wait(flag_word, tag, bad_word, max_polls): a one-wave kernel for the COMMUNICATION stream that returns once
  *     flag_word[0] >= tag (wrap-safe), polling with s_sleep at most max_polls times; if it gives up it raises the error word
- *     read by icka_dp_error() (host memory mapped into the device: no synchronisation) and, when poison_bf16 is given,
- *     stores a bf16 NaN there (the first wire element of the bucket: it reaches every rank's gradients through the
- *     all-reduce).  icka_dp_init() maps the error word (not inside a stream capture); icka_dp_clear_error() resets it. */
+ *     read by icka_dp_error() (host memory mapped into the device: no synchronisation) and, when bad_word (device memory,
+ *     one uint32 per bucket) is given, stores tag there.  The NaN itself is written by kernels ordered AFTER everything
+ *     that could overwrite it:
+ *   icka_dp_poison_if(bad_word, tag, target, target_is_bf16, n): if bad_word[0] == tag, NaN into target[0 .. n) (n <= 64;
+ *     bf16 or f32 elements) -- on the communication stream between the bucket's chunk cast and its all-reduce (the NaN
+ *     reaches every rank through the sum) and again after the cast-back;
+ *   icka_dp_poison_final(bad_words, n_buckets, tag, gflat, starts_dev, n): one launch on the COMPUTE stream after the join
+ *     that ends the step (the graph's late gradient stores are over): for every bucket b with bad_words[b] == tag, NaN into
+ *     gflat[starts_dev[b] .. + n).
+ *   icka_dp_init() maps the error word (not inside a stream capture); icka_dp_clear_error() resets it. */
 int64_t icka_dp_chunk_elems(void);
 int icka_dp_cast_chunks(const float* src, void* dst_bf16, const int64_t* table_dev, int32_t n_chunks, void* stream);
 int icka_dp_cast_back_scaled(const void* src_bf16, float* dst, int64_t n, float scale, void* stream);
@@ -593,7 +602,10 @@ int icka_dp_error(void);
 int icka_dp_clear_error(void);
 int icka_dp_step_bump(void* step_word, void* stream);
 int icka_dp_flag_set(void* flag_word, const void* step_word, void* stream);
-int icka_dp_flag_wait(const void* flag_word, uint32_t tag, void* poison_bf16, int32_t max_polls, void* stream);
+int icka_dp_flag_wait(const void* flag_word, uint32_t tag, void* bad_word, int32_t max_polls, void* stream);
+int icka_dp_poison_if(const void* bad_word, uint32_t tag, void* target, int32_t target_is_bf16, int32_t n, void* stream);
+int icka_dp_poison_final(const void* bad_words, int32_t n_buckets, uint32_t tag, float* gflat, const int64_t* starts_dev,
+                         int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * The parameter update that follows backward in the reference's loop (My_cross_attention.py:831-844: clip_grad_norm_(1.0),

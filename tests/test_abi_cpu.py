@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _header_functions():
         assert hasattr(lib, name), name
-    assert lib.icka_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.icka_abi_version() == _lib.ABI_VERSION == 5
     assert lib.icka_build_arch() == b"gfx950"
     assert lib.icka_ln_bwd_workspace_floats(768) == 1024 * 4 * 768
 

@@ -77,3 +77,38 @@ def test_graphed_data_parallel_step_matches_the_eager_step(tmp_path, comm, bar, 
     assert sum(res["after"]) == res["buckets"]
     assert res["worst"] < bar, res
     assert abs(res["loss"] - res["ref_loss"]) < 1e-6
+
+
+def _run_flag_worker(tmp_path, what, comm):
+    out = str(tmp_path / "flag.pt")
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_flag_worker.py"), str(_free_port()), out, what, comm])
+    try:
+        assert p.wait(timeout=300) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+    return torch.load(out)
+
+
+@pytest.mark.parametrize("comm,bar", [("f32", 2e-6), ("bf16", 6e-3)])
+def test_flagged_step_accumulates_and_exchanges_on_the_last_micro_batch(tmp_path, comm, bar):
+    """``FlaggedStep(inputs=, accumulate=3)`` over RCCL at world 1, three different micro-batches per cycle (the reference
+    accumulates 5, My_cross_attention.py:587-590, :831): gradients after each cycle == the eager sum; only every third call
+    bumps the step word (= exchanges); three captures exist: (overwrite, quiet), (accumulate, quiet), (accumulate, exchange)."""
+    res = _run_flag_worker(tmp_path, "accumulate", comm)
+    print("\n[flagged accumulate=3, %s buckets] worst gradient rel-L2 vs eager sum %.3e; step word after each call %s; captures %s"
+          % (comm, res["worst"], res["step_words"], res["graphs"]))
+    assert res["worst"] < bar, res
+    assert res["step_words"] == [0, 0, 1, 1, 1, 2], res
+    assert res["graphs"] == [(False, False), (True, False), (True, True)], res
+
+
+@pytest.mark.parametrize("comm", ["f32", "bf16"])
+def test_flag_wait_that_gives_up_poisons_the_bucket_and_raises(tmp_path, comm):
+    """the NaN of a wait that gave up must survive the bucket's chunk cast and late gradient stores -- for the
+    embedding-table bucket (cast by the chunk launch: round 3's poison was overwritten there) and for the first bucket (whose
+    GEMM epilogues store AFTER the early all-reduce)."""
+    res = _run_flag_worker(tmp_path, "poison", comm)
+    print("\n[flag give-up, %s buckets] %s" % (comm, res))
+    assert res["clean_finite"] and res["poisoned"] == [True, True] and res["others_finite"], res
+    assert res["norm_is_nan"] and res["error_word"] == 1 and res["raised"] and res["recovered_finite"], res

@@ -1,0 +1,179 @@
+"""GPU: the reference's OWN optimisation recipe through the captured step.
+
+My_cross_attention.py:797-844 per optimisation step: ``gradient_accumulation_steps`` (default 5, :587-590) micro-batches of
+DIFFERENT inputs, each moved to the device (:797-798), loss / 5 (:821-822), backward (:827), then clip_grad_norm_(1.0)
+(:841), optimizer.step() (AdamW over the two weight-decay groups of :743-751), scheduler.step() (linear warm-up, :756-757)
+and model.zero_grad() (:842-844).  Here that loop runs twice on copies of one seeded model -- launched eagerly, and through
+``GraphedStep(model, step_fn, inputs=first_batch)`` with ``gs(*batch)`` per micro-batch -- and the loss sequence and every
+parameter after two optimisation steps are compared (dropout off: eval mode).  fp32 mode: the two runs launch the same
+kernels on the same data, bar 1e-6 (the embedding scatter's f32 atomics are order-dependent in the last bit); bf16: same bar
+class, one bf16 rounding of slack."""
+import copy
+
+import pytest
+import torch
+
+import icka_amd
+from icka_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+K_ACC = 5          # gradient_accumulation_steps, My_cross_attention.py:587-590
+OPT_STEPS = 2
+NAMES = ("input_ids", "segment_ids", "input_mask", "added_attention_mask", "visual_embeds_mean", "visual_embeds_att", "labels")
+
+
+def _model(precision):
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    cfg = BertConfig(512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=64)
+    m = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=36)
+    synth.fill_module_(m)
+    return icka_amd.set_precision(m.cuda().eval(), precision)
+
+
+def _batches(n, device="cuda"):
+    out = []
+    for i in range(n):
+        b = synth.synthetic_batch(4, 32, 36, vocab_size=512, seed=100 + i)
+        out.append(tuple(b[k].to(device) for k in NAMES))
+    return out
+
+
+def _recipe(model, run_micro, batches, use_arena_adamw):
+    """The reference's loop (:797-844) around ``run_micro(batch) -> loss``."""
+    from icka_amd.optim import ArenaAdamW, reference_param_groups
+    total = OPT_STEPS
+    if use_arena_adamw:
+        opt = ArenaAdamW(model, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(reference_param_groups(model, 0.01), lr=1e-3)
+    warm = 1      # get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps) is this LambdaLR
+    sched = torch.optim.lr_scheduler.LambdaLR(
+        opt, lambda s: float(s) / max(1, warm) if s < warm else max(0.0, float(total + 1 - s) / max(1, total + 1 - warm)))
+    model.zero_grad()
+    losses = []
+    for step, batch in enumerate(batches):
+        loss = run_micro(batch)
+        losses.append(loss.item())
+        if (step + 1) % K_ACC == 0:
+            if not use_arena_adamw:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            sched.step()
+            model.zero_grad()
+    torch.cuda.synchronize()
+    return losses, {n: p.detach().clone() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("arena_adamw", [False, True], ids=["torch-adamw", "arena-adamw"])
+@pytest.mark.parametrize("precision,bar", [("fp32", 2e-6), ("bf16", 2e-4)])
+def test_reference_recipe_eager_equals_graphed(precision, bar, arena_adamw):
+    from icka_amd.graph import GraphedStep
+    base = _model(precision)
+    batches = _batches(K_ACC * OPT_STEPS)
+    results = []
+    for graphed in (False, True):
+        model = copy.deepcopy(base)
+
+        def micro(ids, seg, mask, added, vmean, vatt, labels):
+            loss = model(ids, seg, mask, added, vmean, vatt, labels=labels) / K_ACC      # :821-822
+            loss.backward()
+            return loss
+
+        if graphed:
+            gs = GraphedStep(model, micro, inputs=batches[0])
+            run = lambda b: gs(*b)          # noqa: E731  (new tensors every call: copied into the static buffers)
+        else:
+            run = lambda b: micro(*b)       # noqa: E731
+        results.append(_recipe(model, run, batches, arena_adamw))
+        if graphed:
+            assert set(gs._graphs) == {False, True}, "one overwrite capture + one accumulate capture"
+            gs.close()
+    (le, pe), (lg, pg) = results
+    print("\n[%s, %s] losses eager %s\n%s graphed %s" % (precision, "ArenaAdamW" if arena_adamw else "torch AdamW",
+                                                       ["%.6f" % x for x in le], " " * 12, ["%.6f" % x for x in lg]))
+    assert le[K_ACC] != le[0] and abs(le[-1] - le[0]) > 1e-5      # different inputs, and the weights moved
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= bar * max(1.0, abs(a)), (le, lg)
+    worst, wkey = 0.0, ""
+    for n in pe:
+        d = (pe[n] - pg[n]).abs().max().item() / (pe[n].abs().max().item() + 1e-6)
+        if d > worst:
+            worst, wkey = d, n
+    print("    worst parameter difference after %d optimisation steps: %.3e (%s), bar %.1e" % (OPT_STEPS, worst, wkey, bar))
+    assert worst <= bar, (worst, wkey)
+
+
+def test_accumulated_gradients_equal_the_sum_of_micro_batches():
+    """5 replays between two zero_grads == the eager sum of the 5 micro-batch gradients (fp32 mode), with host-resident
+    batches (the reference moves every batch to the device inside the loop) and zero_grad(set_to_none=False) in between."""
+    from icka_amd.graph import GraphedStep
+    model = _model("fp32")
+    batches = _batches(K_ACC, device="cpu")
+    dev_batches = [tuple(t.cuda() for t in b) for b in batches]
+
+    def micro(ids, seg, mask, added, vmean, vatt, labels):
+        loss = model(ids, seg, mask, added, vmean, vatt, labels=labels) / K_ACC
+        loss.backward()
+        return loss
+
+    model.zero_grad()
+    for b in dev_batches:
+        micro(*b)
+    torch.cuda.synchronize()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    gs = GraphedStep(model, micro, inputs=dev_batches[0])
+    for cycle in range(2):
+        if cycle == 0:
+            model.zero_grad()                   # set_to_none=True: the first replay of the cycle overwrites
+        else:
+            model.zero_grad(set_to_none=False)  # zeros kept: the first replay accumulates onto them
+        for b in batches:
+            gs(*b)                              # pageable host tensors: copy_ stages them
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if n in ref:
+                assert p.grad is not None, n
+                err = (p.grad - ref[n]).abs().max().item() / (ref[n].abs().max().item() + 1e-12)
+                assert err < 2e-6, (cycle, n, err)
+    gs.close()
+
+
+def test_refresh_checks_shapes_dtypes_and_arity():
+    from icka_amd.graph import GraphedStep
+    model = _model("bf16")
+    b = _batches(1)[0]
+
+    def micro(ids, seg, mask, added, vmean, vatt, labels):
+        loss = model(ids, seg, mask, added, vmean, vatt, labels=labels)
+        loss.backward()
+        return loss
+
+    gs = GraphedStep(model, micro, inputs=b, warmup=1)
+    with pytest.raises(ValueError, match="static shapes"):
+        gs(*(t[:2] for t in b))
+    with pytest.raises(ValueError, match="static shapes"):
+        gs(*([b[0].int()] + list(b[1:])))
+    with pytest.raises(TypeError):
+        gs(*b[:-1])
+    l0 = gs(*b).item()
+    l1 = gs(b).item()                 # a single tuple is unpacked
+    assert l0 == l1
+    no_inputs = GraphedStep(model, lambda: micro(*b), warmup=1)
+    with pytest.raises(TypeError, match="without inputs"):
+        no_inputs(*b)
+    # keyword form
+    d = dict(zip(NAMES, b))
+
+    def micro_kw(**kw):
+        return micro(*(kw[k] for k in NAMES))
+
+    gk = GraphedStep(model, micro_kw, inputs=d, warmup=1)
+    model.zero_grad()
+    assert gk(**d).item() == l0
+    with pytest.raises(TypeError):
+        gk(*b)
+    for g in (gs, no_inputs, gk):
+        g.close()
