@@ -242,6 +242,43 @@ def self_launch(n: int, json_fd: int) -> int:
     return rc
 
 
+def dry_rank(args, json_fd, world, rank, local_rank):
+    """ICKA_BENCH_DRY=1: rehearsal of the N-rank FLOW of this file without a GPU -- what can be proven about `--gpus 8` on a
+    box with fewer devices (this pool allows at most 6 processes on a card): launcher, port, rendezvous over gloo, the
+    rank -> device map (LOCAL_RANK, as the reference's `--local_rank`, My_cross_attention.py:653-657), barrier + max-over-ranks
+    timing, legs that only rank 0 runs while the others wait at the barrier, and the relay of rank 0's single JSON line.  The
+    step itself is a sleep: the JSON line says so ("dry": true) and carries no roofline / cpu_baseline."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    dev_index = 0 if os.environ.get("ICKA_BENCH_ONE_GPU") else local_rank
+    devs = [None] * world
+    dist.all_gather_object(devs, (rank, dev_index))
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 + 0.0005 * rank)           # the slowest rank sets the time
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    if rank == 0:
+        time.sleep(0.2)                              # rank-0-only legs (roofline, cpu baseline): the others wait below
+    dist.barrier()
+    if rank == 0:
+        out = {"metric": "MNER samples/sec (fwd+bwd) at seq=%d, %d regions, bs=%d per GPU" % (args.seq, args.regions, args.batch),
+               "value": round(args.batch * world * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)", "data": "none",
+               "dry": True, "rank_devices": sorted(devs),
+               "config": {"workload": "DRY RUN of the launch flow: no kernels ran", "global_batch": args.batch * world,
+                          "parallelism": "dp%d" % world}, "roofline": None, "cpu_baseline": None}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +357,8 @@ def main():
         sys.exit(self_launch(args.gpus, json_fd))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if os.environ.get("ICKA_BENCH_DRY"):
+        return dry_rank(args, json_fd, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in icka_amd)")
     if os.environ.get("ICKA_BENCH_ONE_GPU"):   # rehearsal of the N > 1 flow on a one-GPU box (with ICKA_BENCH_BACKEND=gloo)

@@ -375,6 +375,31 @@ __global__ void scalar_ratio_kernel(float* out, const float* num, const float* d
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = num[0] / fmaxf(den[0], 1.f);
 }
 
+// Several device-to-device copies in ONE launch (the per-call input refresh of a captured step: ids, masks, labels, region
+// features -- seven tensors of 32 KB .. 9.4 MB at c2).  blockIdx.y = copy, blockIdx.x strides over its 16-byte words; a
+// copy that is not 16-byte sized / aligned goes byte by byte (small tensors only).
+constexpr int COPY_MAX = 8;
+struct CopyMany {
+    const char* src[COPY_MAX];
+    char* dst[COPY_MAX];
+    long long bytes[COPY_MAX];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyMany t) {
+    const int e = blockIdx.y;
+    const long long nb = t.bytes[e];
+    const char* s = t.src[e];
+    char* d = t.dst[e];
+    const bool vec = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | (uintptr_t)nb) & 15) == 0;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+    if (vec) {
+        const long long nv = nb >> 4;
+        for (long long i = tid; i < nv; i += nth)
+            reinterpret_cast<u32x4*>(d)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(s) + i);
+    } else {
+        for (long long i = tid; i < nb; i += nth) d[i] = s[i];
+    }
+}
+
 }  // namespace
 
 const uint32_t* g_icka_nonce = nullptr;
@@ -391,6 +416,25 @@ extern "C" int icka_bump_dropout_nonce(uint32_t* device_words, void* stream) {
     return 0;
 }
 extern "C" const char* icka_build_arch(void) { return "gfx950"; }
+
+extern "C" int icka_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream) {
+    if (n < 0 || n > COPY_MAX || (n > 0 && (!src || !dst || !bytes))) return ICKA_E_ARG;
+    if (n == 0) return 0;
+    CopyMany t{};
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] < 0 || (bytes[i] > 0 && (!src[i] || !dst[i]))) return ICKA_E_ARG;
+        t.src[i] = (const char*)src[i];
+        t.dst[i] = (char*)dst[i];
+        t.bytes[i] = bytes[i];
+        most = bytes[i] > most ? bytes[i] : most;
+    }
+    long long blocks = (most / 16 + 256 * 4 - 1) / (256 * 4);     // ~4 x 16 bytes per thread for the largest copy
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int icka_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
     if (!src || !dst) return ICKA_E_ARG;

@@ -83,6 +83,7 @@ class StaticInputs(object):
                 raise TypeError("step inputs: expected %d positional tensors, got %d (+ keywords %s)"
                                 % (len(self.keys), len(args), sorted(kwargs)))
             new = list(args)
+        dev_src, dev_dst = [], []
         for k, dst, src in zip(self.keys, self.static, new):
             if not isinstance(dst, torch.Tensor):
                 if isinstance(src, torch.Tensor) or src != dst:
@@ -94,8 +95,16 @@ class StaticInputs(object):
                 raise ValueError("step input %r: captured as %s %s, got %s %s -- a captured step has static shapes (pad the "
                                  "batch as the reference's loader does, My_cross_attention.py:375-379, or build another step)"
                                  % (k, tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
-            if src.data_ptr() != dst.data_ptr():
-                dst.copy_(src, non_blocking=True)
+            if src.data_ptr() == dst.data_ptr():
+                continue
+            if src.device == dst.device and src.is_contiguous():
+                dev_src.append(src)
+                dev_dst.append(dst)
+            else:
+                dst.copy_(src, non_blocking=True)       # host tensors (pinned or pageable), strided sources
+        # device-resident sources: ONE launch for all of them (icka_copy_many), 8 per launch
+        for i in range(0, len(dev_src), 8):
+            K.copy_many(dev_src[i:i + 8], dev_dst[i:i + 8])
 
 
 class _StepBase(object):
@@ -172,6 +181,7 @@ class GraphedStep(_StepBase):
         self._capture(False)
         self._grad_slots = [s for s in self.arena.order if s.live]
         self.loss = self._loss[False]
+        model.zero_grad()                       # a capture executes nothing: the gradients it "wrote" do not exist
 
     def _capture(self, accumulate: bool) -> None:
         if accumulate:      # every gradient store of the capture must see its slot live: beta = 1, no 'mixed' memsets
@@ -277,6 +287,7 @@ class SegmentedStep(_StepBase):
         torch.cuda.synchronize()
         self.segments = cap.segments
         self._grad_slots = [s for s in self.arena.order if s.live]
+        model.zero_grad()                       # a capture executes nothing: the gradients it "wrote" do not exist
 
     def __call__(self, *args, **kwargs) -> torch.Tensor:
         if self.segments is None:
@@ -374,6 +385,7 @@ class FlaggedStep(_StepBase):
         self.loss = self._loss[first]
         self.graph = self._graphs[first]
         self.order = self._order.get(first, [])
+        model.zero_grad()                       # a capture executes nothing: the gradients it "wrote" do not exist
 
     def _capture(self, accumulate: bool, exchange: bool) -> None:
         reducer, arena = self.reducer, self.arena

@@ -504,6 +504,21 @@ def lstm_check_error(where: str = "") -> None:
             % ((" (" + where + ")") if where else "", rc))
 
 
+def copy_many(srcs, dsts) -> None:
+    """dsts[i] <- srcs[i] (contiguous device tensors of equal byte size, at most 8) in one launch."""
+    import ctypes as C
+    n = len(srcs)
+    if n != len(dsts) or n > 8:
+        raise ValueError("copy_many: up to 8 (source, destination) pairs")
+    sp = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    for a, b in zip(srcs, dsts):
+        if a.numel() * a.element_size() != b.numel() * b.element_size() or not (a.is_contiguous() and b.is_contiguous()):
+            raise ValueError("copy_many: contiguous tensors of equal byte size")
+    nb = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in srcs])
+    check(_lib.load().icka_copy_many(sp, dp, nb, n, _stream()), "icka_copy_many")
+
+
 _LSTM_RESERVED = [0]
 
 

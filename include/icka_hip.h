@@ -30,10 +30,15 @@ extern "C" {
  *    NaN-poisons the recurrence and raises a host-visible error word; icka_gemm_desc.C3 may accompany an f32 main output
  *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h, icka_optim_* (additive).
  * 5: round 4 -- icka_dp_flag_wait's third argument is the bucket's BAD WORD (it no longer writes the NaN itself);
- *    icka_dp_poison_if, icka_dp_poison_final; icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN. */
+ *    icka_dp_poison_if, icka_dp_poison_final, icka_copy_many; icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN. */
 #define ICKA_ABI_VERSION 5
 int icka_abi_version(void);
 const char* icka_build_arch(void);
+
+/* n <= 8 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; src / dst / bytes are HOST arrays) in one launch: the
+ * per-call input refresh of a captured step (icka_amd/graph.py: StaticInputs), which stands where the reference's loop
+ * moves a new batch to the device every step (My_cross_attention.py:797-798).  16-byte words when pointers and size allow. */
+int icka_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GEMM on MFMA (v_mfma_f32_16x16x32_bf16), bf16 operands, fp32 accumulate.

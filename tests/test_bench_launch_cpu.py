@@ -47,3 +47,25 @@ def test_self_launch_stops_ranks_that_never_finish(tmp_path):
     err = p.stderr.decode("utf-8", "replace")
     assert p.returncode == 124, (p.returncode, err[-2000:])
     assert "stopping the ranks" in err, err[-2000:]
+
+
+def test_bench_gpus_8_launch_flow_dry_run():
+    """`python bench.py --gpus 8` at the world size BASELINE's c3 names, as far as a box without 8 GPUs can
+    prove it (ICKA_BENCH_DRY=1: gloo, the step is a sleep): eight ranks start under the self-launcher, rank r maps to device r
+    (My_cross_attention.py:653-657), the timing is the max over ranks, rank 0 alone runs its extra legs while the others wait,
+    and exactly one JSON line comes back with the whole-job value."""
+    import json
+    env = dict(os.environ, ICKA_BENCH_DRY="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = p.stderr.decode("utf-8", "replace")
+    assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, (lines, err[-2000:])
+    out = json.loads(lines[0])
+    assert out["dry"] and out["n_gpus"] == 8 and out["config"]["global_batch"] == 256 and out["config"]["parallelism"] == "dp8"
+    assert out["rank_devices"] == [[r, r] for r in range(8)]
+    assert out["ms_per_step"] >= 2.0 + 0.5 * 7 - 0.2          # the slowest rank's sleep: max over ranks, not rank 0's
+    assert out["value"] == __import__("pytest").approx(256 / (out["ms_per_step"] * 1e-3), rel=1e-3)

@@ -16,26 +16,30 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_gpus_2_launches_its_own_ranks():
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_gpus_n_launches_its_own_ranks(n):
+    """n = 4: as many ranks as this pool lets share one card beside the test process (at most 6 processes on a GPU); the
+    world-8 launch flow itself is rehearsed without kernels in tests/test_bench_launch_cpu.py (ICKA_BENCH_DRY)."""
     env = dict(os.environ, ICKA_BENCH_BACKEND="gloo", ICKA_BENCH_ONE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-roofline", "--optimizer-steps", "2"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline", "--optimizer-steps", "2", "--eager-steps", "2"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
     err = p.stderr.decode("utf-8", "replace")
     assert p.returncode == 0, err[-4000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, (lines, err[-2000:])        # stdout carries exactly ONE line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 64
+    assert out["n_gpus"] == n and out["config"]["parallelism"] == "dp%d" % n and out["config"]["global_batch"] == 32 * n
     assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 3
-    assert out["value"] == pytest.approx(64 / (out["ms_per_step"] * 1e-3), rel=1e-3)    # whole-job samples/s
+    assert out["value"] == pytest.approx(32 * n / (out["ms_per_step"] * 1e-3), rel=1e-3)    # whole-job samples/s
+    assert out["eager_ms_per_step"] > 0
     # (a rehearsal through gloo and host memory: the two legs' step times are dominated by host transfers and differ by more
     #  than the update costs -- only presence and sanity of the key are checked here; tests/test_optim_gpu.py prices the update)
     assert out["with_optimizer_ms_per_step"] > 0 and out["with_optimizer"]["steps"] >= 1
     assert "self-launch" in err
-    print("\n[bench --gpus 2, self-launched, one-GPU gloo rehearsal] %s" % lines[0][:300])
+    print("\n[bench --gpus %d, self-launched, one-GPU gloo rehearsal] %s" % (n, lines[0][:300]))
 
 
 def test_bench_exit_status_of_a_failing_rank_is_relayed():

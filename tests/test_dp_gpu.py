@@ -112,3 +112,29 @@ def test_flag_wait_that_gives_up_poisons_the_bucket_and_raises(tmp_path, comm):
     print("\n[flag give-up, %s buckets] %s" % (comm, res))
     assert res["clean_finite"] and res["poisoned"] == [True, True] and res["others_finite"], res
     assert res["norm_is_nan"] and res["error_word"] == 1 and res["raised"] and res["recovered_finite"], res
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs of one node (RCCL over xGMI)")
+@pytest.mark.parametrize("comm,bar", [("f32", 1e-5), ("bf16", 1.2e-2)])
+def test_two_gpus_rccl_flagged_step(tmp_path, comm, bar):
+    """the bench's default N > 1 path (FlaggedStep, bf16 wire, c3_only, flag waits + eager RCCL all-reduces) with
+    two real ranks on two GPUs == one rank on the concatenated batch.  Skipped on the one-GPU test box; the first multi-GPU
+    node that runs the suite exercises it (torch.cuda.device_count() does not initialise the GPU on this image)."""
+    port = str(_free_port())
+    outs = [str(tmp_path / ("n%d.pt" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_nccl_worker.py"), str(r), "2", port, outs[r], comm])
+             for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r in range(2):
+        res = torch.load(outs[r])
+        print("\n[2 GPUs, RCCL, flagged step, %s buckets, rank %d] worst gradient rel-L2 vs one rank on the full batch %.3e at %s"
+              % (comm, r, res["worst"], res["key"]))
+        assert res["worst"] < bar and res["error_word"] == 0, res
+        if comm == "bf16":
+            assert res["wire_only"] > 0, res

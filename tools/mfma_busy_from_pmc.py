@@ -21,6 +21,7 @@ import json
 import re
 
 SIMDS = 1024
+NOMINAL_GHZ = 2.4
 XCDS = 8
 
 
@@ -77,13 +78,20 @@ def main():
             continue
         ns, nd = dur.get(k, [0.0, 0])
         row = {"launches": n, "mfma_util_pct": round(100.0 * b / (gui * SIMDS), 2),
+               # the same busy cycles against the cycles the NOMINAL 2.4 GHz clock offers in the kernel's traced duration:
+               # directly comparable with FLOP / time / 2.5 PFLOP/s (1024 SIMDs x 1024 bf16 FLOP per SIMD-cycle x 2.4 GHz);
+               # GUI_ACTIVE spans more than the dispatch on launches well under 0.3 ms, so mfma_util_pct reads LOW there
+               "mfma_busy_frac_of_nominal_peak": round(b / (SIMDS * ns * NOMINAL_GHZ), 4) if ns > 0 else None,
                "avg_us_profiled": round(ns / max(nd, 1) / 1e3, 2), "avg_gui_cycles_per_xcd": round(gui / n),
-               "effective_clock_ghz": round(gui / ns, 3) if ns > 0 else None}
+               "gui_cycles_over_duration_ghz": round(gui / ns, 3) if ns > 0 else None}
         m = mops.get(k, {})
         if m:
             ops = 512.0 * (m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [0, 0])[0] + m.get("SQ_INSTS_VALU_MFMA_MOPS_F16", [0, 0])[0])
             nm = max(m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", [0, 1])[1], 1)
             row["mfma_gflop_per_launch_counted"] = round(ops / nm / 1e9, 3)
+            if nd:
+                row["counted_tflops"] = round(ops / nm / (ns / nd) / 1e3, 1)          # FLOP / ns / 1e3 = TFLOP/s
+                row["counted_frac_of_2500"] = round(ops / nm / (ns / nd) / 1e3 / 2500.0, 4)
             if "SQ_BUSY_CU_CYCLES" in m:
                 row["sq_busy_cu_quadcycles_per_launch"] = round(m["SQ_BUSY_CU_CYCLES"][0] / m["SQ_BUSY_CU_CYCLES"][1])
         if k in fetch or k in write:
@@ -107,10 +115,12 @@ def main():
         "label": a.label,
         "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 "
                   "--no-graph --no-cpu-baseline --no-roofline --no-optimizer-leg --no-eager-leg (+ separate passes for the "
-                  "MOPS / FETCH_SIZE / WRITE_SIZE columns); MfmaUtil = BUSY / (GUI_ACTIVE / 8 XCDs x 1024 SIMDs); durations are "
-                  "the profiled pass's own",
-        "classes": {k: {"mfma_util_pct": round(100.0 * v[0] / (v[1] * SIMDS), 2), "share_of_kernel_time_pct": None,
-                        "effective_clock_ghz": round(v[1] / v[2], 3) if v[2] > 0 else None} for k, v in cls.items()},
+                  "MOPS / FETCH_SIZE / WRITE_SIZE columns); MfmaUtil = BUSY / (GUI_ACTIVE / 8 XCDs x 1024 SIMDs); "
+                  "mfma_busy_frac_of_nominal_peak = BUSY / (1024 SIMDs x traced duration x 2.4 GHz); durations are the profiled "
+                  "pass's own",
+        "classes": {k: {"mfma_util_pct": round(100.0 * v[0] / (v[1] * SIMDS), 2),
+                        "mfma_busy_frac_of_nominal_peak": round(v[0] / (SIMDS * v[2] * NOMINAL_GHZ), 4) if v[2] > 0 else None,
+                        "share_of_kernel_time_pct": None} for k, v in cls.items()},
         "all_kernels_mfma_util_pct": round(100.0 * tot_busy / (tot_gui * SIMDS), 2) if tot_gui else None,
         "per_kernel": dict(sorted(rows.items(), key=lambda kv: -kv[1]["avg_us_profiled"] * kv[1]["launches"])),
     }
