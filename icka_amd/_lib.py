@@ -60,6 +60,7 @@ class XGemmDesc(C.Structure):
 PROTOTYPES = {
     "icka_abi_version": (c_i32, []),
     "icka_copy_many": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "icka_ln_set_rows_per_wave": (c_i32, [c_i32]),
     "icka_build_arch": (C.c_char_p, []),
     "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "icka_gemm_grouped": (c_i32, [C.POINTER(GemmDesc), c_i32, c_vp]),

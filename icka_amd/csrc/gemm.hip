@@ -55,6 +55,8 @@ struct GemmArgs {
     int w3_sn, w3_pnlog;   // 12-wave kernel: column tiles per XCD patch and log2(pn) of the pm x pn XCD cut (gemm_w3_grid)
     int c3_only;       // f32 C + C3 + beta == 0: write ONLY the bf16 wire copy C3 (the f32 value is produced later, from the
                        // reduced wire buffer, by icka_dp_cast_back_scaled): the epilogue stores 2 bytes per element, not 4 + 2
+    int plain;         // the MAIN 16-bit output is stored with ordinary stores instead of streaming ones (st_main): per launch,
+                       // from icka_gemm_desc.store_plain or the diagnostic site mask ICKA_GEMM_PLAIN_MASK (site_bit)
     // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
     // output pixel m and the reduction index is k = tap * cvC + c -- the loader waves compute the patch addresses, no
     // patch matrix exists.  cvZero: at least 128 B of zeros for the taps that fall off the image / rows past cvRows.
@@ -490,15 +492,28 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
     st_out(reinterpret_cast<u32x4*>(p), as_u32x4(o));
 }
+// MAIN activation output with a per-launch store policy (GemmArgs.plain, icka_gemm_desc.store_plain): plain = an ordinary
+// store, the line stays in the L2 / Infinity Cache for the consumer kernel; else the streaming store of st_out
+template <typename T>
+__device__ __forceinline__ void st_main(T* p, const T v, int plain) {
+    if (plain) *p = v;
+    else st_out(p, v);
+}
+__device__ __forceinline__ void store8_bf16_main(bf16_t* p, const float (&v)[8], int plain) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    st_main(reinterpret_cast<u32x4*>(p), as_u32x4(o), plain);
+}
 
 // fp16 outputs saturate at the largest finite half instead of overflowing to inf (an inf would turn the next LayerNorm
 // row into NaNs); real BERT activations stay orders of magnitude below it.
 __device__ __forceinline__ _Float16 f2h(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
-__device__ __forceinline__ void store8_f16(void* p, const float (&v)[8]) {
+__device__ __forceinline__ void store8_f16(void* p, const float (&v)[8], int plain = 0) {
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2h(v[e]);
-    st_out(reinterpret_cast<u32x4*>(p), __builtin_bit_cast(u32x4, o));
+    st_main(reinterpret_cast<u32x4*>(p), __builtin_bit_cast(u32x4, o), plain);
 }
 
 // Block -> output tile.  Blocks b and b+8 share an XCD (round-robin dispatch); each XCD has a private 4 MiB L2.
@@ -640,7 +655,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
                 }
             }
         } else if (g.c_f16) {   // fp16 main output (+ optional bf16 copy); beta is rejected on the host
-            store8_f16(reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n, v);
+            store8_f16(reinterpret_cast<_Float16*>(g.C) + (int64_t)m * g.ldc + n, v, g.plain);
             if (g.C3) store8_bf16(g.C3 + (int64_t)m * g.ldc3 + n, v);
         } else {
             bf16_t* p = reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
@@ -649,7 +664,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += g.beta * a[e];
             }
-            store8_bf16(p, v);
+            store8_bf16_main(p, v, g.plain);
         }
     }
 }
@@ -1152,8 +1167,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                         if constexpr (A_KM) {   // weight-gradient instances only: the data-parallel wire copy
                             if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
                         }
-                    } else st_out(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
-                                pack4(v[0], v[1], v[2], v[3]));
+                    } else st_main(reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n),
+                                pack4(v[0], v[1], v[2], v[3]), g.plain);
                 }
             }
         }
@@ -1571,6 +1586,37 @@ extern "C" int icka_gemm_set_ring(int nbuf) {
     return 0;
 }
 
+// Diagnostic site classes of the per-site store-policy matrix (profiles/r04_store_policy_matrix.txt): which producer of a
+// BERT layer a launch is, from its op / epilogue / shape ratio (N, K in units of H = min(N, K) work for bert-base and -large).
+//   bit 0 QKV (NT, N = 3H)            -> attention          bit 4 d(ffn-down) dgrad (NN, N = 4H, GELU' epilogue) -> d(ffn-up), wgrad
+//   bit 1 out-proj (NT, N = K)        -> LayerNorm          bit 5 d(ffn-up) dgrad   (NN, K = 4N)               -> LayerNorm bwd
+//   bit 2 ffn-up + GELU (NT, N = 4K)  -> ffn-down           bit 6 d(out-proj) dgrad (NN, N = K)                -> attention bwd
+//   bit 3 ffn-down (NT, K = 4N)       -> LayerNorm          bit 7 d(QKV) dgrad      (NN, K = 3N)               -> LayerNorm bwd
+static int site_bit(const icka_gemm_desc* d) {
+    const int64_t N = d->N, K = d->K;
+    if (d->c_is_f32 == 1 || d->M < 1024) return -1;
+    if (d->op == ICKA_GEMM_NT) {
+        if (N == 3 * K) return 0;
+        if (N == K) return 1;
+        if (N == 4 * K) return 2;
+        if (K == 4 * N) return 3;
+    } else if (d->op == ICKA_GEMM_NN) {
+        if (N == 4 * K) return 4;
+        if (K == 4 * N) return 5;
+        if (N == K) return 6;
+        if (K == 3 * N) return 7;
+    }
+    return -1;
+}
+static int plain_mask() {
+    static int m = -1;
+    if (m < 0) {
+        const char* e = getenv("ICKA_GEMM_PLAIN_MASK");
+        m = e ? (int)strtol(e, nullptr, 0) : 0;
+    }
+    return m;
+}
+
 static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     if (!d || !d->A || !d->B || !d->C) return ICKA_E_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return ICKA_E_SHAPE;
@@ -1596,6 +1642,10 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     // op would return 0 and leave the wire buffer stale
     if (g.C3 && g.c_f32 && d->op != ICKA_GEMM_TN) return ICKA_E_ARG;
     g.c3_only = d->c3_only != 0;
+    {
+        const int sb = site_bit(d);
+        g.plain = (sb >= 0 && ((plain_mask() >> sb) & 1)) ? 1 : 0;
+    }
     if (g.c3_only && !(g.C3 && g.c_f32 && d->beta == 0.f && d->epilogue == ICKA_EPI_NONE)) return ICKA_E_ARG;
     if (g.c_f16 && d->colsum_out) return ICKA_E_ARG;
     g.abl = g_abl;

@@ -64,6 +64,21 @@ __device__ __forceinline__ void store8t(void* base, int is_f16, int64_t off, con
     else store8f(reinterpret_cast<float*>(base) + off, v);
 }
 
+// One wave per row at a time; a wave that owns several rows (grid < M / 4: icka_ln_set_rows_per_wave) issues the loads of its
+// NEXT row before it reduces and stores the current one, so that a CU's read and write streams overlap instead of the whole
+// chip reading, then reducing, then writing in step.
+template <int NCH>
+__device__ __forceinline__ void ln_load_raw(const LnFwdArgs& a, int row, int lane, int nchunk, float (&x)[NCH][8], float (&r)[NCH][8]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            load8x(a.x, a.x_f32, (int64_t)row * a.ldx + c * 8, x[i]);
+            if (a.res) load8x(a.res, a.r_f32, (int64_t)row * a.ldr + c * 8, r[i]);
+        }
+    }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
     LnFwdArgs a = a_;
@@ -72,14 +87,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nchunk = a.H >> 3;
     const float inv_h = 1.f / (float)a.H;
+    float s[NCH][8], rr[NCH][8];
+    if (wid < a.M) ln_load_raw<NCH>(a, wid, lane, nchunk, s, rr);
     for (int row = wid; row < a.M; row += nw) {
-        float s[NCH][8];
+        float nx[NCH][8], nr[NCH][8];
+        const int nrow = row + nw;
+        if (nrow < a.M) ln_load_raw<NCH>(a, nrow, lane, nchunk, nx, nr);   // in flight while this row is reduced and stored
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                load8x(a.x, a.x_f32, (int64_t)row * a.ldx + c * 8, s[i]);
                 if (a.bias) {
                     float b[8];
                     load8f(a.bias + c * 8, b);
@@ -92,10 +110,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
                     for (int e = 0; e < 8; ++e) s[i][e] *= drop_mul(a.drop, base + e);
                 }
                 if (a.res) {
-                    float r[8];
-                    load8x(a.res, a.r_f32, (int64_t)row * a.ldr + c * 8, r);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] += r[e];
+                    for (int e = 0; e < 8; ++e) s[i][e] += rr[i][e];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += s[i][e];
@@ -129,6 +145,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
                 if (a.yf) store8t(a.yf, a.yf_f16, (int64_t)row * a.H + c * 8, o);
                 if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
             }
+        }
+        if (nrow < a.M) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[i][e] = nx[i][e]; rr[i][e] = nr[i][e]; }
         }
     }
 }
@@ -611,7 +633,13 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
 }
 
 inline int pick_nch(int H) { return (H / 8 + 63) / 64; }
+int g_ln_rows_per_wave = 1;   // icka_ln_set_rows_per_wave: rows a forward wave owns (> 1: its next row's loads overlap its stores)
 inline int row_grid(int M) { int g = (M + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+inline int fwd_grid(int M) {
+    const int r = g_ln_rows_per_wave < 1 ? 1 : g_ln_rows_per_wave;
+    int g = (M + 4 * r - 1) / (4 * r);
+    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
 inline int bwd_grid(int M) { int g = (M + 3) / 4; return g > BWD_BLOCKS ? BWD_BLOCKS : (g < 1 ? 1 : g); }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -641,8 +669,14 @@ static int ln_fwd_impl(int32_t twin_f16, const void* x, int64_t ldx, int32_t x_i
     LnFwdArgs a{x, ldx, x_is_f32, bias, residual, ldr, res_is_f32, gamma, beta, (bf16_t*)y, ldy,
                 (bf16_t*)y2, ldy2, y_twin, (bf16_t*)xhat, rstd, M, H, eps, make_drop(p_drop, seed), twin_f16};
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_NCH(pick_nch(H), ln_fwd_kernel, row_grid(M), 0, st, a);
+    DISPATCH_NCH(pick_nch(H), ln_fwd_kernel, fwd_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_ln_set_rows_per_wave(int32_t rows) {
+    if (rows < 1 || rows > 16) return ICKA_E_ARG;
+    g_ln_rows_per_wave = rows;
     return 0;
 }
 

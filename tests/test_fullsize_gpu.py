@@ -185,7 +185,8 @@ def _train_step_vs_oracle(tag, precision, graphed, logit_tol, grad_tol, B=32, S=
         gs = GraphedStep(model, step, warmup=1)     # logs the warm-up step's seeds, then the captured step's
         nsite = len(_site_kinds(cfgkw["num_hidden_layers"], 1))
         seeds = A.seed_log[-nsite:]
-        gs(); gs()                                  # two replays: the masks compared are those of the LAST one (nonce != 0)
+        gs(); model.zero_grad(); gs()               # two replays of the overwrite capture (the gradients are dropped in between,
+                                                    # as the reference loop does): the masks compared are those of the LAST one (nonce != 0)
         nonce = gs.nonce.cpu().tolist()
         assert nonce[0] != 0
     else:

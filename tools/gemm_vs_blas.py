@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Reference point: the c2 GEMM shapes on COLD operands (12 buffer sets > Infinity Cache), icka_gemm against torch.matmul
-(hipBLASLt / rocBLAS behind it), plain bf16 outputs, HIP-event timed back to back.  Not used by the product."""
+"""Reference point: the GEMM shapes of a BASELINE configuration on COLD operands (buffer sets > Infinity Cache), icka_gemm
+against torch.matmul (hipBLASLt / rocBLAS behind it), plain bf16 outputs (f32 for the weight gradients), HIP-event timed back
+to back.  Not used by the product.   usage: python tools/gemm_vs_blas.py [c2|c4|c5]   (c4: bert-large, M = 32 x 256 = 8192;
+c5: bert-base at batch 64, M = 8192)"""
 import os
 import sys
 
@@ -26,11 +28,17 @@ def timed(fn, sets, reps=6):
     return e0.elapsed_time(e1) * 1e3 / (reps * len(sets))
 
 
-for name, op, M, N, Kd in (("qkv NT", "NT", 4096, 2304, 768), ("outproj NT", "NT", 4096, 768, 768), ("ffnup NT", "NT", 4096, 3072, 768),
-                           ("ffndn NT", "NT", 4096, 768, 3072), ("dffndn NN", "NN", 4096, 3072, 768), ("dffnup NN", "NN", 4096, 768, 3072),
-                           ("dqkv NN", "NN", 4096, 768, 2304), ("W1 TN", "TN", 3072, 768, 4096), ("Wqkv TN", "TN", 2304, 768, 4096)):
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+M, H = {"c2": (4096, 768), "c4": (8192, 1024), "c5": (8192, 768)}[cfg]
+I = 4 * H
+NSETS = 12 if M * I * 2 * 12 < (3 << 30) else 8
+print("# %s: M = %d tokens, H = %d, I = %d; %d rotating buffer sets per shape" % (cfg, M, H, I, NSETS))
+for name, op, M, N, Kd in (("qkv NT", "NT", M, 3 * H, H), ("outproj NT", "NT", M, H, H), ("ffnup NT", "NT", M, I, H),
+                           ("ffndn NT", "NT", M, H, I), ("dffndn NN", "NN", M, I, H), ("dffnup NN", "NN", M, H, I),
+                           ("doutproj NN", "NN", M, H, H), ("dqkv NN", "NN", M, H, 3 * H), ("W1 TN", "TN", I, H, M),
+                           ("W2 TN", "TN", H, I, M), ("Wqkv TN", "TN", 3 * H, H, M), ("Wo TN", "TN", H, H, M)):
     sets = []
-    for _ in range(12):
+    for _ in range(NSETS):
         if op == "NT":
             A, B = torch.randn(M, Kd, device="cuda").to(BF16), torch.randn(N, Kd, device="cuda").to(BF16)
         elif op == "NN":

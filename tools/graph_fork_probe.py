@@ -61,10 +61,12 @@ step()
 model._icka_arena.reducer = hook if nfork else None
 gs = GraphedStep(model, step)
 for _ in range(10):
+    model.zero_grad()
     gs()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(100):
+    model.zero_grad()
     gs()
 torch.cuda.synchronize()
 print("%s forks=%d: %.3f ms/step" % (mode, nfork, 10 * (time.perf_counter() - t0)), flush=True)

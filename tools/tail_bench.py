@@ -75,7 +75,11 @@ def main():
             return step()
         mode = "eager"
     else:
-        run = GraphedStep(model, step)
+        gs = GraphedStep(model, step)
+
+        def run():
+            model.zero_grad()      # the reference loop drops the gradients after every step: the overwrite capture replays
+            return gs()
         mode = "hipgraph"
     ms = timed(run, args.steps, args.warmup)
     loss = float(run().item())
