@@ -5,6 +5,7 @@
 // rows a wave visits, combined per block through LDS and written as per-block partial slabs that a tiny finalize
 // kernel sums: no global float atomics on hot addresses, bitwise reproducible.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -636,7 +637,8 @@ inline int pick_nch(int H) { return (H / 8 + 63) / 64; }
 int g_ln_rows_per_wave = 1;   // icka_ln_set_rows_per_wave: rows a forward wave owns (> 1: its next row's loads overlap its stores)
 inline int row_grid(int M) { int g = (M + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
 inline int fwd_grid(int M) {
-    const int r = g_ln_rows_per_wave < 1 ? 1 : g_ln_rows_per_wave;
+    static const int env_rows = [] { const char* e = getenv("ICKA_LN_ROWS"); return e ? atoi(e) : 0; }();   // diagnostic A/B
+    const int r = env_rows >= 1 && env_rows <= 16 ? env_rows : (g_ln_rows_per_wave < 1 ? 1 : g_ln_rows_per_wave);
     int g = (M + 4 * r - 1) / (4 * r);
     return g > 2048 ? 2048 : (g < 1 ? 1 : g);
 }
