@@ -20,9 +20,18 @@ from .arena import ParamArena
 
 BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
 import os as _os
-# 1 = the attention forward leaves its dropout keep bits for the backward (off: same-box the c2 step is 0.4 % slower with
-# them -- the forward pays for packing and storing the bits, the backward's hashes were hidden behind its MFMA / LDS waits)
-ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "0") == "1"
+# The attention forward may leave its dropout keep bits for the backward.  At 128 x 128 the c2 step is 0.4 % slower with them
+# (the forward pays for packing and storing the bits, the backward's hashes were hidden behind its MFMA / LDS waits:
+# profiles/r03_attn_keepbits_ab.txt); at the 256 x 256 whole-head instance of bert-large the hashes are NOT hidden: backward
+# 98.1 -> 87.2 us, forward 43.5 -> 45.4 us, c4 step 23.26 -> 23.17 ms (profiles/r04_attn_keepbits_256.txt).
+# "auto" (default): on for self-attention sites with more than 128 keys; "1" / "0": always / never.
+ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "auto")
+
+
+def _keepbits_on(Sq: int, Skv: int) -> bool:
+    if ATTN_KEEPBITS == "auto":
+        return Sq > 128 and Skv > 128 and Sq <= 256 and Skv <= 256
+    return ATTN_KEEPBITS == "1"
 
 
 def _empty(ref: torch.Tensor, *shape, dtype=BF16) -> torch.Tensor:
@@ -141,7 +150,7 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
     # optional (ATTN_KEEPBITS): the forward leaves the keep decisions of its probability dropout as bits and the backward reads
     # them instead of hashing every (query, key) element a second time
-    kb = K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if (save and d.p_attn > 0 and ATTN_KEEPBITS) else None
+    kb = K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if (save and d.p_attn > 0 and _keepbits_on(d.S, Skv)) else None
     K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8, out16=ctx16,
                keepbits=kb)
     return ctx, ctx16, ((qkv, kvbuf, lse, seed_a, kb) if save else None)

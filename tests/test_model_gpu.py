@@ -175,7 +175,7 @@ def test_attention_keep_bits_option_gives_the_same_step(monkeypatch):
     model = _build(case["cfg"]).train()
     _run(model, case["batch"]).backward()                  # builds the arena
     outs = []
-    for keep in (False, True):
+    for keep in ("0", "1"):
         monkeypatch.setattr(ops, "ATTN_KEEPBITS", keep)
         model._icka_arena.set_seed(4321)
         model.zero_grad()
