@@ -186,6 +186,26 @@ __device__ __forceinline__ void flush_columns(float (&acc)[NS][NCH][8], float* l
 // Row part of the backward: dres / dx only (pure streaming, one row per wave).  The column reductions (dgamma, dbeta,
 // dbias) are a separate pass (ln_cols_kernel): fusing them here forced either few waves (latency-bound rows) or a
 // per-block flush of 3*H partial sums that cost more than the rows themselves (measured 28 -> 56 us at 1024 blocks).
+// raw (packed bf16) operands of one backward row: issued one row ahead of their use when a wave owns several rows
+template <int NCH>
+__device__ __forceinline__ void ln_bwd_load_raw(const LnBwdArgs& a, int row, int lane, int nchunk, u32x4 (&dy)[NCH], u32x4 (&dy2)[NCH],
+                                                u32x4 (&xh)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            dy[i] = *reinterpret_cast<const u32x4*>(a.dy + (int64_t)row * a.lddy + c * 8);
+            if (a.dy2) dy2[i] = *reinterpret_cast<const u32x4*>(a.dy2 + (int64_t)row * a.lddy2 + c * 8);
+            xh[i] = *reinterpret_cast<const u32x4*>(a.xhat + (int64_t)row * a.H + c * 8);
+        }
+    }
+}
+__device__ __forceinline__ void unpack8(const u32x4 raw, float (&o)[8]) {
+    const bf16x8 v = as_bf16x8(raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
+}
+
 template <int NCH>
 __device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int nblk) {
     LnBwdArgs a = a_;
@@ -194,10 +214,12 @@ __device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int n
     const int wid = blk * 4 + (threadIdx.x >> 6), nw = nblk * 4;
     const int nchunk = a.H >> 3;
     const float inv_h = 1.f / (float)a.H;
+    u32x4 rdy[NCH], rdy2[NCH], rxh[NCH];
+    if (wid < a.M) ln_bwd_load_raw<NCH>(a, wid, lane, nchunk, rdy, rdy2, rxh);
     for (int row = wid; row < a.M; row += nw) {
         float xh[NCH][8], gd[NCH][8];
         float s1 = 0.f, s2 = 0.f;
-        // the keep decisions of the row's dropout mask FIRST (one bit each), while the loads below are in flight: left next to
+        // the keep decisions of the row's dropout mask FIRST (one bit each), while the loads are in flight: left next to
         // their use after the row reductions, the 8 hashes per chunk sat on the critical path of a latency-bound kernel
         // (+1.1 us per launch at 4096 x 768, tools/ln_bench.py)
         uint32_t kb[NCH];
@@ -220,14 +242,14 @@ __device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int n
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float dy[8];
-                load8(a.dy + (int64_t)row * a.lddy + c * 8, dy);
+                unpack8(rdy[i], dy);
                 if (a.dy2) {
                     float t[8];
-                    load8(a.dy2 + (int64_t)row * a.lddy2 + c * 8, t);
+                    unpack8(rdy2[i], t);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) dy[e] += t[e];
                 }
-                load8(a.xhat + (int64_t)row * a.H + c * 8, xh[i]);
+                unpack8(rxh[i], xh[i]);
                 float g[8];
                 load8f(a.gamma + c * 8, g);
 #pragma unroll
@@ -238,6 +260,9 @@ __device__ __forceinline__ void ln_rows_body(const LnBwdArgs& a_, int blk, int n
                 }
             }
         }
+        // a wave that owns another row issues its loads now: they are in flight under the reductions and stores below
+        const int nrow = row + nw;
+        if (nrow < a.M) ln_bwd_load_raw<NCH>(a, nrow, lane, nchunk, rdy, rdy2, rxh);
         const float c1 = wave_sum(s1) * inv_h, c2 = wave_sum(s2) * inv_h;
         const float rstd = a.rstd[row];
 #pragma unroll
@@ -634,15 +659,31 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
 }
 
 inline int pick_nch(int H) { return (H / 8 + 63) / 64; }
-int g_ln_rows_per_wave = 1;   // icka_ln_set_rows_per_wave: rows a forward wave owns (> 1: its next row's loads overlap its stores)
+// icka_ln_set_rows_per_wave: rows a forward wave owns (> 1: its next row's loads overlap its stores); 0 = automatic: two
+// rows per wave from 4096 rows on (c2: 4.534 -> 4.489 ms per step, same box, twice: profiles/r04_ln_rows_per_wave.txt; three
+// and more rows per wave are slower again, and the backward rows do not gain)
+int g_ln_rows_per_wave = 0;
 inline int row_grid(int M) { int g = (M + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
 inline int fwd_grid(int M) {
     static const int env_rows = [] { const char* e = getenv("ICKA_LN_ROWS"); return e ? atoi(e) : 0; }();   // diagnostic A/B
-    const int r = env_rows >= 1 && env_rows <= 16 ? env_rows : (g_ln_rows_per_wave < 1 ? 1 : g_ln_rows_per_wave);
+    const int r = env_rows >= 1 && env_rows <= 16 ? env_rows : (g_ln_rows_per_wave < 1 ? (M >= 4096 ? 2 : 1) : g_ln_rows_per_wave);
     int g = (M + 4 * r - 1) / (4 * r);
     return g > 2048 ? 2048 : (g < 1 ? 1 : g);
 }
 inline int bwd_grid(int M) { int g = (M + 3) / 4; return g > BWD_BLOCKS ? BWD_BLOCKS : (g < 1 ? 1 : g); }
+inline int rows_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 16 ? v : dflt;
+}
+// row blocks of the fused backward launch: rows-per-wave knob ICKA_LN_BWD_ROWS (diagnostic A/B; default g_ln_bwd_rows)
+int g_ln_bwd_rows = 1;
+inline int bwd_row_grid(int M) {
+    static const int env_rows = rows_knob("ICKA_LN_BWD_ROWS", 0);
+    const int r = env_rows ? env_rows : g_ln_bwd_rows;
+    int g = (M + 4 * r - 1) / (4 * r);
+    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #define DISPATCH_NCH(nch, KERNEL, grid, shmem, st, args)                                                 \
@@ -677,7 +718,7 @@ static int ln_fwd_impl(int32_t twin_f16, const void* x, int64_t ldx, int32_t x_i
 }
 
 extern "C" int icka_ln_set_rows_per_wave(int32_t rows) {
-    if (rows < 1 || rows > 16) return ICKA_E_ARG;
+    if (rows < 0 || rows > 16) return ICKA_E_ARG;
     g_ln_rows_per_wave = rows;
     return 0;
 }
@@ -716,7 +757,7 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
     const int nx = (H + 255) / 256;
     if ((dgamma || dbeta) && !dbias) {
         const LnColsArgs c{nx, groups, rpg};
-        const int grid = nx * groups + row_grid(M);
+        const int grid = nx * groups + bwd_row_grid(M);
         switch (pick_nch(H)) {
             case 1: hipLaunchKernelGGL((ln_bwd_fused_kernel<1>), dim3(grid), dim3(256), 0, st, a, c); break;
             case 2: hipLaunchKernelGGL((ln_bwd_fused_kernel<2>), dim3(grid), dim3(256), 0, st, a, c); break;
@@ -729,7 +770,7 @@ extern "C" int icka_ln_bwd(const void* dy, int64_t lddy, const void* dy2, int64_
         ICKA_CHECK_LAUNCH();
         return 0;
     }
-    DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, row_grid(M), 0, st, a);
+    DISPATCH_NCH(pick_nch(H), ln_bwd_kernel, bwd_row_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
     if (dgamma || dbeta || dbias) {
         hipLaunchKernelGGL(ln_cols_kernel, dim3((H + 255) / 256, groups), dim3(256), 0, st, (const bf16_t*)dy, lddy,
@@ -765,7 +806,7 @@ extern "C" int icka_ln_bwd_slabs(const void* dy, int64_t lddy, const void* dy2, 
     const int groups = icka_ln_bwd_nslab(M);
     const int nx = (H + 255) / 256;
     const LnColsArgs c{nx, groups, (M + groups - 1) / groups};
-    const int grid = nx * groups + row_grid(M);
+    const int grid = nx * groups + bwd_row_grid(M);
     hipStream_t st = (hipStream_t)stream;
     switch (pick_nch(H)) {
         case 1: hipLaunchKernelGGL((ln_bwd_fused_kernel<1>), dim3(grid), dim3(256), 0, st, a, c); break;

@@ -146,8 +146,8 @@ int icka_gemm_set_stamp_buffer(void* p);
  *   optional second bf16 copy (ldy2); y_f32 optional contiguous f32 copy (the residual stream is carried in f32
  *   so bf16 rounding does not accumulate over layers); xhat [M,H] bf16 contiguous and rstd f32[M] are the saved
  *   statistics for backward (may be NULL in inference).
- * icka_ln_set_rows_per_wave(rows): rows a forward wave owns (1 .. 16; process-global tuning knob).  With more than one, the
- *   loads of a wave's next row are issued before the current row is reduced and stored.
+ * icka_ln_set_rows_per_wave(rows): rows a forward wave owns (1 .. 16, 0 = automatic: two from 4096 rows on; process-global
+ *   tuning knob).  With more than one, the loads of a wave's next row are issued before the current row is reduced and stored.
  */
 int icka_ln_set_rows_per_wave(int32_t rows);
 int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual, int64_t ldr,

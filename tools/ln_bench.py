@@ -57,7 +57,7 @@ def timed(fn, p, reps=30):
 for rows in (1, 2, 4, 8, 1):      # rows a forward wave owns (icka_ln_set_rows_per_wave): > 1 overlaps next-row loads with stores
     lib.icka_ln_set_rows_per_wave(rows)
     print("ln_fwd, %d row(s) per wave: p = 0 %6.2f us | p = 0.1 %6.2f us" % (rows, timed(fwd, 0.0), timed(fwd, 0.1)), flush=True)
-lib.icka_ln_set_rows_per_wave(1)
+lib.icka_ln_set_rows_per_wave(0)
 for name, fn in (("ln_fwd", fwd), ("ln_bwd (rows + column slabs)", bwd)):
     for rnd in range(2):
         a, b = timed(fn, 0.0), timed(fn, 0.1)
