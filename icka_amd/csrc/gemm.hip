@@ -549,8 +549,11 @@ __device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, i
 // WIRE: the instance may be asked for the data-parallel wire copy of an f32 output (C3 / c3_only): weight-gradient (TN)
 // instances only -- compiled out everywhere else (as a run-time test in every instance it cost the 12-wave kernels, which run
 // at their register cap, 5 % and showed up in kernels that never see a wire copy)
-template <int RSTEP, int NC8 = 16, int WIDE = 0, bool WIRE = false>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
+// ROWS: rows of the staged tile (128; 64 for the passes of gemm_sq_kernel).  PREB: the bias of the thread's 8 columns was loaded
+// by the caller (``pre``) -- gemm_sq_kernel keeps the epilogue free of loads while the next tile's LDS-DMA is in flight.
+template <int RSTEP, int NC8 = 16, int WIDE = 0, bool WIRE = false, int ROWS = 128, bool PREB = false>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid,
+                                              const float* pre = nullptr) {
     // NC8 = 8-column groups per tile row: 16 (128-wide tile), 12 (96-wide: 384 of 512 threads) or 24 (192-wide, 768 threads)
     if (tid >= RSTEP * NC8) return;
     const int c8 = NC8 == 16 ? (tid & 15) : tid % NC8;   // 8-column group of the row
@@ -558,13 +561,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
     const int n = n0 + 8 * c8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-    if (g.bias) {
+    for (int e = 0; e < 8; ++e) bias[e] = PREB ? pre[e] : 0.f;
+    if (!PREB && g.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
     }
-    if (g.bias2) {
+    if (!PREB && g.bias2) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias2 + n), b1 = *reinterpret_cast<const f32x4*>(g.bias2 + n + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
@@ -573,7 +576,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
     // the first staged row is read: inside the row loop (behind the switch on the epilogue kind) every row's load waited for
     // the previous row's store to issue -- 128 / RSTEP global-load latencies in series per thread, twice that in the two
     // passes of the 12-wave kernel.
-    constexpr int NROW = 128 / RSTEP;
+    constexpr int NROW = ROWS / RSTEP;
     const bool use_aux = g.epi == ICKA_EPI_DGELU || g.epi == ICKA_EPI_ADD || g.epi == ICKA_EPI_GATE || g.epi == ICKA_EPI_ADD_RELU;
     u32x4 araw[NROW];
 #pragma unroll
@@ -584,9 +587,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
         if (use_aux) araw[i] = ld_once(reinterpret_cast<const u32x4*>(g.aux + (int64_t)m * g.ldaux + n));
     }
     // (the 12-wave kernel runs at a 168-register cap with accumulators of the other pass alive: keep its row loop rolled)
-    constexpr int UNR = WIDE ? 1 : 128 / RSTEP;
+    constexpr int UNR = WIDE ? 1 : ROWS / RSTEP;
 #pragma unroll UNR
-    for (int i = 0; i < 128 / RSTEP; ++i) {
+    for (int i = 0; i < ROWS / RSTEP; ++i) {
         const int row = rb + RSTEP * i;
         // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
         const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
@@ -1254,6 +1257,8 @@ int g_abl = 0;
 unsigned long long* g_stamp = nullptr;
 int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
 int g_direct = 1;  // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
+int g_sq = 0;    // 256x256 tiles of the 8-wave load+compute kernel: OFF by default (icka_gemm_set_square_tiles; 96 vs 99 us
+                 // at 8192 x 4096 x 1024 cold, ahead only from K = 2048 on, where no shape of the path qualifies)
 int g_w3 = 1;    // 256x192 tiles for wide / short-K outputs (icka_gemm_set_wide_tiles)
 int g_bn = 0;    // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced (icka_gemm_set_tile_n)
 int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
@@ -1397,6 +1402,198 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
+// =====================================================================================================================
+// 256 x 256 output tiles, 8 waves that ALL load and compute (2 x 4 wave tiles of 128 x 64, two waves per SIMD, 256 registers
+// each), for large outputs with N % 256 == 0 whose tile grid fills whole rounds of the CUs: bert-large's ffn-up and
+// d(ffn-down) (8192 x 4096 x 1024: 512 tiles = two rounds), where the 128 x 128 two-blocks-per-CU kernel measured 758 TFLOP/s
+// against 1211 for the vendor library (profiles/r04_gemm_vs_hipblaslt.txt).  Per FLOP the tile moves half the operand bytes
+// of a 128 x 128 one through L2 -> LDS and through the LDS read port (a wave tile of 128 x 64 reads 24 KiB of fragments per
+// 64-deep k-tile for 64 MFMAs).  LDS: ring of TWO stages of [A rows 0..127 | A rows 128..255 | B 0..127 | B 128..255]
+// (4 x 16 KiB images each, the usual swizzled layouts) = 128 KiB; waves 0-3 stage the first A and B images of a k-tile, waves
+// 4-7 the second ones (8 LDS-DMA instructions per wave and k-tile).  ONE barrier per k-tile, in the middle of it: by then the
+// wave holds all fragments of stage kt & 1 in registers and has waited for its pieces of tile kt + 1, so the barrier both
+// publishes tile kt + 1 and frees the stage for tile kt + 2, whose DMA is issued right behind it and lands under the MFMAs
+// of tile kt + 1; fragment reads always run under the MFMAs of the other register set (as gemm_big_tn_body).  Epilogue: four passes of a
+// 128 x 128 f32 tile through the (dead) ring, finished by all 512 threads in 16-byte row-contiguous accesses (epilogue_rows).
+constexpr int SQ_STAGE = 4 * TILE_BYTES;
+constexpr int SQ_CTILE = 64 * 128 * 4;     // epilogue staging: 64 rows x 128 columns of f32 behind the ring
+// tile t of nb (w3_origin with an explicit tile count: the kernel is persistent, gridDim.x is the number of CUs it runs on)
+__device__ __forceinline__ void sq_origin(int t, int nb, int sn, int pnlog, int& m0, int& n0) {
+    const int xcd = t & 7, li = t >> 3;
+    const int xi = xcd >> pnlog, xj = xcd & ((1 << pnlog) - 1);
+    const int r = li / sn, c = li - r * sn;
+    m0 = (xi * ((nb >> 3) / sn) + r) * 256;
+    n0 = (xj * sn + c) * 256;
+}
+template <bool B_KM, bool F16 = false>
+__global__ __launch_bounds__(512) void gemm_sq_kernel(const GemmArgs gp, const int ntiles) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[2 * SQ_STAGE + SQ_CTILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    const int nk = g.K / BK;
+    // ---- this wave's share of the staging: image pair (A half hf, B half hf), pieces lw, lw + 4, lw + 8, lw + 12 of each
+    const int lw = wave & 3, hf = wave >> 2;
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    const int64_t sa = BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+#define ICKA_SQ_STAGE(BUF)                                                                  \
+    do {                                                                                    \
+        dma_issue(pa, sa, lds0 + (BUF) * SQ_STAGE + hf * TILE_BYTES + lw * 1024);           \
+        dma_issue(pb, sb, lds0 + (BUF) * SQ_STAGE + (2 + hf) * TILE_BYTES + lw * 1024);     \
+    } while (0)
+    // ---- this wave's output: rows 128 * wsub .., columns 64 * wq ..
+    const int wsub = wave >> 2, wq = wave & 3;
+    const int bimg = 2 + (wq >> 1), wc = (wq & 1) * 64;
+    const bool use_aux = g.epi == ICKA_EPI_DGELU || g.epi == ICKA_EPI_ADD || g.epi == ICKA_EPI_GATE || g.epi == ICKA_EPI_ADD_RELU;
+    char* const ctile = smem + 2 * SQ_STAGE;
+    int t = blockIdx.x;
+    int m0, n0;
+    sq_origin(t, ntiles, g.w3_sn, g.w3_pnlog, m0, n0);
+    dma_init<false>(pa, g.A, g.lda, m0 + 128 * hf, lw, lane);
+    dma_init<B_KM>(pb, g.B, g.ldb, n0 + 128 * hf, lw, lane);
+    ICKA_SQ_STAGE(0);
+    if (nk > 1) ICKA_SQ_STAGE(1);
+#define ICKA_SQ_READ(FA, FB, BUFI, KS)                                                                      \
+    do {                                                                                                    \
+        const char* b_ = smem + (BUFI) * SQ_STAGE;                                                          \
+        int l_ = lane;                                                                                      \
+        asm volatile("" : "+v"(l_)); /* opaque: LDS addresses recomputed per read, not held across the loop */ \
+        _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) FA[t_] = read_frag<false>(b_ + wsub * TILE_BYTES, 16 * t_, KS, l_); \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) FB[t_] = read_frag<B_KM>(b_ + bimg * TILE_BYTES, wc + 16 * t_, KS, l_); \
+    } while (0)
+#define ICKA_SQ_MMA(FA, FB)                                                                                 \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                    \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16t<F16>(FB[ni], FA[mi], acc[mi][ni]); \
+    } while (0)
+#define ICKA_SQ_INTERLEAVE()                                                                                \
+    do { /* fragment reads into the idle register set spread between the 32 MFMAs of the other set */       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+        // (from the second tile on, the stores of the previous epilogue are still counted in vmcnt: these waits then also
+        //  cover the tail of that store burst, which has had the whole epilogue to drain)
+        if (nk > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();   // my pieces of tile 0 landed (tile 1: 8 in flight)
+        __builtin_amdgcn_s_barrier();                          // ... and everyone else's
+        asm volatile("" ::: "memory");
+        ICKA_SQ_READ(fa0, fb0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int buf = kt & 1;
+            ICKA_SQ_READ(fa1, fb1, buf, 1);
+            ICKA_SQ_MMA(fa0, fb0);
+            ICKA_SQ_INTERLEAVE();
+            // stage `buf` is completely in registers; my pieces of tile kt + 1 (the only DMA in flight) must have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();      // tile kt + 1 published AND every wave is done with stage `buf`
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) ICKA_SQ_STAGE(buf);   // tile kt + 2: lands under the MFMAs of tile kt + 1
+            ICKA_SQ_READ(fa0, fb0, buf ^ 1, 0);
+            ICKA_SQ_MMA(fa1, fb1);
+            ICKA_SQ_INTERLEAVE();
+        }
+        ICKA_SQ_READ(fa1, fb1, (nk - 1) & 1, 1);   // last k-tile
+        ICKA_SQ_MMA(fa0, fb0);
+        ICKA_SQ_INTERLEAVE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ICKA_SQ_MMA(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
+        // ---- the bias of this thread's epilogue columns (both column halves), loaded BEFORE the next tile's DMA is issued:
+        //      nothing in the epilogue passes waits on vmcnt any more (aux-operand epilogues excepted, see below)
+        float bq[2][8];
+        {
+            const int c8 = tid & 15;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int n = n0 + 128 * pc + 8 * c8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bq[pc][e] = 0.f;
+                if (g.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bq[pc][e] = b0[e]; bq[pc][4 + e] = b1[e]; }
+                }
+                if (g.bias2) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias2 + n), b1 = *reinterpret_cast<const f32x4*>(g.bias2 + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bq[pc][e] += b0[e]; bq[pc][4 + e] += b1[e]; }
+                }
+            }
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bq[pc][e]));   // (materialise: the loads complete here)
+        }
+        // ---- next tile of this block: its first two k-tiles go into the ring while the epilogue runs out of the staging
+        //      tile behind it.  (With an aux-operand epilogue the DMA is issued after the passes instead: their aux loads
+        //      return in order behind anything issued earlier.)
+        const int m0c = m0, n0c = n0;
+        const int tn = t + (int)gridDim.x;
+        __builtin_amdgcn_s_barrier();          // every wave has read the last stage
+        if (tn < ntiles) {
+            sq_origin(tn, ntiles, g.w3_sn, g.w3_pnlog, m0, n0);
+            dma_init<false>(pa, g.A, g.lda, m0 + 128 * hf, lw, lane);
+            dma_init<B_KM>(pb, g.B, g.ldb, n0 + 128 * hf, lw, lane);
+            if (!use_aux) {
+                ICKA_SQ_STAGE(0);
+                if (nk > 1) ICKA_SQ_STAGE(1);
+            }
+        }
+        // ---- epilogue: 8 passes of 64 x 128; pass (ph, pc, r2) = rows 64 r2 .. of the quadrant held by the two waves with
+        //      wsub == ph and wq >> 1 == pc
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int ph = pass >> 2, pc = (pass >> 1) & 1, r2 = pass & 1;
+            if (pass) {   // previous staging tile consumed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (wsub == ph && (wq >> 1) == pc) {
+#pragma unroll
+                for (int mj = 0; mj < 4; ++mj) {
+                    const int row = 16 * mj + (lane & 15);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
+                        *reinterpret_cast<f32x4*>(ctile + off_c(row, ch)) = acc[4 * r2 + mj][ni] * g.alpha;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            epilogue_rows<32, 16, 0, false, 64, true>(g, ctile, m0c + 128 * ph + 64 * r2, n0c + 128 * pc, tid, bq[pc]);
+        }
+        if (tn >= ntiles) break;
+        if (use_aux) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ICKA_SQ_STAGE(0);
+            if (nk > 1) ICKA_SQ_STAGE(1);
+        }
+        t = tn;
+    }
+#undef ICKA_SQ_INTERLEAVE
+#undef ICKA_SQ_STAGE
+#undef ICKA_SQ_READ
+#undef ICKA_SQ_MMA
+}
+
 int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
 static int gemm_w3_grid(int M, int N, int bnw) {
@@ -1419,6 +1616,17 @@ static int gemm_w3_grid(int M, int N, int bnw) {
         }
     }
     return best;
+}
+
+// CUs of this device rounded down to a multiple of 8 (the persistent 256x256 kernel keeps the b -> XCD map of sq_origin)
+static int sq_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) n = v & ~7;
+        else { n = 256; (void)hipGetLastError(); }
+    }
+    return n;
 }
 
 template <bool A_KM, bool B_KM, bool F16 = false>
@@ -1453,6 +1661,26 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
 #endif
                 // 256x192 tiles (12-wave kernel) where they cover the CUs in ONE round: wide outputs with a short reduction
+                if constexpr (!A_KM) {
+                    // 256x256 tiles (8-wave load+compute kernel) for large outputs in whole rounds of the CUs: N % 256 == 0,
+                    // at least two full rounds' worth of work and at least 7/8 of the last round filled
+                    const int nbq = (g.M / 256) * (g.N / 256);
+                    const int roundsq = (nbq + 255) / 256;
+                    if (g_sq && g.M % 256 == 0 && g.N % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nbq % 8 == 0 && !g.colsum &&
+                        (g_sq == 2 || (nbq >= 448 && 8 * nbq >= 7 * 256 * roundsq))) {   // (2: forced, tests)
+                        { const int pm = gemm_w3_grid(g.M, g.N, 256), pn = 8 / pm;
+                          g.w3_sn = (g.N / 256) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
+                        // one block per tile; ICKA_GEMM_SQ_PERSIST=1 (diagnostic): one block per CU (LDS: the whole 160 KiB),
+                        // block b takes tiles b, b + grid, ... with the next tile's first k-tiles issued under the epilogue --
+                        // measured SLOWER (125.8 vs 96.0 us at 8192 x 4096 x 1024): the epilogue's stores are counted by the
+                        // same vmcnt the next tile's DMA waits use (profiles/NEGATIVE_RESULTS.md)
+                        static const int persist = [] { const char* e = getenv("ICKA_GEMM_SQ_PERSIST"); return e && e[0] == '1'; }();
+                        const int gridq = (persist && nbq > sq_cus()) ? sq_cus() : nbq;
+                        hipLaunchKernelGGL((gemm_sq_kernel<B_KM, F16>), dim3(gridq), dim3(512), 0, st, g, nbq);
+                        ICKA_CHECK_LAUNCH();
+                        return 0;
+                    }
+                }
                 if constexpr (!A_KM) {
                     const int nb3 = (g.M / 256) * (g.N / 192);
                     // ... or in whole rounds: at least 3/4 of the last round of 256 must be filled
@@ -1569,6 +1797,10 @@ extern "C" int icka_gemm_set_direct_epilogue(int on) {
     return 0;
 }
 
+extern "C" int icka_gemm_set_square_tiles(int on) {
+    g_sq = on < 0 || on > 2 ? 0 : on;   // 0 off (default), 1 by shape, 2 wherever the tile divides the output (tests)
+    return 0;
+}
 extern "C" int icka_gemm_set_wide_tiles(int on) {
     g_w3 = on ? 1 : 0;
     return 0;

@@ -220,6 +220,54 @@ def test_gemm_wide_tiles(M, N, K, op, wide, request):
     assert rel_err(ov, 0.5 * ref) < 1e-2
 
 
+@pytest.mark.parametrize("op", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K,forced", [(8192, 4096, 1024, 1), (2048, 1024, 64, 2), (2048, 2048, 192, 2), (4096, 1024, 3072, 2),
+                                          (2048, 512, 128, 2)])
+def test_gemm_square_tiles(M, N, K, forced, op, request):
+    """256x256-tile kernel (8 waves, all loading and computing; off by default -- profiles/NEGATIVE_RESULTS.md; bert-large's ffn-up /
+    d(ffn-down) shape 8192 x 4096 x 1024 takes it by shape when enabled, the small cases force it) against fp32 matmul with every epilogue those GEMMs use, one / two / three / many k-tiles
+    (the two-stage ring's prologue, steady state and drain), fp16 operands, strided outputs; and bitwise against the 128x128
+    path's result for the plain bf16 output (same MFMA k-order per output element)."""
+    k = _k()
+    lib = k._lib.load()
+    assert lib.icka_gemm_set_square_tiles(forced) == 0
+    request.addfinalizer(lambda: lib.icka_gemm_set_square_tiles(0))
+    A = rnd(M, K, seed=21, scale=0.5)
+    B = rnd(N, K, seed=22, scale=0.5) if op == "NT" else rnd(K, N, seed=22, scale=0.5)
+    kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
+    bias = rnd(N, seed=23, dtype=F32)
+    ref = A.float() @ (B.float().t() if op == "NT" else B.float())
+    o = torch.full((M, N), float("nan"), dtype=BF16, device="cuda")
+    k.gemm(kop, A, B, o)
+    assert torch.isfinite(o.float()).all()                   # no tile left out
+    assert rel_err(o, ref) < 1e-2
+    lib.icka_gemm_set_square_tiles(0)
+    o128 = torch.empty_like(o)
+    k.gemm(kop, A, B, o128)
+    lib.icka_gemm_set_square_tiles(forced)
+    assert torch.equal(o, o128)
+    of = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(kop, A, B, of, bias=bias)
+    assert rel_err(of, ref + bias) < 1e-4
+    z = torch.empty_like(o)
+    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    assert rel_err(z, ref + bias) < 1e-2 and rel_err(o, torch.nn.functional.gelu(ref + bias)) < 1e-2
+    aux = rnd(M, N, seed=24)
+    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(o, ref * x.grad) < 1e-2
+    k.gemm(kop, A, B, o, epilogue=k.EPI_ADD, aux=aux)
+    assert rel_err(o, ref + aux.float()) < 1e-2
+    ov = torch.empty(M, N + 64, dtype=BF16, device="cuda")[:, :N]      # strided output view
+    k.gemm(kop, A, B, ov, alpha=0.5)
+    assert rel_err(ov, 0.5 * ref) < 1e-2
+    if op == "NT":                                                     # the "mixed16" forward form: fp16 operands and output
+        oh = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        k.gemm(kop, A.to(torch.float16), B.to(torch.float16), oh, bias=bias)
+        assert rel_err(oh, A.to(torch.float16).float() @ B.to(torch.float16).float().t() + bias) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K,op", [(4096, 3072, 768, "NT"), (4096, 2304, 768, "NT"), (4096, 3072, 768, "NN"), (2048, 3072, 192, "NT"),
                                       (8192, 1024, 1024, "NN"), (6144, 1024, 192, "NT")])
 def test_gemm_wide_tiles_xcd_cut_does_not_change_results(M, N, K, op, request):
