@@ -633,15 +633,30 @@ def main():
         flops, ms, launches, abytes = K.profile_gemm(False, reps=nprof)
         traffic, traffic_src = None, None
         tpath = None
-        for tag in ("r03", "r02", "r01"):      # the newest committed PMC passes
+        for tag in ("r04", "r03", "r02", "r01"):      # the newest committed PMC passes
             cand = os.path.join(ROOT, "profiles", "%s_gemm_traffic.json" % tag)
             if os.path.exists(cand):
                 tpath = cand
                 break
         # PMC passes cannot run inside this process: taken from the committed rocprofv3 runs (measured on c2 only)
-        if tpath is not None and workload_name(args) == "c2":
+        if tpath is not None and workload_name(args) == "c2":   # (measured on c2 only)
             tj = json.load(open(tpath))
             traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/%s (%s)" % (os.path.basename(tpath), tj["method"])
+        # MFMA-busy counters of the same GEMM launches (SQ_VALU_MFMA_BUSY_CYCLES, separate rocprofv3 --pmc pass over the eager
+        # step: tools/profile_mfma.sh -> profiles/r0N_mfma_busy_<config>.json); like `traffic`, not collectable in-process
+        mfma_busy = None
+        for tag in ("r04",):
+            cand = os.path.join(ROOT, "profiles", "%s_mfma_busy_%s.json" % (tag, workload_name(args)))
+            if os.path.exists(cand):
+                mj = json.load(open(cand))
+                gc = mj.get("classes", {}).get("gemm")
+                if gc:
+                    mfma_busy = {"gemm_class_mfma_util_pct": gc["mfma_util_pct"],
+                                 "gemm_class_busy_frac_of_nominal_peak": gc["mfma_busy_frac_of_nominal_peak"],
+                                 "all_kernels_mfma_util_pct": mj.get("all_kernels_mfma_util_pct"),
+                                 "source": "profiles/%s (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); busy cycles / "
+                                           "(1024 SIMDs x traced duration x 2.4 GHz): a profiled eager pass)" % os.path.basename(cand)}
+                break
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma",
@@ -650,7 +665,7 @@ def main():
                               "gemm_kernel (ragged shapes); NT / NN / TN, bf16 MFMA 16x16x32",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(abytes / launches),
+                    "traffic_source": traffic_src, "mfma_busy": mfma_busy, "algorithmic_bytes_per_launch": round(abytes / launches),
                     "algorithmic_flop_per_launch": round(flops / launches),
                     "launches_per_step": launches // nprof, "avg_launch_us": round(1e3 * ms / launches, 2),
                     "gemm_ms_per_step": round(ms / nprof, 3),

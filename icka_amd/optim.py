@@ -11,7 +11,13 @@ shadows the next forward's GEMMs read, so the arena's per-forward re-cast has no
 A ``torch.optim.Optimizer``: ``param_groups`` / ``lr`` are the usual ones, so the reference's
 ``get_linear_schedule_with_warmup`` (a LambdaLR) drives it unchanged.  Arithmetic = ``torch.optim.AdamW`` (what transformers
 now ships in place of the ``transformers.AdamW`` the reference imported; that class is absent from the installed
-transformers 5.x -- parity with it is unpinned; tests pin this class against torch.optim.AdamW + clip_grad_norm_).
+transformers 5.x -- PARITY WITH IT IS UNPINNED: the defaults below (eps 1e-8, decoupled decay applied as in torch) are
+torch's, the reference passed no eps; tests pin this class against torch.optim.AdamW + clip_grad_norm_).
+
+Checkpoints: the moments and the step count live in flat arena-layout buffers, not in ``Optimizer.state``;
+``state_dict()`` / ``load_state_dict()`` carry them (keys ``icka_m`` / ``icka_v`` / ``icka_t`` / ``icka_layout``), and a
+resumed run continues with the same bias correction.  A state saved for another arena layout is refused; a model whose arena
+is rebuilt after the first step (``.to()``, new Parameter objects) raises instead of silently restarting the moments.
 """
 from __future__ import annotations
 
@@ -52,6 +58,7 @@ class ArenaAdamW(torch.optim.Optimizer):
         self._norm_table = None
         self._partials = None
         self._clip = None
+        self._pending = None     # state loaded before the arena was bound
 
     # ------------------------------------------------------------------------------------------------------------
     def _bind(self) -> ParamArena:
@@ -59,12 +66,54 @@ class ArenaAdamW(torch.optim.Optimizer):
         if A.device.type != "cuda":
             raise RuntimeError("ArenaAdamW: the model's parameters are on %s (icka_amd has no CPU path)" % A.device)
         if A is not self._arena:
+            if self._arena is not None and self._t > 0:
+                raise RuntimeError("ArenaAdamW: the model's parameter arena was rebuilt after %d optimizer steps (.to() / new "
+                                   "Parameter objects): the moment buffers belong to the old layout.  Save state_dict() before "
+                                   "moving the model and load it into a new optimizer afterwards." % self._t)
             self._arena = A
             self._m = torch.zeros(A.total, dtype=torch.float32, device=A.device)
             self._v = torch.zeros(A.total, dtype=torch.float32, device=A.device)
             self._clip = torch.ones(2, dtype=torch.float32, device=A.device)
             self._sig = None
+            if self._pending is not None:       # a state loaded before the arena existed
+                self._install(A, self._pending)
+                self._pending = None
         return A
+
+    # ------------------------------------------------------------------------------------------------------------ checkpoints
+    @staticmethod
+    def _layout(A: ParamArena):
+        return [(s.name, s.off, s.numel) for s in A.order]
+
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._arena is not None and self._m is not None:
+            sd["icka_m"], sd["icka_v"] = self._m.detach().cpu().clone(), self._v.detach().cpu().clone()
+            sd["icka_layout"] = self._layout(self._arena)
+        elif self._pending is not None:
+            sd["icka_m"], sd["icka_v"], sd["icka_layout"] = self._pending["icka_m"], self._pending["icka_v"], self._pending["icka_layout"]
+        sd["icka_t"] = int(self._t)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        extra = {k: state_dict[k] for k in ("icka_m", "icka_v", "icka_layout", "icka_t") if k in state_dict}
+        super().load_state_dict({k: v for k, v in state_dict.items() if not k.startswith("icka_")})
+        if "icka_t" not in extra:
+            raise ValueError("ArenaAdamW.load_state_dict: no 'icka_t' -- not a state_dict of this class (moments and step count "
+                             "would silently restart)")
+        self._t = int(extra["icka_t"])
+        if "icka_m" in extra:
+            if self._arena is not None:
+                self._install(self._arena, extra)
+            else:
+                self._pending = extra          # installed when the arena is bound (first step)
+
+    def _install(self, A: ParamArena, extra) -> None:
+        if list(map(tuple, extra["icka_layout"])) != self._layout(A):
+            raise ValueError("ArenaAdamW.load_state_dict: the saved moments belong to another parameter layout (different model "
+                             "or registration order)")
+        self._m.copy_(extra["icka_m"])
+        self._v.copy_(extra["icka_v"])
 
     def _build(self, A: ParamArena):
         """Chunk tables: one per param group over the slots that hold a gradient this step, one over all of them."""

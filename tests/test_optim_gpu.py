@@ -82,3 +82,54 @@ def test_arena_adamw_follows_a_lambda_lr_schedule_and_skips_parameters_without_g
     torch.cuda.synchronize()
     assert torch.equal(model.bert.pooler.dense.weight.detach(), pooler_before)
     assert not torch.equal(model.classifier.weight.detach(), w_before)
+
+
+def test_arena_adamw_state_dict_resumes_moments_and_step_count():
+    """the moments and the step count live outside Optimizer.state; state_dict() / load_state_dict() carry them, so a
+    resumed run (new model object + new optimizer, state loaded BEFORE the first step binds the arena) continues exactly like
+    the uninterrupted one; a foreign layout and a plain torch state_dict are refused; a rebuilt arena after step 1 raises."""
+    import copy
+    from icka_amd.optim import ArenaAdamW
+    model, args, labels = _model()
+    twin = copy.deepcopy(model)
+
+    def run(m, opt, n):
+        for _ in range(n):
+            m.zero_grad()
+            m(*args, labels=labels).backward()
+            opt.step()
+        torch.cuda.synchronize()
+
+    full = ArenaAdamW(model, lr=1e-2, max_grad_norm=1.0)
+    run(model, full, 4)
+    first = ArenaAdamW(twin, lr=1e-2, max_grad_norm=1.0)
+    run(twin, first, 2)
+    sd = first.state_dict()
+    assert sd["icka_t"] == 2 and sd["icka_m"].abs().sum().item() > 0
+    resumed_model = copy.deepcopy(twin)
+    resumed_model._icka_arena = None                 # a fresh process would build its own arena on the first forward
+    for mod in resumed_model.modules():
+        object.__setattr__(mod, "_icka_arena", None)
+    second = ArenaAdamW(resumed_model, lr=1e-2, max_grad_norm=1.0)
+    second.load_state_dict(sd)                       # before any step: installed when the arena is bound
+    run(resumed_model, second, 2)
+    worst = max((p.detach() - q.detach()).abs().max().item() for p, q in zip(model.parameters(), resumed_model.parameters()))
+    assert worst < 1e-6, worst
+    assert second.state_dict()["icka_t"] == 4
+    with pytest.raises(ValueError, match="icka_t"):
+        ArenaAdamW(model, lr=1e-2).load_state_dict(torch.optim.AdamW(model.parameters()).state_dict())
+    bad = dict(sd)
+    bad["icka_layout"] = [("x", 0, 8)]
+    with pytest.raises(ValueError, match="another parameter layout"):
+        full.load_state_dict(bad)
+    # arena rebuilt behind a stepping optimizer
+    model.float()                                    # no-op cast keeps the views; force a rebuild the way .to() does
+    for mod in model.modules():
+        object.__setattr__(mod, "_icka_arena", None)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data = p.data.clone()
+    model.zero_grad()
+    model(*args, labels=labels).backward()
+    with pytest.raises(RuntimeError, match="rebuilt"):
+        full.step()

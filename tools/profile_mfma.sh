@@ -5,7 +5,8 @@ CFG=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-optimizer-leg --no-eager-leg"
+STEPS=3; [ "$CFG" = "c4" ] && STEPS=2
+B="$GRAFT_REPO_ROOT/bench.py --config $CFG --steps $STEPS --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-optimizer-leg --no-eager-leg"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${CFG}_busy -o b -- python3 $B > /dev/null 2> $OUT/${CFG}_busy.err &&
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/${CFG}_mops -o m -- python3 $B > /dev/null 2> $OUT/${CFG}_mops.err &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${CFG}_fetch -o f -- python3 $B > /dev/null 2> $OUT/${CFG}_fetch.err &&

@@ -1,23 +1,22 @@
 # (profiled runs skip the optimizer leg: its ATen kernels are not part of the step)
 # Round profile set (run on the GPU box through gpurun): kernel stats of the default bench, the c4 / c5 presets, and the
 # two PMC passes behind roofline.traffic.  Outputs under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2 -o c2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-optimizer-leg > $OUT/bench_c2_profiled.jsonl 2> $OUT/c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2 -o c2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-optimizer-leg --no-eager-leg > $OUT/bench_c2_profiled.jsonl 2> $OUT/c2.err
 python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_c2.jsonl 2>> $OUT/c2.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -o c4 -- python3 $GRAFT_REPO_ROOT/bench.py --config c4 --steps 30 --no-cpu-baseline --no-optimizer-leg > $OUT/bench_c4_profiled.jsonl 2> $OUT/c4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -o c4 -- python3 $GRAFT_REPO_ROOT/bench.py --config c4 --steps 30 --no-cpu-baseline --no-optimizer-leg --no-eager-leg > $OUT/bench_c4_profiled.jsonl 2> $OUT/c4.err
 python3 $GRAFT_REPO_ROOT/bench.py --config c4 --steps 30 > $OUT/bench_c4.jsonl 2>> $OUT/c4.err
 python3 $GRAFT_REPO_ROOT/bench.py --config c5 --steps 50 > $OUT/bench_c5.jsonl 2> $OUT/c5.err
 # the other arithmetic mode of each: c2 in mixed16, c4 in pure bf16 (no CPU leg)
 python3 $GRAFT_REPO_ROOT/bench.py --precision mixed16 --no-cpu-baseline > $OUT/bench_c2_mixed16.jsonl 2>> $OUT/c2.err
 python3 $GRAFT_REPO_ROOT/bench.py --config c4 --precision bf16 --steps 30 --no-cpu-baseline > $OUT/bench_c4_bf16.jsonl 2>> $OUT/c4.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-optimizer-leg > /dev/null 2> $OUT/pmc_f.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-optimizer-leg > /dev/null 2> $OUT/pmc_w.err
+# counter passes: MFMA busy / MOPS / FETCH_SIZE / WRITE_SIZE per kernel (c2 also yields gemm_traffic.json), c2 and c4
+bash $GRAFT_REPO_ROOT/tools/profile_mfma.sh $TAG c2
+bash $GRAFT_REPO_ROOT/tools/profile_mfma.sh $TAG c4
 cd $GRAFT_REPO_ROOT
-find $OUT -name "*counter_collection.csv" | head
-python3 tools/traffic_from_pmc.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/gemm_traffic.json
 # keep the merge-back small: stats + bench lines + traffic json only
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 for f in $OUT/bench_*.jsonl; do echo $f; cut -c1-300 $f; done
