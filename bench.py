@@ -319,6 +319,11 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true", help="(kept for round-1/2 command lines; the optimizer leg "
                                                                   "now always runs unless --no-optimizer-leg)")
     ap.add_argument("--no-optimizer-leg", action="store_true", help="skip the fwd+bwd+clip+AdamW leg")
+    ap.add_argument("--accumulate", type=int, default=1,
+                    help="micro-batches per gradient exchange / zero_grad (the reference's gradient_accumulation_steps, "
+                         "My_cross_attention.py:587-590; default 1 = the metric's one exchange per forward+backward).  A step "
+                         "stays one forward+backward of one batch per GPU; with k > 1 the captured step accumulates and, "
+                         "data-parallel, only every k-th step exchanges (graph.FlaggedStep(accumulate=k))")
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager (no hipGraph) timing of the same step")
     ap.add_argument("--eager-steps", type=int, default=10, help="steps of the eager leg (bounded: it is a side report)")
     ap.add_argument("--optimizer-steps", type=int, default=20, help="steps of the optimizer leg (bounded: it is a side report)")
@@ -446,7 +451,7 @@ def main():
             log("capturing the step as one hipGraph with bucket-ready flags (eager all-reduces on the communication stream)")
             if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallbacks below
                 raise RuntimeError("simulated capture failure")
-            fstep = FlaggedStep(model, step, reducer, inputs=pool[0])
+            fstep = FlaggedStep(model, step, reducer, inputs=pool[0], accumulate=args.accumulate)
             run_step = fstep
             mode = "hipgraph+flag-waits+eager-allreduce(%d buckets, overlapped)" % len(reducer.buckets)
         except Exception as e:  # noqa: BLE001
@@ -507,16 +512,22 @@ def main():
                     run_step = step
 
     log("warm-up %d steps" % args.warmup)
+    acc_k = max(1, args.accumulate)
+    if acc_k > 1 and reducer is not None and not mode.startswith("hipgraph+flag-waits"):
+        raise SystemExit("--accumulate > 1 under data parallelism needs the flagged step (the other forms exchange every step)")
     for i in range(args.warmup):
-        model.zero_grad()
+        if i % acc_k == 0:
+            model.zero_grad()
         step_loss = run_step(*pool[i % POOL])
+    model.zero_grad()
     sync()
     log("timing %d steps (%s)" % (args.steps, mode))
     t0 = time.perf_counter()
     for i in range(args.steps):
         # the reference drops the gradients after every optimisation step (:843); set_to_none: the next backward overwrites
         # the gradient arena (no memset) -- a captured step replays its overwrite capture
-        model.zero_grad()
+        if i % acc_k == 0:
+            model.zero_grad()
         step_loss = run_step(*pool[i % POOL])
     sync()
     dt = time.perf_counter() - t0
@@ -693,7 +704,7 @@ def main():
                                       " with fp8 QK^T/PV" if args.fp8_cross else "", args.labels),
                        "global_batch": args.batch * world, "seq_len": args.seq, "regions": args.regions,
                        "parallelism": "dp%d" % world, "flops_per_sample_fwd_bwd": fl_sample, "launch": mode,
-                       "precision": args.precision,
+                       "precision": args.precision, "accumulate": acc_k,
                        "shadow_policy": arena.shadow_policy,
                        "gradient_exchange": None if reducer is None else
                        "%s buckets x %d, %s on the wire (%d MB per rank and step)%s"

@@ -97,10 +97,10 @@ class ArenaAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         extra = {k: state_dict[k] for k in ("icka_m", "icka_v", "icka_layout", "icka_t") if k in state_dict}
-        super().load_state_dict({k: v for k, v in state_dict.items() if not k.startswith("icka_")})
         if "icka_t" not in extra:
             raise ValueError("ArenaAdamW.load_state_dict: no 'icka_t' -- not a state_dict of this class (moments and step count "
                              "would silently restart)")
+        super().load_state_dict({k: v for k, v in state_dict.items() if not k.startswith("icka_")})
         self._t = int(extra["icka_t"])
         if "icka_m" in extra:
             if self._arena is not None:
