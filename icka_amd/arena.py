@@ -117,10 +117,11 @@ class ParamArena(object):
         """False when a parameter was re-allocated behind our back (.to(), .cuda(), new Parameter objects).
         Cheap by design (runs in every module forward): .to()/.cuda() move ALL parameters, so checking the first
         one of the sub-tree is enough."""
-        for p in root.parameters():
-            s = self.slots.get(id(p))
-            return s is not None and p.data_ptr() == self.flat.data_ptr() + 4 * s.off
-        return False
+        p = _first_param(root)      # (root.parameters() builds the whole named_modules machinery: ~3 us per module forward)
+        if p is None:
+            return False
+        s = self.slots.get(id(p))
+        return s is not None and p.data_ptr() == self.flat.data_ptr() + 4 * s.off
 
     # ------------------------------------------------------------------------------------------ views
     def slot(self, p: nn.Parameter) -> Slot:
@@ -322,6 +323,19 @@ def _install_optimizer_hook() -> None:
 _install_optimizer_hook()
 
 
+def _first_param(module: nn.Module):
+    """First parameter of a module tree in ``parameters()`` order (own parameters, then children), without generators."""
+    for p in module._parameters.values():
+        if p is not None:
+            return p
+    for child in module._modules.values():
+        if child is not None:
+            p = _first_param(child)
+            if p is not None:
+                return p
+    return None
+
+
 def _collect(module: nn.Module, prefix: str):
     """Parameters in arena order: registration order, except that a module may impose the order of its whole
     sub-tree through ``icka_param_order()`` (attention blocks put query/key/value weights, then their biases,
@@ -364,10 +378,9 @@ class ArenaModule(nn.Module):
             # the OUTERMOST module of a call tree owns the arena of its whole sub-tree, also when its own forward launches
             # nothing (BertAttention, BertCrossAttention: containers whose children would otherwise build one arena each)
             if getattr(self, "_icka_arena", None) is None:
-                for p in self.parameters():
-                    if p.device.type == "cuda":
-                        arena_of(self)
-                    break
+                p = _first_param(self)
+                if p is not None and p.device.type == "cuda":
+                    arena_of(self)
         _FWD_DEPTH[0] += 1
         try:
             return super().__call__(*args, **kwargs)
