@@ -68,6 +68,7 @@ PROTOTYPES = {
     "icka_gemm_set_ring": (c_i32, [c_i32]),
     "icka_gemm_set_tile_n": (c_i32, [c_i32]),
     "icka_gemm_set_wide_tiles": (c_i32, [c_i32]),
+    "icka_gemm_set_persistent": (c_i32, [c_i32]),
     "icka_gemm_set_square_tiles": (c_i32, [c_i32]),
     "icka_gemm_set_direct_epilogue": (c_i32, [c_i32]),
     "icka_gemm_set_big_tiles": (c_i32, [c_i32]),

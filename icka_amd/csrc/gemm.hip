@@ -582,22 +582,25 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
     for (int i = 0; i < NROW; ++i) {
         const int row = rb + RSTEP * i;
-        const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
+        const int m = (WIDE == 1 || WIDE == 2) ? m0 + ((row >> 5) << 6) + (row & 31)
+                      : ((WIDE == 4 || WIDE == 5) ? m0 + ((row >> 4) << 6) + (row & 15) : m0 + row);
         araw[i] = u32x4{0u, 0u, 0u, 0u};
         if (use_aux) araw[i] = ld_once(reinterpret_cast<const u32x4*>(g.aux + (int64_t)m * g.ldaux + n));
     }
     // (the 12-wave kernel runs at a 168-register cap with accumulators of the other pass alive: keep its row loop rolled)
-    constexpr int UNR = WIDE ? 1 : ROWS / RSTEP;
+    constexpr int UNR = (WIDE == 1 || WIDE == 2) ? 1 : ROWS / RSTEP;
 #pragma unroll UNR
     for (int i = 0; i < ROWS / RSTEP; ++i) {
         const int row = rb + RSTEP * i;
         // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
-        const int m = WIDE ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
+        // (3: 192-wide image, plain rows; 4 / 5: 16-row slabs of four 64-row wave tiles, 192- / 128-wide image: gemm_w3p_kernel)
+        const int m = (WIDE == 1 || WIDE == 2) ? m0 + ((row >> 5) << 6) + (row & 31)
+                      : ((WIDE == 4 || WIDE == 5) ? m0 + ((row >> 4) << 6) + (row & 15) : m0 + row);
         const u32x4 acur = araw[0];   // (constant indices: the queue stays in registers when the loop is rolled)
 #pragma unroll
         for (int q = 0; q + 1 < NROW; ++q) araw[q] = araw[q + 1];
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + ((WIDE == 1 || WIDE == 3 || WIDE == 4) ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + ((WIDE == 1 || WIDE == 3 || WIDE == 4) ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
         float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
                       hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
         float a[8];
@@ -1259,6 +1262,10 @@ int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagno
 int g_direct = 1;  // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
 int g_sq = 0;    // 256x256 tiles of the 8-wave load+compute kernel: OFF by default (icka_gemm_set_square_tiles; 96 vs 99 us
                  // at 8192 x 4096 x 1024 cold, ahead only from K = 2048 on, where no shape of the path qualifies)
+int g_w3p = [] { const char* e = getenv("ICKA_GEMM_W3P"); return e ? atoi(e) : 0; }();   // (env: same-box A/B)
+// persistent form of the 12-wave kernel (icka_gemm_set_persistent), OFF by default: 1 = for the 256x128 tile where an output has
+// whole multiples of 256 tiles and K <= 1024 (bert-large ffn-up / d(ffn-down): 92 vs 99 us stand-alone, but the c4 STEP is
+// 2.6 % slower with it: profiles/NEGATIVE_RESULTS.md), 2 = also 256x192 (tests; 69 vs 65 us)
 int g_w3 = 1;    // 256x192 tiles for wide / short-K outputs (icka_gemm_set_wide_tiles)
 int g_bn = 0;    // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced (icka_gemm_set_tile_n)
 int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
@@ -1399,6 +1406,144 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
         }
         __syncthreads();
         epilogue_rows<32, BNW / 8, BNW == 192 ? 1 : 2>(g, smem, m0 + 32 * pass, n0, tid);
+    }
+}
+
+// =====================================================================================================================
+// PERSISTENT form of the 12-wave kernel for outputs of more than one tile per CU (M = 8192: bert-large / batch-64 shapes).
+// One block per CU walks tiles b, b + grid, ...  What it buys: a tile's epilogue (LDS passes + a store burst of the whole
+// chip: 33 - 67 MB per round) no longer runs with the matrix pipe idle and the next tile's first loads still to be issued --
+// the LOADER waves, which never store (so their counted vmcnt sees LDS-DMA only), issue the next tile's A(0), B(0), A(1)
+// right after the last k-tile has been read, the compute waves run the epilogue out of ONE A-ring slot (8 passes of 32 rows)
+// and return to a ring that is already filling, and their stores drain under the next tile's MFMAs (compute waves never
+// wait on vmcnt).  Ring slots are numbered continuously across tiles (A: 3 slots, B: 2); the staging slot of a tile's
+// epilogue is the A slot the next tile's first two k-tiles do not use.
+template <bool B_KM, bool F16 = false, int BNW = 192>
+__global__ __launch_bounds__(768) void gemm_w3p_kernel(const GemmArgs gp, const int ntiles) {
+    const GemmArgs g = gp;
+    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    constexpr int BH = BNW / 2, NB16 = BH / 16;
+    static_assert(BNW == 192 || BNW == 128, "tile width");
+    const int nk = g.K / BK;
+    const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block
+    auto origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, li = t >> 3;
+        const int xi = xcd >> g.w3_pnlog, xj = xcd & ((1 << g.w3_pnlog) - 1);
+        const int r = li / g.w3_sn, c = li - r * g.w3_sn;
+        m0 = (xi * ((ntiles >> 3) / g.w3_sn) + r) * 256;
+        n0 = (xj * g.w3_sn + c) * BNW;
+    };
+    // Every tile numbers its ring from A slot 0 and B slot 1 (after the barrier E0 the whole ring is free): the next tile's
+    // A(0), B(0), A(1) go to A slots 0, 1 and B slot 1, which leaves [A slot 2 | B slot 0] = 64 KiB of CONTIGUOUS LDS for the
+    // epilogue's staging tile (64 rows x 192 or 128 columns of f32).
+    if (wave >= 8) {
+        // ------------------------------------------------------------------------------------------- loader waves
+        const int lw = wave - 8;
+        const bf16_t* pa0[4];
+        const bf16_t* pa1[4];
+        const bf16_t* pb0[4];
+        const bf16_t* pb1[4];
+        const int64_t sa = BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
+        constexpr int NJB = B_KM ? 4 : BH / 32;
+        const uint32_t ldsB = lds0 + W3_NA * W3_A;
+#define ICKA_W3P_A(SLOT)                                                         \
+    do {                                                                         \
+        dma_issue(pa0, sa, lds0 + (SLOT) * W3_A + lw * 1024);                    \
+        dma_issue(pa1, sa, lds0 + (SLOT) * W3_A + TILE_BYTES + lw * 1024);       \
+    } while (0)
+#define ICKA_W3P_B(SLOT)                                                         \
+    do {                                                                         \
+        dma_issue<NJB>(pb0, sb, ldsB + (SLOT) * W3_B + lw * 1024);               \
+        dma_issue<NJB>(pb1, sb, ldsB + (SLOT) * W3_B + TILE_BYTES + lw * 1024);  \
+    } while (0)
+#define ICKA_W3P_FIRST(T)                                                        \
+    do {                                                                         \
+        int m0_, n0_;                                                            \
+        origin((T), m0_, n0_);                                                   \
+        dma_init<false>(pa0, g.A, g.lda, m0_, lw, lane);                         \
+        dma_init<false>(pa1, g.A, g.lda, m0_ + 128, lw, lane);                   \
+        dma_init<B_KM, BH>(pb0, g.B, g.ldb, n0_, lw, lane);                      \
+        dma_init<B_KM, BH>(pb1, g.B, g.ldb, n0_ + BH, lw, lane);                 \
+        ICKA_W3P_A(0);                                                           \
+        ICKA_W3P_B(1);                                                           \
+        if (nk > 1) ICKA_W3P_A(1);                                               \
+    } while (0)
+        ICKA_W3P_FIRST((int)blockIdx.x);
+        for (int i = 0; i < ntl; ++i) {
+            int sa3 = 2;   // A slot of k-tile kt + 2
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();   // A(kt+1) may still be in flight (8 pieces)
+                __builtin_amdgcn_s_barrier();        // k-tile kt published; every compute wave is done with k-tile kt-1
+                if (kt + 1 < nk) ICKA_W3P_B(kt & 1);                     // B(kt+1) -> slot (1 + kt + 1) & 1
+                if (kt + 2 < nk) ICKA_W3P_A(sa3);
+                sa3 = sa3 == 2 ? 0 : sa3 + 1;
+            }
+            __builtin_amdgcn_s_barrier();            // E0: every compute wave has read the tile's last k-tile
+            if (i + 1 < ntl) ICKA_W3P_FIRST((int)blockIdx.x + (i + 1) * (int)gridDim.x);   // under this tile's epilogue
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) __builtin_amdgcn_s_barrier();   // the compute waves' 4 passes x 2 barriers
+        }
+#undef ICKA_W3P_A
+#undef ICKA_W3P_B
+#undef ICKA_W3P_FIRST
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------- compute waves
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * BH;
+    char* const ctile = smem + 2 * W3_A;       // [A slot 2 | B slot 0]
+    for (int i = 0; i < ntl; ++i) {
+        int m0, n0;
+        origin((int)blockIdx.x + i * (int)gridDim.x, m0, n0);
+        f32x4 acc[4][NB16];
+#pragma unroll
+        for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j) acc[a_][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* sA = smem + (kt % W3_NA) * W3_A + (wr >> 7) * TILE_BYTES;
+            const char* sB = smem + W3_NA * W3_A + ((kt + 1) & 1) * W3_B + (wave & 1) * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[NB16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t] = read_frag<false>(sA, (wr & 127) + 16 * t, ks, lane);
+#pragma unroll
+                for (int t = 0; t < NB16; ++t) fb[t] = read_frag<B_KM>(sB, 16 * t, ks, lane);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NB16; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
+            }
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // E0 (all 12 waves): the ring's last k-tile is in registers
+        // ---- 4 passes of 64 rows x BNW: in pass j EVERY compute wave deposits the 16-row group j of its 64 x BH tile
+        //      (staged row 16 q + r = tile row 64 q + 16 j + r for wave row q), then the 8 compute waves finish the rows
+#define ICKA_W3P_PASS(J)                                                                                              \
+        do {                                                                                                          \
+            const int row_ = (wave >> 1) * 16 + (lane & 15);                                                          \
+            _Pragma("unroll") for (int ni = 0; ni < NB16; ++ni) {                                                     \
+                const int ch_ = (wc >> 2) + 4 * ni + (lane >> 4);                                                     \
+                *reinterpret_cast<f32x4*>(ctile + (BNW == 192 ? off_cw(row_, ch_) : off_c(row_, ch_))) = acc[J][ni] * g.alpha; \
+            }                                                                                                         \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+            __builtin_amdgcn_s_barrier();                                                                             \
+            asm volatile("" ::: "memory");                                                                            \
+            epilogue_rows<(BNW == 192 ? 16 : 32), BNW / 8, (BNW == 192 ? 4 : 5), false, 64>(g, ctile, m0 + 16 * (J), n0, tid); \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+            __builtin_amdgcn_s_barrier();                  /* staging tile consumed */                                \
+        } while (0)
+        ICKA_W3P_PASS(0);
+        ICKA_W3P_PASS(1);
+        ICKA_W3P_PASS(2);
+        ICKA_W3P_PASS(3);
+#undef ICKA_W3P_PASS
     }
 }
 
@@ -1689,20 +1834,26 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                         nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
                         { const int pm = gemm_w3_grid(g.M, g.N, 192), pn = 8 / pm;
                           g.w3_sn = (g.N / 192) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
-                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
+                        if (g_w3p == 2 && nb3 > sq_cus())   // (2 = tests: at 256x192 the persistent form measured SLOWER, 69 vs 65 us)
+                            hipLaunchKernelGGL((gemm_w3p_kernel<B_KM, F16>), dim3(sq_cus()), dim3(768), 0, st, g, nb3);
+                        else
+                            hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }
                     // 256x128 tiles (the same kernel, 64-column halves) where 128x128 tiles would take exactly two rounds of
                     // the CUs with one block each (N = 1024 at bert-large / M = 8192: 256 tiles), any K
                     const int nb2 = (g.M / 256) * (g.N / 128);
-                    if (g_w3 && g.M % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nb2 % 8 == 0 && nb2 >= 192 && nb2 <= 256 &&
+                    if (g_w3 && g.M % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nb2 % 8 == 0 && nb2 >= 192 && (nb2 <= 256 || (g_w3p && nb2 % 256 == 0 && g.K <= 1024)) &&
                         !(g.n96ok && g_bn == 96) && !(g.K <= 1024 && g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f)) {
                         // (short reductions with a plain f32 output stay on the 128-wide kernel: its direct epilogue beats
                         //  the two staged passes here, 25.9 vs 28.3 us at 8192 x 1024 x 1024)
                         { const int pm = gemm_w3_grid(g.M, g.N, 128), pn = 8 / pm;
                           g.w3_sn = (g.N / 128) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
-                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
+                        if (g_w3p && nb2 > sq_cus())
+                            hipLaunchKernelGGL((gemm_w3p_kernel<B_KM, F16, 128>), dim3(sq_cus()), dim3(768), 0, st, g, nb2);
+                        else
+                            hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }
@@ -1799,6 +1950,10 @@ extern "C" int icka_gemm_set_direct_epilogue(int on) {
 
 extern "C" int icka_gemm_set_square_tiles(int on) {
     g_sq = on < 0 || on > 2 ? 0 : on;   // 0 off (default), 1 by shape, 2 wherever the tile divides the output (tests)
+    return 0;
+}
+extern "C" int icka_gemm_set_persistent(int on) {
+    g_w3p = on < 0 || on > 2 ? 0 : on;
     return 0;
 }
 extern "C" int icka_gemm_set_wide_tiles(int on) {

@@ -117,6 +117,8 @@ int icka_gemm_set_tile_n(int bn);
 /* 256x192 output tiles (12-wave kernel) for wide outputs with a short reduction whose tile grid covers the 256 CUs in one
  * round (M % 256 == 0, N % 192 == 0, K <= 1024, 128..256 tiles): on by default; 0 switches back to 128x128 tiles. */
 int icka_gemm_set_wide_tiles(int on);
+int icka_gemm_set_persistent(int on);     /* persistent form of the 12-wave kernel: 0 off (default), 1 = 256x128 tiles in whole
+                                             multiples of 256 tiles with K <= 1024, 2 = also 256x192 tiles (tests) */
 int icka_gemm_set_square_tiles(int on);   /* 256x256 tiles of the 8-wave load+compute kernel: 0 off (default), 1 by shape,
                                              2 wherever the tile divides the output (tests) */
 /* 1 (default): f32 outputs without activation / fan-in operand / accumulate are stored straight from the MFMA

@@ -221,6 +221,50 @@ def test_gemm_wide_tiles(M, N, K, op, wide, request):
 
 
 @pytest.mark.parametrize("op", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (8192, 4096, 1024), (8192, 3072, 64), (16384, 1536, 192), (8192, 2048, 128)])
+def test_gemm_persistent_wide_tiles(M, N, K, op, request):
+    """Persistent form of the 12-wave kernel (gemm_w3p_kernel: one block per CU walks 2 - 4 tiles of 256 x 192 / 256 x 128, the
+    loader waves issue the next tile's first k-tiles under the epilogue, ring slots numbered across tiles) == the one-tile-per-
+    block kernels bitwise for the plain bf16 output, and against fp32 matmul with the epilogues these GEMMs use; one, two, three
+    and many k-tiles per tile (ring hand-over across tiles at every phase of the 3-slot / 2-slot rings)."""
+    k = _k()
+    lib = k._lib.load()
+    request.addfinalizer(lambda: lib.icka_gemm_set_persistent(0))
+    A = rnd(M, K, seed=31, scale=0.5)
+    B = rnd(N, K, seed=32, scale=0.5) if op == "NT" else rnd(K, N, seed=32, scale=0.5)
+    kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
+    bias = rnd(N, seed=33, dtype=F32)
+    ref = A.float() @ (B.float().t() if op == "NT" else B.float())
+    lib.icka_gemm_set_persistent(0)
+    o0 = torch.empty(M, N, dtype=BF16, device="cuda")
+    k.gemm(kop, A, B, o0)
+    assert lib.icka_gemm_set_persistent(2) == 0
+    o = torch.full((M, N), float("nan"), dtype=BF16, device="cuda")
+    k.gemm(kop, A, B, o)
+    assert torch.isfinite(o.float()).all()                   # no tile left out
+    assert rel_err(o, ref) < 1e-2
+    assert torch.equal(o, o0)
+    of = torch.empty(M, N, dtype=F32, device="cuda")
+    k.gemm(kop, A, B, of, bias=bias)
+    assert rel_err(of, ref + bias) < 1e-4
+    z = torch.empty_like(o)
+    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    assert rel_err(z, ref + bias) < 1e-2 and rel_err(o, torch.nn.functional.gelu(ref + bias)) < 1e-2
+    aux = rnd(M, N, seed=34)
+    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(o, ref * x.grad) < 1e-2
+    ov = torch.empty(M, N + 64, dtype=BF16, device="cuda")[:, :N]      # strided output view
+    k.gemm(kop, A, B, ov, alpha=0.5)
+    assert rel_err(ov, 0.5 * ref) < 1e-2
+    if op == "NT":
+        oh = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        k.gemm(kop, A.to(torch.float16), B.to(torch.float16), oh, bias=bias)
+        assert rel_err(oh, A.to(torch.float16).float() @ B.to(torch.float16).float().t() + bias) < 2e-3
+
+
+@pytest.mark.parametrize("op", ["NT", "NN"])
 @pytest.mark.parametrize("M,N,K,forced", [(8192, 4096, 1024, 1), (2048, 1024, 64, 2), (2048, 2048, 192, 2), (4096, 1024, 3072, 2),
                                           (2048, 512, 128, 2)])
 def test_gemm_square_tiles(M, N, K, forced, op, request):

@@ -17,7 +17,7 @@ for kv in sys.argv[5:]:
     if k == "sets":
         NSETS = int(v)
         continue
-    assert getattr(lib, {"sq": "icka_gemm_set_square_tiles", "wide": "icka_gemm_set_wide_tiles", "ring": "icka_gemm_set_ring"}[k])(int(v)) == 0
+    assert getattr(lib, {"sq": "icka_gemm_set_square_tiles", "wide": "icka_gemm_set_wide_tiles", "ring": "icka_gemm_set_ring", "w3p": "icka_gemm_set_persistent"}[k])(int(v)) == 0
 BF16 = torch.bfloat16
 sets = []
 for _ in range(NSETS):
