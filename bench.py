@@ -310,6 +310,10 @@ def main():
     ap.add_argument("--comm-f32", action="store_true", help="fp32 gradient buckets on the wire (the library default; the "
                                                             "bench's default at N > 1 is bf16, see DESIGN.md section 6)")
     ap.add_argument("--comm-bf16", action="store_true", help="force bf16 buckets (already the bench's default at N > 1)")
+    ap.add_argument("--sparse-embeddings", action="store_true",
+                    help="data parallel: exchange the word-embedding gradient as all-gathered token rows instead of the dense "
+                         "[vocab, H] all-reduce (dp.GradReducer(sparse_embeddings=True); halves the bytes of the exposed tail at "
+                         "N <= 4, about even at N = 8 x 4096 tokens: profiles/r04_dp_budget.md)")
     ap.add_argument("--dp-step", choices=("flagged", "segmented"), default="flagged",
                     help="data parallel: 'flagged' = ONE hipGraph whose bucket-ready points are flag words waited for on the "
                          "communication stream (graph.FlaggedStep); 'segmented' = linear graph segments with the all-reduces "
@@ -425,7 +429,7 @@ def main():
     if use_dist:
         from icka_amd.dp import GradReducer
         reducer = GradReducer(arena, bucket_mb=args.bucket_mb, comm_dtype="f32" if args.comm_f32 else "bf16",
-                              diag=args.dp_diag)
+                              diag=args.dp_diag, sparse_embeddings=args.sparse_embeddings)
         reducer.broadcast_parameters(0)
         arena.reducer = reducer
     opt = None
@@ -709,7 +713,8 @@ def main():
                        "gradient_exchange": None if reducer is None else
                        "%s buckets x %d, %s on the wire (%d MB per rank and step)%s"
                        % ("bf16" if reducer.comm_bf16 else "f32", len(reducer.buckets), reducer.backend,
-                          reducer.wire_bytes() >> 20, (" DIAG=" + args.dp_diag) if args.dp_diag else "")},
+                          reducer.wire_bytes() >> 20, (" DIAG=" + args.dp_diag) if args.dp_diag else "") +
+                       ("" if reducer.sparse_word is None else "; word-embedding gradient as all-gathered token rows")},
             "shadow_cast_us": round(shadow_cast_us, 1),
             # the same step without the capture harness (eager launches from Python: what a plain import swap of the
             # reference's modules gets), and the per-call copy of a new batch into the captured step's static input buffers

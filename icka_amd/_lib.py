@@ -93,6 +93,9 @@ PROTOTYPES = {
                                c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
+    "icka_embed_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                    c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_i32, c_vp]),
+    "icka_embed_scatter_rows": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "icka_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_attn_fwd_ex": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,

@@ -474,6 +474,8 @@ struct EmbBwdArgs {
     const float* gamma; float* dword; float* dpos; float* dtype; float* partials;
     int M, S, H, vocab, n_type, padding_idx; DropCfg drop;
     const int32_t* src; bf16_t* dprompt; int S_in, P, pos_offset;   // prompt splice, see EmbFwdArgs (pos kernel only)
+    float* dtok;   // row-sparse data-parallel exchange (icka_embed_bwd_rows): the per-token word-gradient row is WRITTEN to
+                   // dtok[row][H] (zeros for the padding id) instead of being added into dword
 };
 
 template <int NCH>
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbBwdArgs a_) {
         __builtin_amdgcn_wave_barrier();
         for (int j = lane; j < a.H; j += 64) {
             const float ds = rowbuf[j];
-            if (id != a.padding_idx) atomicAdd(a.dword + id * a.H + j, ds);
+            if (a.dtok) a.dtok[(int64_t)row * a.H + j] = id != a.padding_idx ? ds : 0.f;
+            else if (id != a.padding_idx) atomicAdd(a.dword + id * a.H + j, ds);
             atomicAdd(a.dpos + (int64_t)sp * a.H + j, ds);
             if (a.n_type > 2) atomicAdd(a.dtype + t * a.H + j, ds);
         }
@@ -626,6 +629,12 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
         if (sidx < 0) {   // prompt position: the row IS the gradient of this sample's prompt vector
             bf16_t* dp = a.dprompt + ((int64_t)b * a.P + (-1 - sidx)) * a.H;
             for (int j = lane; j < a.H; j += 64) dp[j] = f2bf(rowbuf[j]);
+        } else if (a.dtok) {
+            for (int j = lane; j < a.H; j += 64) {
+                const float ds = rowbuf[j];
+                a.dtok[(int64_t)row * a.H + j] = id != a.padding_idx ? ds : 0.f;
+                if (a.n_type > 2) atomicAdd(a.dtype + t * a.H + j, ds);
+            }
         } else if (id != a.padding_idx || a.n_type > 2) {
             for (int j = lane; j < a.H; j += 64) {
                 const float ds = rowbuf[j];
@@ -874,18 +883,18 @@ extern "C" int icka_embed_prompt_fwd(const int64_t* ids, const int32_t* src, con
     return 0;
 }
 
-extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
-                              const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype,
-                              float* dgamma, float* dbeta, float* partials, int32_t B, int32_t S, int32_t H,
-                              int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop, uint64_t seed,
-                              int32_t accumulate, void* stream) {
-    if (!dy || !ids || !xhat || !rstd || !gamma || !dword || !dpos || !dtype || !dgamma || !dbeta || !partials)
+static int embed_bwd_impl(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
+                          const float* rstd, const float* gamma, float* dword, float* dtok, float* dpos, float* dtype,
+                          float* dgamma, float* dbeta, float* partials, int32_t B, int32_t S, int32_t H,
+                          int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop, uint64_t seed,
+                          int32_t accumulate, void* stream) {
+    if (!dy || !ids || !xhat || !rstd || !gamma || (!dword && !dtok) || !dpos || !dtype || !dgamma || !dbeta || !partials)
         return ICKA_E_ARG;
     if (B <= 0 || S <= 0 || H <= 0 || H % 8 != 0 || H > 8 * 64 * MAX_CH || vocab <= 0 || n_type <= 0)
         return ICKA_E_SHAPE;
     if (!al16(dy) || !al16(xhat) || !al16(gamma)) return ICKA_E_ALIGN;
     EmbBwdArgs a{(const bf16_t*)dy, ids, token_type, (const bf16_t*)xhat, rstd, gamma, dword, dpos, dtype, partials,
-                 B * S, S, H, vocab, n_type, padding_idx, make_drop(p_drop, seed), nullptr, nullptr, S, 0, 0};
+                 B * S, S, H, vocab, n_type, padding_idx, make_drop(p_drop, seed), nullptr, nullptr, S, 0, 0, dtok};
     hipStream_t st = (hipStream_t)stream;
     int grid = bwd_grid(B * S);
     if (S <= BWD_BLOCKS) {   // position-major: one block per position, S slabs
@@ -904,6 +913,64 @@ extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t*
     float* t1 = n_type == 2 ? dtype + H : nullptr;
     hipLaunchKernelGGL(finalize_kernel, dim3((SLOTS * H + 63) / 64), dim3(1024), 0, st, partials, grid, H, dgamma,
                        dbeta, t0, t1, accumulate);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
+                              const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype,
+                              float* dgamma, float* dbeta, float* partials, int32_t B, int32_t S, int32_t H,
+                              int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop, uint64_t seed,
+                              int32_t accumulate, void* stream) {
+    if (!dword) return ICKA_E_ARG;
+    return embed_bwd_impl(dy, ids, token_type, xhat, rstd, gamma, dword, nullptr, dpos, dtype, dgamma, dbeta, partials, B, S, H, vocab,
+                          n_type, padding_idx, p_drop, seed, accumulate, stream);
+}
+// Row-sparse form for the data-parallel exchange (dp.GradReducer(sparse_embeddings=True)): everything as icka_embed_bwd, except
+// that the word-table gradient is left as per-token rows dtok f32 [B*S, H] (zero rows for the padding id) for an all-gather
+// + icka_embed_scatter_rows instead of being scattered into the [vocab, H] table here.
+extern "C" int icka_embed_bwd_rows(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat,
+                                   const float* rstd, const float* gamma, float* dtok, float* dpos, float* dtype,
+                                   float* dgamma, float* dbeta, float* partials, int32_t B, int32_t S, int32_t H,
+                                   int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop, uint64_t seed,
+                                   int32_t accumulate, void* stream) {
+    if (!dtok) return ICKA_E_ARG;
+    return embed_bwd_impl(dy, ids, token_type, xhat, rstd, gamma, nullptr, dtok, dpos, dtype, dgamma, dbeta, partials, B, S, H, vocab,
+                          n_type, padding_idx, p_drop, seed, accumulate, stream);
+}
+
+namespace {
+// dword[ids[t]] += scale * rows[t] for T gathered token rows (f32 or bf16 rows); a wave per row, lane-strided f32 atomics
+// (64 consecutive floats per wave-instruction), rows of the padding id (and ids outside the table) skipped.
+__global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const void* __restrict__ rows, int rows_bf16,
+                                                                 const int64_t* __restrict__ ids, float* __restrict__ dword,
+                                                                 int64_t T, int H, int vocab, int padding_idx, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t t = w; t < T; t += nw) {
+        const int64_t id = ids[t];
+        if (id == padding_idx || id < 0 || id >= vocab) continue;
+        float* dst = dword + id * H;
+        if (rows_bf16) {
+            const bf16_t* r = reinterpret_cast<const bf16_t*>(rows) + t * H;
+            for (int j = lane; j < H; j += 64) atomicAdd(dst + j, scale * bf2f(r[j]));
+        } else {
+            const float* r = reinterpret_cast<const float*>(rows) + t * H;
+            for (int j = lane; j < H; j += 64) atomicAdd(dst + j, scale * r[j]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int icka_embed_scatter_rows(const void* rows, int32_t rows_are_bf16, const int64_t* ids, float* dword, int64_t T,
+                                       int32_t H, int32_t vocab, int32_t padding_idx, float scale, void* stream) {
+    if (!rows || !ids || !dword) return ICKA_E_ARG;
+    if (T < 0 || H <= 0 || vocab <= 0) return ICKA_E_SHAPE;
+    if (T == 0) return 0;
+    int64_t blocks = (T + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, rows_are_bf16, ids,
+                       dword, T, H, vocab, padding_idx, scale);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

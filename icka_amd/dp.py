@@ -23,6 +23,15 @@ the layout of the gradient buffer:
     gradient buffer with the 1 / world factor folded in (icka_dp_cast_back_scaled).
 The N-rank bf16 ring sum rounds once per hop; tests/test_dp_gloo_cpu.py bounds that error against the fp32 mean.
 
+Row-sparse word-embedding exchange (``sparse_embeddings=True``).  The word-embedding table is 20 % of bert-base's parameters
+(23.4 M of 119 M), its gradient is final only with the LAST kernel of backward, and a step touches at most B x S of its rows:
+instead of all-reducing the dense [vocab, H] gradient the ranks all-gather their B x S token-gradient rows (wire dtype) and
+ids and every rank scatter-adds all N x B x S rows with 1 / N folded in (icka_embed_bwd_rows + icka_embed_scatter_rows); a rank
+that brings at least vocab / 4 rows falls back to a dense all-reduce of the slot.  f32 atomics: the sum order differs from the
+dense path's in the last bits (tests bound it at 1e-6).  Not combined with accumulation inside a captured step
+(FlaggedStep(accumulate > 1) refuses it: the earlier micro-batches' rows would stay local).  Priced in
+profiles/r04_dp_budget.md: it halves the bytes of the exposed tail at N <= 4 and is about even at N = 8 x 4096 tokens.
+
 A slot counts as final when it has received ALL the gradient contributions it received in the calibration (first)
 step -- a module applied twice per forward contributes twice -- so a bucket is never reduced while a late write into it
 is still to come; a write that arrives for a bucket already in flight raises.  Works with the ``nccl`` (= RCCL) backend on
@@ -38,6 +47,14 @@ import torch.distributed as dist
 
 from .arena import ParamArena
 
+
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
 # CUs dp.GradReducer keeps free of persistent BiLSTM blocks while RCCL workgroups may share the GPU (icka_hip.h:
 # icka_lstm_set_reserved_cus): RCCL runs one workgroup per channel, at most 64 channels
 LSTM_RESERVED_CUS = 64
@@ -45,7 +62,8 @@ LSTM_RESERVED_CUS = 64
 
 class GradReducer(object):
     def __init__(self, arena: ParamArena, group=None, bucket_mb: float = 64.0, comm_dtype: Optional[str] = None,
-                 comm_bf16: Optional[bool] = None, diag: str = "", lstm_reserved_cus: Optional[int] = None):
+                 comm_bf16: Optional[bool] = None, diag: str = "", lstm_reserved_cus: Optional[int] = None,
+                 sparse_embeddings: bool = False):
         """``bucket_mb``: minimum bucket size in MB of fp32 gradients.  ``comm_dtype``: "f32" (default) | "bf16" (ROCm devices
         only; module docstring).  ``comm_bf16`` is the round-1 spelling of the same switch.  ``diag``: DIAGNOSTIC ONLY --
         any of "cast" / "comm" (comma-separated), or "none": leave parts of the exchange out to price the others
@@ -71,6 +89,33 @@ class GradReducer(object):
             print("[icka_amd.dp] DIAGNOSTIC MODE diag=%r: parts of the gradient exchange are skipped -- the gradients of "
                   "this process are WRONG (pricing runs only)" % self.diag, file=sys.stderr, flush=True)
         self.buckets: List[Tuple[int, int]] = arena.buckets(int(bucket_mb * (1 << 20) / 4))
+        # ---- row-sparse exchange of the word-embedding gradient (module docstring): the largest embedding table leaves the
+        #      dense buckets; its gradient travels as the ranks' token rows (set_sparse_rows / exchange_sparse)
+        self.sparse_word = None
+        self._sparse = None          # (rows f32 [T, H], ids int64 [T], accumulate) of the step in flight
+        self._sparse_ws = {}
+        self.sparse_stats = {"sparse": 0, "dense_fallback": 0}
+        if sparse_embeddings:
+            tables = [sl for sl in arena.order if sl.is_table]
+            word = max(tables, key=lambda sl: sl.shape[0]) if tables else None
+            if word is not None:
+                lo_w, hi_w = word.off, word.off + (word.numel + 7) // 8 * 8
+                cut = None
+                for bi, (lo, hi) in enumerate(self.buckets):
+                    if lo == lo_w and hi_w <= hi:
+                        cut = (bi, (hi_w, hi))
+                    elif hi == hi_w and lo <= lo_w:
+                        cut = (bi, (lo, lo_w))
+                if cut is None:
+                    print("[icka_amd.dp] sparse_embeddings: %s is not at an edge of a gradient bucket: dense exchange kept"
+                          % word.name, file=sys.stderr, flush=True)
+                else:
+                    bi, (lo, hi) = cut
+                    if hi > lo:
+                        self.buckets[bi] = (lo, hi)
+                    else:
+                        del self.buckets[bi]
+                    self.sparse_word = word
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.is_cuda else None
         # slot -> bucket index
         self._bucket_of: Dict[int, int] = {}
@@ -270,6 +315,8 @@ class GradReducer(object):
         which autograd runs the blocks.  A write into a bucket whose all-reduce is already in flight (more writes than in
         the calibration step: a data-dependent branch, a module applied more often) would be lost or race with the
         in-place reduction: it raises."""
+        if self.sparse_word is not None:
+            slots = [s for s in slots if s is not self.sparse_word]
         if not self._calibrated:
             for s in slots:
                 self._expected[id(s)] = self._expected.get(id(s), 0) + 1
@@ -307,6 +354,7 @@ class GradReducer(object):
             if not self._launched[bi]:
                 self._launch(bi)
         if self.capture is None:
+            self.exchange_sparse()
             self.join()
         self._calibrated = True
         # parameters that never receive a gradient (e.g. the pooler when only logits are used) are not waited for
@@ -325,7 +373,118 @@ class GradReducer(object):
         """Non-overlapped form: all-reduce every bucket now (after backward)."""
         self.finish()
 
+    # ------------------------------------------------------------------------------------------------- row-sparse word table
+    def set_sparse_rows(self, rows: torch.Tensor, ids: torch.Tensor, accumulate: bool = False) -> None:
+        """Called by the embedding backward (ops.EmbeddingsFn; tests call it directly): this step's per-token gradient rows of
+        the word table (f32 [T, H], zero rows for the padding id) and their ids (int64 [T]).  ``accumulate``: the caller still
+        holds an earlier gradient of this cycle in the table's slot (the exchanged rows are added to it)."""
+        if self.sparse_word is None:
+            raise RuntimeError("GradReducer was built without sparse_embeddings=True (or the table is not at a bucket edge)")
+        if rows.dim() != 2 or rows.shape[1] != self.sparse_word.shape[1] or ids.numel() != rows.shape[0]:
+            raise ValueError("sparse rows must be [T, %d] with one id per row" % self.sparse_word.shape[1])
+        self._sparse = (rows, ids, bool(accumulate))
+
+    def _sparse_buffers(self, T: int, H: int, dtype, device):
+        key = (T, H, dtype, str(device))
+        ws = self._sparse_ws.get(key)
+        if ws is None:
+            ws = {"rows_w": torch.empty(T, H, dtype=dtype, device=device),
+                  "all_rows": torch.empty(self.world * T, H, dtype=dtype, device=device),
+                  "all_ids": torch.empty(self.world * T, dtype=torch.int64, device=device)}
+            self._sparse_ws[key] = ws
+        return ws
+
+    def exchange_sparse(self) -> None:
+        """All-gather every rank's token rows + ids and add (1 / world) * rows into the word table's gradient slot; dense
+        fallback (local scatter + all-reduce of the slot) when a rank brings at least vocab / 4 rows.  On devices with RCCL the
+        work goes to the communication stream (after everything already on the current stream); ``join`` orders it before the
+        consumers of the gradient."""
+        if self.sparse_word is None or self._sparse is None:
+            return
+        rows, ids, accumulate = self._sparse
+        self._sparse = None
+        w = self.sparse_word
+        V, H = w.shape
+        T = rows.shape[0]
+        g = self.arena.gflat[w.off:w.off + w.numel].view(V, H)
+        inv = 1.0 / self.world
+        dense = T * 4 >= V
+        self.sparse_stats["dense_fallback" if dense else "sparse"] += 1
+        if not self.is_cuda:                                   # CPU arena over gloo (tests): plain tensor arithmetic
+            keep = (ids != 0).to(rows.dtype).unsqueeze(1)
+            if dense:
+                loc = torch.zeros_like(g).index_add_(0, ids, rows * keep)
+                dist.all_reduce(loc, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(g + loc * inv if accumulate else loc * inv)
+                return
+            all_rows = [torch.empty_like(rows) for _ in range(self.world)]
+            all_ids = [torch.empty_like(ids) for _ in range(self.world)]
+            dist.all_gather(all_rows, rows.contiguous(), group=self.group)
+            dist.all_gather(all_ids, ids.contiguous(), group=self.group)
+            if not accumulate:
+                g.zero_()
+            for r_, i_ in zip(all_rows, all_ids):
+                g.index_add_(0, i_, r_ * (i_ != 0).to(r_.dtype).unsqueeze(1) * inv)
+            return
+        from . import kernels as K
+        nccl = self.backend == "nccl"
+        on_current = getattr(self, "_exchange_on_current", False)     # graph.FlaggedStep: already on the communication stream
+        if nccl and not on_current:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(self.comm_stream) if (nccl and not on_current) else _NullCtx()
+        with ctx:
+            if dense:
+                if accumulate:
+                    tmp = self.arena.workspace("sparse_dense", V * H).view(V, H)
+                    K.zero_(tmp.view(-1))
+                    K.embed_scatter_rows(rows, ids, tmp, padding_idx=0, scale=inv)
+                    self._allreduce_tensor(tmp.view(-1))
+                    ar = self._sparse_ws.get("arange")
+                    if ar is None:
+                        ar = self._sparse_ws["arange"] = torch.arange(V, dtype=torch.int64, device=g.device)
+                    K.embed_scatter_rows(tmp, ar, g, padding_idx=-1, scale=1.0)      # g += tmp (row-wise atomics kernel)
+                else:
+                    K.zero_(g.view(-1))
+                    K.embed_scatter_rows(rows, ids, g, padding_idx=0, scale=inv)
+                    self._allreduce_tensor(g.view(-1))
+                return
+            wdt = torch.bfloat16 if self.comm_bf16 else torch.float32
+            ws = self._sparse_buffers(T, H, wdt, rows.device)
+            if self.comm_bf16:
+                K.cast_f32_to_bf16(rows.view(-1), ws["rows_w"].view(-1))
+                mine = ws["rows_w"]
+            else:
+                mine = rows
+            ids_c = ids.contiguous()
+            if nccl:
+                dist.all_gather_into_tensor(ws["all_rows"], mine, group=self.group)
+                dist.all_gather_into_tensor(ws["all_ids"], ids_c, group=self.group)
+            else:                                              # gloo with device tensors (one-GPU tests): through the host
+                hr = [torch.empty(T, H, dtype=torch.float32) for _ in range(self.world)]
+                hi = [torch.empty(T, dtype=torch.int64) for _ in range(self.world)]
+                dist.all_gather(hr, mine.float().cpu(), group=self.group)
+                dist.all_gather(hi, ids_c.cpu(), group=self.group)
+                ws["all_rows"].copy_(torch.cat(hr).to(wdt))
+                ws["all_ids"].copy_(torch.cat(hi))
+            if not accumulate:
+                K.zero_(g.view(-1))
+            K.embed_scatter_rows(ws["all_rows"], ws["all_ids"], g, padding_idx=0, scale=inv)
+
+    def _allreduce_tensor(self, t: torch.Tensor) -> None:
+        if self.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+
     # -------------------------------------------------------------------------------------------------
     def wire_bytes(self) -> int:
         """Bytes one rank puts into the all-reduces of a step (before the algorithm's 2(N-1)/N factor)."""
-        return sum(e - s for s, e in self.buckets) * (2 if self.comm_bf16 else 4)
+        b = sum(e - s for s, e in self.buckets) * (2 if self.comm_bf16 else 4)
+        if self.sparse_word is not None and self._sparse_ws:
+            for k, ws in self._sparse_ws.items():
+                if isinstance(k, tuple):
+                    b += ws["rows_w"].numel() * ws["rows_w"].element_size() + ws["all_ids"].numel() // self.world * 8
+                    break
+        return b

@@ -286,6 +286,9 @@ class SegmentedStep(_StepBase):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.segments = cap.segments
+        self._sparse_args = None     # row-sparse word-table exchange: the static row / id buffers the captured backward fills
+        if getattr(reducer, "sparse_word", None) is not None:
+            self._sparse_args, reducer._sparse = reducer._sparse, None
         self._grad_slots = [s for s in self.arena.order if s.live]
         model.zero_grad()                       # a capture executes nothing: the gradients it "wrote" do not exist
 
@@ -300,6 +303,9 @@ class SegmentedStep(_StepBase):
             graph.replay()
             for bi in buckets:
                 self.reducer.launch_now(bi)
+        if self._sparse_args is not None:
+            self.reducer.set_sparse_rows(*self._sparse_args)
+            self.reducer.exchange_sparse()
         self.reducer.join()
         self.arena.attach_grads(self._grad_slots)
         return self.loss
@@ -355,6 +361,9 @@ class FlaggedStep(_StepBase):
             raise RuntimeError("FlaggedStep needs the nccl (= RCCL) backend on a ROCm device")
         if accumulate < 1:
             raise ValueError("accumulate must be >= 1")
+        if accumulate > 1 and getattr(reducer, "sparse_word", None) is not None:
+            raise ValueError("FlaggedStep(accumulate > 1) cannot be combined with GradReducer(sparse_embeddings=True): the token "
+                             "rows of the micro-batches that do not exchange would stay local")
         self._setup(model, step_fn, inputs)
         self.reducer = reducer
         self.accumulate = int(accumulate)
@@ -411,6 +420,13 @@ class FlaggedStep(_StepBase):
                 raise RuntimeError("FlaggedStep: buckets flagged during capture %s != all %d buckets"
                                    % (cap.order, len(reducer.buckets)))
             self._order[key] = cap.order
+            # (the captured embedding backward registered its static row / id buffers: the same ones every replay fills)
+            self._sparse_args = getattr(self, "_sparse_args", {})
+            if getattr(reducer, "sparse_word", None) is not None:
+                if reducer._sparse is None:
+                    raise RuntimeError("FlaggedStep: the captured step did not leave token rows for the row-sparse exchange")
+                self._sparse_args[key] = reducer._sparse
+                reducer._sparse = None
         else:
             # a micro-batch that is not the last of its cycle: the same step with the reducer detached (no wire copies, no
             # flags; the step_fn's reducer.finish() is made a no-op for the duration of the capture)
@@ -452,6 +468,16 @@ class FlaggedStep(_StepBase):
                 late = idx in self._test_late
                 r.launch_now(idx, wait=(self._never_ptr if late else self._flag_ptr[idx], self._tag,
                                         64 if late else self._polls, self._bad_ptr[idx]))
+            if getattr(r, "sparse_word", None) is not None:
+                # the row-sparse word-table exchange: on the communication stream BEHIND the last bucket's flag wait (the
+                # embedding backward, which leaves the rows, is what makes that bucket final)
+                r.set_sparse_rows(*self._sparse_args[key])
+                with torch.cuda.stream(r.comm_stream):
+                    r._exchange_on_current = True
+                    try:
+                        r.exchange_sparse()
+                    finally:
+                        r._exchange_on_current = False
             r.join()
             # after the join nothing of this step writes gradients any more: a bucket whose wait gave up gets its NaN here
             # for good (one launch; the bad words carry the step number, so nothing is ever reset)

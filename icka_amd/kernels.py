@@ -347,6 +347,34 @@ def embed_bwd(dy, ids, token_type, xhat, rstd, gamma, dword, dpos, dtype_, dgamm
           "icka_embed_bwd")
 
 
+def embed_bwd_rows(dy, ids, token_type, xhat, rstd, gamma, dtok, dpos, dtype_, dgamma, dbeta, partials, *, vocab,
+                   padding_idx=0, p_drop=0.0, seed=0, accumulate=True):
+    """embed_bwd with the word-table gradient left as per-token rows ``dtok`` f32 [B*S, H] (row-sparse data-parallel exchange)."""
+    lib = _lib.load()
+    B, S = ids.shape
+    H = dtok.shape[1]
+    if dtok.dtype != F32 or tuple(dtok.shape) != (B * S, H) or not dtok.is_contiguous():
+        raise ValueError("dtok must be contiguous f32 [B*S, H]")
+    check(lib.icka_embed_bwd_rows(dy.data_ptr(), ids.data_ptr(), _ptr(token_type), xhat.data_ptr(), rstd.data_ptr(),
+                                  gamma.data_ptr(), dtok.data_ptr(), dpos.data_ptr(), dtype_.data_ptr(), dgamma.data_ptr(),
+                                  dbeta.data_ptr(), partials.data_ptr(), B, S, H, int(vocab), dtype_.shape[0], padding_idx, p_drop,
+                                  seed, int(accumulate), _stream()), "icka_embed_bwd_rows")
+
+
+def embed_scatter_rows(rows, ids, dword, *, padding_idx=0, scale=1.0):
+    """dword[ids[t]] += scale * rows[t]  (rows f32 or bf16 [T, H] contiguous, ids int64 [T], dword f32 [vocab, H])."""
+    _dev(rows, "rows"); _dev(ids, "ids"); _dev(dword, "dword")
+    if rows.dtype not in (F32, BF16) or rows.dim() != 2 or not rows.is_contiguous():
+        raise ValueError("rows must be contiguous f32 / bf16 [T, H]")
+    if ids.dtype != torch.int64 or ids.numel() != rows.shape[0] or not ids.is_contiguous():
+        raise ValueError("ids must be contiguous int64 with one entry per row")
+    if dword.dtype != F32 or dword.dim() != 2 or dword.shape[1] != rows.shape[1] or not dword.is_contiguous():
+        raise ValueError("dword must be contiguous f32 [vocab, H]")
+    check(_lib.load().icka_embed_scatter_rows(rows.data_ptr(), int(rows.dtype == BF16), ids.data_ptr(), dword.data_ptr(),
+                                              rows.shape[0], rows.shape[1], dword.shape[0], padding_idx, float(scale), _stream()),
+          "icka_embed_scatter_rows")
+
+
 def embed_prompt_fwd(ids, src, prompt, word, pos, typ, gamma, beta, y, *, y_f32=None, xhat=None, rstd=None,
                      pos_offset=0, eps=1e-5, p_drop=0.0, seed=0):
     """Prompt-spliced embeddings + LayerNorm + dropout (icka_hip.h: icka_embed_prompt_fwd).  ids int64 [B,S_in],

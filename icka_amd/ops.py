@@ -323,9 +323,24 @@ class EmbeddingsFn(torch.autograd.Function):
         dy = _c(dy)
         ws = A.workspace("ln", K._lib.load().icka_ln_bwd_workspace_floats(d.H))
         tables = (mod.word_embeddings.weight, mod.position_embeddings.weight)
+        small = (mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
+        red = A.reducer
+        if red is not None and getattr(red, "sparse_word", None) is A.slot(tables[0]):
+            # row-sparse data-parallel exchange of the word-embedding gradient (dp.GradReducer(sparse_embeddings=True)): the
+            # kernel leaves the per-token rows, the reducer all-gathers them with the ids and scatters every rank's rows
+            beta_w = A.grad_beta(tables[0])
+            if A.grad_beta(tables[1]) == 0.0:
+                K.zero_(A.g(tables[1]).view(-1))
+            acc = A.grad_beta(small) > 0
+            dtok = A.workspace("dtok", ids.numel() * d.H).view(ids.numel(), d.H)
+            K.embed_bwd_rows(dy, ids, tt, xhat, rstd, mod.LayerNorm.weight, dtok, A.g(tables[1]), A.g(small[0]), A.g(small[1]),
+                             A.g(small[2]), ws, vocab=tables[0].shape[0], padding_idx=0, p_drop=d.p_hidden, seed=ctx.seed,
+                             accumulate=acc)
+            red.set_sparse_rows(dtok, ids.reshape(-1), accumulate=beta_w > 0)
+            A.flush_final()
+            return None, None, None, None, None, None
         if A.grad_beta(tables) == 0.0:   # atomically accumulated tables: fresh gradient starts from zero
             K.zero_(A.g_cat(tables).view(-1))
-        small = (mod.token_type_embeddings.weight, mod.LayerNorm.weight, mod.LayerNorm.bias)
         acc = A.grad_beta(small) > 0
         K.embed_bwd(dy, ids, tt, xhat, rstd, mod.LayerNorm.weight, A.g(tables[0]), A.g(tables[1]), A.g(small[0]),
                     A.g(small[1]), A.g(small[2]), ws, padding_idx=0, p_drop=d.p_hidden, seed=ctx.seed, accumulate=acc)

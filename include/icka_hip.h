@@ -30,7 +30,8 @@ extern "C" {
  *    NaN-poisons the recurrence and raises a host-visible error word; icka_gemm_desc.C3 may accompany an f32 main output
  *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h, icka_optim_* (additive).
  * 5: round 4 -- icka_dp_flag_wait's third argument is the bucket's BAD WORD (it no longer writes the NaN itself);
- *    icka_dp_poison_if, icka_dp_poison_final, icka_copy_many; icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN. */
+ *    icka_dp_poison_if, icka_dp_poison_final, icka_copy_many, icka_embed_bwd_rows, icka_embed_scatter_rows,
+ *    icka_ln_set_rows_per_wave, icka_gemm_set_square_tiles, icka_gemm_set_persistent (additive); icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN. */
 #define ICKA_ABI_VERSION 5
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -203,6 +204,17 @@ int icka_embed_bwd(const void* dy, const int64_t* ids, const int64_t* token_type
                    const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma,
                    float* dbeta, float* partials, int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type,
                    int32_t padding_idx, float p_drop, uint64_t seed, int32_t accumulate, void* stream);
+/* Row-sparse form for the data-parallel exchange of the word-embedding gradient (icka_amd/dp.py: GradReducer(sparse_embeddings=
+ * True); reference: apex DDP all-reduces the dense [vocab, H] gradient, My_cross_attention.py:768-776): as icka_embed_bwd, but
+ * the word-table gradient is left as per-token rows dtok f32 [B*S, H] (zero rows for padding_idx).  After an all-gather of every
+ * rank's rows and ids, icka_embed_scatter_rows adds scale * rows[t] into dword[ids[t]] (f32 atomics; rows f32 or bf16; the
+ * padding id and ids outside [0, vocab) are skipped; the caller zeroes dword for a fresh gradient). */
+int icka_embed_bwd_rows(const void* dy, const int64_t* ids, const int64_t* token_type, const void* xhat, const float* rstd,
+                        const float* gamma, float* dtok, float* dpos, float* dtype, float* dgamma, float* dbeta, float* partials,
+                        int32_t B, int32_t S, int32_t H, int32_t vocab, int32_t n_type, int32_t padding_idx, float p_drop,
+                        uint64_t seed, int32_t accumulate, void* stream);
+int icka_embed_scatter_rows(const void* rows, int32_t rows_are_bf16, const int64_t* ids, float* dword, int64_t T, int32_t H,
+                            int32_t vocab, int32_t padding_idx, float scale, void* stream);
 /* Embeddings of the prompt-accepting encoder stage that ends the current reference model
  * (Cross_Modal_Interaction_Module.py:1010-1012: last_encoder(input_ids=..., prompt_embeddings=prefix_emb, ...); its
  * package `local_transformers` is absent from the reference tree, so the splice rule is this build's definition, taken

@@ -14,6 +14,7 @@ import torch.distributed as dist
 def main():
     port, out, comm = sys.argv[1], sys.argv[2], sys.argv[3]
     kind = sys.argv[4] if len(sys.argv) > 4 else "segmented"
+    sparse = len(sys.argv) > 5 and sys.argv[5] == "sparse"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -23,12 +24,13 @@ def main():
     from icka_amd.dp import GradReducer
     from icka_amd.graph import FlaggedStep, SegmentedStep
     from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
-    cfg = BertConfig(512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    vocab = 2048 if sparse else 512      # (row-sparse exchange: fewer rows per rank than vocab / 4, else it falls back to dense)
+    cfg = BertConfig(vocab, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                      max_position_embeddings=64)
     model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=36)
     synth.fill_module_(model)
     model = model.cuda().eval()
-    b = {k: v.cuda() for k, v in synth.synthetic_batch(4, 32, 36, vocab_size=512, seed=5).items()}
+    b = {k: v.cuda() for k, v in synth.synthetic_batch(4, 32, 36, vocab_size=vocab, seed=5).items()}
 
     def fwd_bwd():
         loss = model(b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
@@ -41,7 +43,7 @@ def main():
     torch.cuda.synchronize()
     ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     arena = model._icka_arena
-    red = GradReducer(arena, bucket_mb=0.25, comm_dtype=comm)
+    red = GradReducer(arena, bucket_mb=0.25, comm_dtype=comm, sparse_embeddings=sparse)
     arena.reducer = red
 
     def step():
@@ -68,7 +70,8 @@ def main():
                "step_word": int(ss.sync[0].item()), "flags": ss.sync[ss.FLAG0:ss.FLAG0 + len(red.buckets)].tolist()}
     res.update({"worst": worst, "buckets": len(red.buckets), "loss": loss.item(), "ref_loss": ref_loss,
                 "cast_elements": red.cast_elements() if red.gwire is not None else None,
-                "total_elements": sum(e - s for s, e in red.buckets), "wire_ranges": len(red._wire_ranges)})
+                "total_elements": sum(e - s for s, e in red.buckets), "wire_ranges": len(red._wire_ranges),
+                "sparse_stats": dict(red.sparse_stats)})
     torch.save(res, out)
     ss.close()
     dist.destroy_process_group()

@@ -15,6 +15,7 @@ import torch.distributed as dist
 def main():
     rank, world, port, out, precision = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     comm = sys.argv[6] if len(sys.argv) > 6 else "f32"
+    sparse = len(sys.argv) > 7 and sys.argv[7] == "sparse"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,7 +24,8 @@ def main():
     from icka_amd.config import BertConfig
     from icka_amd.dp import GradReducer
     from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
-    cfg = BertConfig(512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    vocab = 2048 if sparse else 512      # (row-sparse exchange: fewer rows per rank than vocab / 4, else it falls back to dense)
+    cfg = BertConfig(vocab, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                      max_position_embeddings=64)
     model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=36)
     synth.fill_module_(model)
@@ -32,7 +34,7 @@ def main():
             for p in model.parameters():
                 p.add_(0.5)
     model = icka_amd.set_precision(model.cuda().eval(), precision)
-    full = {k: v.cuda() for k, v in synth.synthetic_batch(8, 32, 36, vocab_size=512, seed=5, ragged=False).items()}
+    full = {k: v.cuda() for k, v in synth.synthetic_batch(8, 32, 36, vocab_size=vocab, seed=5, ragged=False).items()}
     half = {k: v[rank * 4:(rank + 1) * 4].contiguous() for k, v in full.items()}
 
     def step(b):
@@ -44,7 +46,7 @@ def main():
 
     step(half)                                          # builds the arena
     arena = model._icka_arena
-    red = GradReducer(arena, bucket_mb=0.25, comm_dtype=comm)
+    red = GradReducer(arena, bucket_mb=0.25, comm_dtype=comm, sparse_embeddings=sparse)
     red.broadcast_parameters(0)
     arena.reducer = red
     early = []
@@ -70,7 +72,8 @@ def main():
     total = sum(e - s for s, e in red.buckets)
     torch.save({"worst": worst, "key": wkey, "buckets": len(red.buckets), "overlapped": overlapped,
                 "cast_elements": red.cast_elements() if red.gwire is not None else None, "total_elements": total,
-                "wire_ranges": len(red._wire_ranges)}, out)
+                "wire_ranges": len(red._wire_ranges), "sparse_stats": dict(red.sparse_stats),
+                "sparse_word": None if red.sparse_word is None else red.sparse_word.name}, out)
     dist.destroy_process_group()
 
 

@@ -251,3 +251,80 @@ def test_bf16_ring_sum_over_8_ranks_is_bounded_against_the_fp32_mean():
     rel_true = ((out - torch.stack(grads).mean(0)).norm() / torch.stack(grads).mean(0).norm()).item()
     assert rel_true < 2.0 ** -7, rel_true
     print("\n[bf16 ring sum, N = 8] rel-L2 vs fp32 mean of the wire inputs %.2e, vs the fp32 gradients %.2e" % (rel, rel_true))
+
+
+def _sparse_worker(rank, world, port, tmp):
+    """Row-sparse exchange of the word-embedding gradient (GradReducer(sparse_embeddings=True)) against the dense all-reduce of
+    the same gradient: every rank holds its own token rows + ids; after the exchange the table's gradient slot must equal
+    (1 / world) x the scatter of ALL ranks' rows -- which is what the dense path averages."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from icka_amd.dp import GradReducer
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, vocab):
+            super().__init__()
+            self.word = torch.nn.Embedding(vocab, 16, padding_idx=0)
+            self.pos = torch.nn.Embedding(8, 16)
+            self.lin = torch.nn.Linear(16, 16)
+
+    out = {}
+    for vocab, T, expect in ((96, 12, "sparse"), (32, 12, "dense_fallback")):      # 12 rows < 96 / 4; 12 rows >= 32 / 4
+        torch.manual_seed(0)
+        model = Tiny(vocab)
+        arena = ParamArena(model)
+        red = GradReducer(arena, bucket_mb=1e-4, sparse_embeddings=True)
+        assert red.sparse_word is arena.slot(model.word.weight)
+        assert all(not (lo <= red.sparse_word.off < hi) for lo, hi in red.buckets)       # the table left the dense buckets
+        arena.reducer = red
+        g = torch.Generator().manual_seed(100 + rank)
+        ids = torch.randint(0, vocab, (T,), generator=g)
+        ids[0] = 0                                                                        # a padding token: contributes nothing
+        rows = torch.randn(T, 16, generator=g)
+        rows[ids == 0] = 0.0
+        # reference: dense mean over ranks of the local scatter
+        loc = torch.zeros(vocab, 16).index_add_(0, ids, rows)
+        ref = loc.clone()
+        dist.all_reduce(ref)
+        ref /= world
+        for step in range(2):                                                             # calibration step, then a normal one
+            for s in reversed(arena.order):
+                if s is red.sparse_word:
+                    arena.grad_beta(s.param)
+                    red.set_sparse_rows(rows, ids)
+                else:
+                    arena.grad_beta(s.param)
+                    arena.g(s.param).fill_(float(rank + 1))
+                arena.flush_final()
+            red.finish()
+        got = arena.g(model.word.weight)
+        err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        other = arena.g(model.lin.weight)
+        out[expect] = {"err": err, "stats": dict(red.sparse_stats), "row0": got[0].abs().max().item(),
+                       "dense_ok": abs(other.mean().item() - (world + 1) / 2.0) < 1e-6}
+        # accumulation: a second exchange onto the gradient the caller still holds adds the same mean once more
+        arena.grad_beta(model.word.weight)
+        red.set_sparse_rows(rows, ids, accumulate=True)
+        red.exchange_sparse()
+        out[expect]["acc_err"] = (arena.g(model.word.weight) - 2 * ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        arena.reducer = None
+    torch.save(out, os.path.join(tmp, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_row_sparse_word_embedding_exchange_equals_the_dense_mean(tmp_path, world):
+    """all-gather of the ranks' token rows + ids and a local scatter-add == the dense all-reduce mean (f32,
+    <= 1e-6), at world 2 and 8; the dense fallback when a rank brings at least vocab / 4 rows; the padding row stays zero; the
+    other gradients keep going through the dense buckets."""
+    port = _free_port()
+    mp.spawn(_sparse_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), "s%d.pt" % r))
+        for kind in ("sparse", "dense_fallback"):
+            assert res[kind]["err"] < 1e-6 and res[kind]["acc_err"] < 1e-6, res
+            assert res[kind]["row0"] == 0.0 and res[kind]["dense_ok"], res
+        assert res["sparse"]["stats"]["sparse"] >= 2 and res["sparse"]["stats"]["dense_fallback"] == 0, res
+        assert res["dense_fallback"]["stats"]["dense_fallback"] >= 2, res

@@ -138,3 +138,43 @@ def test_two_gpus_rccl_flagged_step(tmp_path, comm, bar):
         assert res["worst"] < bar and res["error_word"] == 0, res
         if comm == "bf16":
             assert res["wire_only"] > 0, res
+
+
+@pytest.mark.parametrize("comm,bar", [("f32", 1e-5), ("bf16", 1.2e-2)])
+def test_two_ranks_with_the_row_sparse_word_embedding_exchange(tmp_path, comm, bar):
+    """GradReducer(sparse_embeddings=True) with the REAL embedding backward (icka_embed_bwd_rows leaves the token rows, the
+    reducer all-gathers them and icka_embed_scatter_rows adds every rank's rows): 2 ranks x half batch == 1 rank x full batch,
+    word-embedding gradient included (it is among the compared tensors), f32 and bf16 rows on the wire."""
+    port = str(_free_port())
+    outs = [str(tmp_path / ("r%d.pt" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), "2", port, outs[r], "bf16", comm, "sparse"])
+             for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r in range(2):
+        res = torch.load(outs[r])
+        print("\n[dp 2-rank, row-sparse word table, %s rows, rank %d] worst gradient rel-L2 vs single-rank full batch %.3e at %s; %s"
+              % (comm, r, res["worst"], res["key"], res["sparse_stats"]))
+        assert res["sparse_word"] == "bert.embeddings.word_embeddings.weight", res
+        assert res["sparse_stats"]["sparse"] >= 2 and res["worst"] < bar, res
+
+
+@pytest.mark.parametrize("kind", ["flagged", "segmented"])
+def test_graphed_step_with_the_row_sparse_exchange_matches_eager(tmp_path, kind):
+    """The row-sparse exchange behind a captured step (world 1 over RCCL): the captured embedding backward fills static row / id
+    buffers, the replay all-gathers and scatters them on the communication stream behind the last bucket's flag."""
+    out = str(tmp_path / "seg.pt")
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_segment_worker.py"), str(_free_port()), out, "f32", kind, "sparse"])
+    try:
+        assert p.wait(timeout=300) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+    res = torch.load(out)
+    print("\n[%s step, row-sparse word table] worst gradient rel-L2 vs eager %.3e; %s" % (kind, res["worst"], res["sparse_stats"]))
+    assert res["worst"] < 2e-6 and res["sparse_stats"]["sparse"] >= 3, res

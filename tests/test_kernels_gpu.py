@@ -766,3 +766,46 @@ def test_linear_small_m(M, N, Kd, act):
         ref = torch.tanh(ref)
     assert rel_err(y, ref) < 1e-2
 
+
+
+def test_embed_bwd_rows_plus_scatter_equals_embed_bwd():
+    """Row-sparse form of the embedding backward: per-token rows (zero for the padding id) + icka_embed_scatter_rows (f32 and
+    bf16 rows, a scale, rows of several 'ranks' concatenated) == the dense scatter of icka_embed_bwd; every other output equal."""
+    k = _k()
+    B, S, H, V = 8, 32, 128, 200
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (B, S), generator=g).cuda()
+    ids[:, -5:] = 0
+    tt = torch.randint(0, 2, (B, S), generator=g).cuda()
+    dy = rnd(B * S, H, seed=5)
+    xhat = rnd(B * S, H, seed=6)
+    rstd = (torch.rand(B * S, generator=g) + 0.5).cuda()
+    gamma = torch.randn(H, generator=g).cuda()
+    lib = k._lib.load()
+    ws = torch.empty(lib.icka_ln_bwd_workspace_floats(H), dtype=F32, device="cuda")
+    outs = []
+    for rows in (False, True):
+        dword = torch.zeros(V, H, device="cuda")
+        dpos, dtyp = torch.zeros(S, H, device="cuda"), torch.zeros(2, H, device="cuda")
+        dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+        if rows:
+            dtok = torch.full((B * S, H), float("nan"), device="cuda")
+            k.embed_bwd_rows(dy, ids, tt, xhat, rstd, gamma, dtok, dpos, dtyp, dg, db, ws, vocab=V, p_drop=0.1, seed=9, accumulate=False)
+            assert torch.isfinite(dtok).all() and dtok[(ids.view(-1) == 0)].abs().max().item() == 0.0
+            k.embed_scatter_rows(dtok, ids.view(-1).contiguous(), dword, scale=1.0)
+        else:
+            k.embed_bwd(dy, ids, tt, xhat, rstd, gamma, dword, dpos, dtyp, dg, db, ws, p_drop=0.1, seed=9, accumulate=False)
+        outs.append((dword, dpos, dtyp, dg, db))
+    torch.cuda.synchronize()
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    assert outs[0][0][0].abs().max().item() == 0.0 and outs[1][0][0].abs().max().item() == 0.0
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b)
+    # two "ranks" concatenated, bf16 rows, scale 1/2
+    two = torch.cat([dtok, 3.0 * dtok]).to(BF16)
+    ids2 = torch.cat([ids.view(-1), ids.view(-1)]).contiguous()
+    acc = torch.zeros(V, H, device="cuda")
+    k.embed_scatter_rows(two, ids2, acc, scale=0.5)
+    ref = torch.zeros(V, H, device="cuda").index_add_(0, ids2, two.float() * 0.5)
+    ref[0] = 0.0
+    assert torch.allclose(acc, ref, rtol=1e-4, atol=1e-5)
