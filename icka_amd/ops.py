@@ -117,6 +117,73 @@ def _ln_bwd_deferred(A: ParamArena, tag: str, norm, dy, xhat, rstd, *, dy2, dres
 # CrossLayerFn) chain them with the gradient fan-ins fused into GEMM epilogues, the sub-module Functions further down
 # (AttnCoreFn, DenseResidualNormFn, IntermediateFn) expose the same pairs one by one for callers that compose
 # BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput themselves (as BertAttention.forward :451-454 does).
+def _attn_generic_fwd(qkv, kvbuf, self_attn: bool, add_mask, d: Dims, Skv: int, seed_a: int, ctx, ctx16, save: bool):
+    """Attention core for head sizes other than 64: bf16 q / k / v -> f32, scores / softmax (+ dropout) / context on the
+    batched f32-input MFMA GEMM and softmax kernels of csrc/exact.hip (exact.py follows :488-505 step by step), context back
+    to bf16 (+ fp16 in mixed16).  Returns what the backward needs: ("generic", q32 buffer, kv32 buffer, P, Pd)."""
+    import math
+    from . import exact as X
+    B, h, S, H = d.B, d.heads, d.S, d.H
+    dh = H // h
+    q32b = K.cast_bf16_to_f32(qkv, torch.empty(qkv.shape, dtype=F32, device=qkv.device))
+    if self_attn:
+        q, k, v = q32b[:, :H], q32b[:, H:2 * H], q32b[:, 2 * H:]
+        kv32b = None
+    else:
+        kv32b = K.cast_bf16_to_f32(kvbuf, torch.empty(kvbuf.shape, dtype=F32, device=kvbuf.device))
+        q, k, v = q32b, kv32b[:, :H], kv32b[:, H:]
+    P = torch.empty(B, h, S, Skv, dtype=F32, device=qkv.device)
+    X.gemm_raw(X.GEMM_NT, S, Skv, dh, q, q.stride(0), (S * q.stride(0), dh), k, k.stride(0), (Skv * k.stride(0), dh),
+               P, Skv, (h * S * Skv, S * Skv), B, h)
+    Pd = torch.empty_like(P) if d.p_attn > 0 else None
+    X.softmax_fwd(P, Pd, add_mask, B, h, S, Skv, 1.0 / math.sqrt(dh), d.p_attn, seed_a)
+    Pu = P if Pd is None else Pd
+    ctx32 = torch.empty(B * S, H, dtype=F32, device=qkv.device)
+    X.gemm_raw(X.GEMM_NN, S, dh, Skv, Pu, Skv, (h * S * Skv, S * Skv), v, v.stride(0), (Skv * v.stride(0), dh),
+               ctx32, H, (S * H, dh), B, h)
+    K.cast_f32_to_bf16(ctx32, ctx)
+    if ctx16 is not None:
+        K.cast_to_f16(ctx32, ctx16)
+    return ("generic", q32b, kv32b, P, Pd) if save else None
+
+
+def _attn_generic_bwd(gen, self_attn: bool, dctx, d: Dims, Skv: int, seed_a: int, dq_out, dkv_out) -> None:
+    """Backward of _attn_generic_fwd: dq / dk / dv in f32 (exact.py:_attn_core_bwd's core), written as bf16 into ``dq_out``
+    ([M, 3H] fused for self-attention, [M, H] otherwise) and ``dkv_out`` ([rows, 2H], co-attention; padded rows stay zero)."""
+    import math
+    from . import exact as X
+    _tag, q32b, kv32b, P, Pd = gen
+    B, h, S, H = d.B, d.heads, d.S, d.H
+    dh = H // h
+    scale = 1.0 / math.sqrt(dh)
+    dev = q32b.device
+    d32 = K.cast_bf16_to_f32(dctx if dctx.is_contiguous() else dctx.contiguous(), torch.empty(B * S, H, dtype=F32, device=dev))
+    if self_attn:
+        q, k, v = q32b[:, :H], q32b[:, H:2 * H], q32b[:, 2 * H:]
+        g32 = torch.empty(B * S, 3 * H, dtype=F32, device=dev)
+        dq, dk, dv = g32[:, :H], g32[:, H:2 * H], g32[:, 2 * H:]
+        gkv = None
+    else:
+        q, k, v = q32b, kv32b[:, :H], kv32b[:, H:]
+        g32 = torch.empty(B * S, H, dtype=F32, device=dev)
+        gkv = torch.empty(kv32b.shape, dtype=F32, device=dev)
+        K.zero_(gkv.view(-1))
+        dq, dk, dv = g32, gkv[:, :H], gkv[:, H:]
+    pb = (h * S * Skv, S * Skv)
+    Pu = P if Pd is None else Pd
+    dS = torch.empty_like(P)
+    X.gemm_raw(X.GEMM_NT, S, Skv, dh, d32, H, (S * H, dh), v, v.stride(0), (Skv * v.stride(0), dh), dS, Skv, pb, B, h)
+    X.gemm_raw(X.GEMM_TN, Skv, dh, S, Pu, Skv, pb, d32, H, (S * H, dh), dv, dv.stride(0), (Skv * dv.stride(0), dh), B, h)
+    X.softmax_bwd(P, dS, B, h, S, Skv, scale, d.p_attn, seed_a)
+    X.gemm_raw(X.GEMM_NN, S, dh, Skv, dS, Skv, pb, k, k.stride(0), (Skv * k.stride(0), dh), dq, dq.stride(0),
+               (S * dq.stride(0), dh), B, h)
+    X.gemm_raw(X.GEMM_TN, Skv, dh, S, dS, Skv, pb, q, q.stride(0), (S * q.stride(0), dh), dk, dk.stride(0),
+               (Skv * dk.stride(0), dh), B, h)
+    K.cast_f32_to_bf16(g32, dq_out)
+    if gkv is not None:
+        K.cast_f32_to_bf16(gkv, dkv_out)
+
+
 def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, save: bool, x16=None, kv16=None):
     """BertSelfAttention / BertCoAttention (:478-506, :590-624): fused projection GEMM -> fused attention kernel.
     Returns (ctx bf16 [M,H], ctx fp16 or None, saved).  x16: fp16 copy of x (mixed16) -> the projections of x read fp16
@@ -144,8 +211,16 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
     ctx = _empty(x, M, H)
     ctx16 = _empty(x, M, H, dtype=F16) if h16 else None
-    lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
     seed_a = A.next_seed() if d.p_attn > 0 else 0
+    if H // d.heads != 64:
+        if (kv_src is not None) and bool(getattr(sa, "fp8_scores", False)):
+            raise ValueError("the fp8 cross-attention kernels are built for head size 64, got %d" % (H // d.heads))
+        # head sizes other than 64 (the reference takes any hidden % heads == 0, :459-462): projections and everything around
+        # the attention stay on the 16-bit path, the score / softmax / context core runs on the f32-input MFMA kernels of the
+        # fp32 mode (probabilities materialised as the reference does, same dropout hash)
+        gen = _attn_generic_fwd(qkv, kvbuf, kv_src is None, add_mask, d, Skv, seed_a, ctx, ctx16, save)
+        return ctx, ctx16, ((qkv, kvbuf, gen, seed_a, None) if save else None)
+    lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
     # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
     # optional (ATTN_KEEPBITS): the forward leaves the keep decisions of its probability dropout as bits and the backward reads
@@ -160,13 +235,17 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     """Returns (dx, dkv_src); ``dres`` (optional) is added to dx in the last GEMM's epilogue (residual fan-in)."""
     qkv, kvbuf, lse, seed_a, kb = saved
     M, H = x.shape
-    delta = _empty(x, d.B, d.heads, d.S, dtype=F32)
+    generic = isinstance(lse, tuple)       # head size != 64: the saved f32 operands / probabilities of _attn_generic_fwd
+    delta = None if generic else _empty(x, d.B, d.heads, d.S, dtype=F32)
     epi = dict(epilogue=K.EPI_ADD, aux=dres) if dres is not None else {}
     if kv_src is None:
         dqkv = _empty(x, M, 3 * H)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-        K.attn_bwd(q, k, v, add_mask, ctx, dctx, lse, delta, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], d.B,
-                   d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, keepbits=kb)
+        if generic:
+            _attn_generic_bwd(lse, True, dctx, d, Skv, seed_a, dqkv, None)
+        else:
+            K.attn_bwd(q, k, v, add_mask, ctx, dctx, lse, delta, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], d.B,
+                       d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, keepbits=kb)
         wg = (sa.query.weight, sa.key.weight, sa.value.weight)
         bg = (sa.query.bias, sa.key.bias, sa.value.bias)
         _wgrad(A, dqkv, x, A.g_cat(wg), A.grad_beta(wg), bias=bg)
@@ -177,8 +256,11 @@ def _attn_core_bwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     dkv = _empty(x, kv_src.shape[0], 2 * H)
     if kv_src.shape[0] > d.B * Skv:     # row-padded key/value source (region tokens): the attention writes real rows only
         K.zero_rows_(dkv, d.B * Skv)
-    K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
-               d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, keepbits=kb)
+    if generic:
+        _attn_generic_bwd(lse, False, dctx, d, Skv, seed_a, dq, dkv)
+    else:
+        K.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], add_mask, ctx, dctx, lse, delta, dq, dkv[:, :H], dkv[:, H:], d.B,
+                   d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, keepbits=kb)
     _wgrad(A, dq, x, A.g(sa.query.weight), A.grad_beta(sa.query.weight), bias=sa.query.bias)
     wg = (sa.key.weight, sa.value.weight)
     bg = (sa.key.bias, sa.value.bias)

@@ -221,8 +221,9 @@ def test_fp32_mode_other_head_size():
     ref_layers, ref_pooled = O.bert_model(P, "bert", b["input_ids"], b["segment_ids"], b["input_mask"], ocfg)
     assert (layers[-1].cpu() - ref_layers[-1]).abs().max().item() < FP32_TOL
     assert (pooled.cpu() - ref_pooled).abs().max().item() < FP32_TOL
-    with pytest.raises(ValueError):
-        icka_amd.set_precision(m, "bf16")(b["input_ids"].cuda(), b["segment_ids"].cuda(), b["input_mask"].cuda())
+    # since round 4 the 16-bit modes take this geometry too (attention core on the f32-input kernels, ops._attn_generic_fwd)
+    l16, _ = icka_amd.set_precision(m, "bf16")(b["input_ids"].cuda(), b["segment_ids"].cuda(), b["input_mask"].cuda())
+    assert (l16[-1].float().cpu() - ref_layers[-1]).abs().max().item() < 3e-2
 
 
 # ----------------------------------------------------------------------------------------- SURVEY.md section 8(f) rows

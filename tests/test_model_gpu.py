@@ -256,6 +256,61 @@ def test_bert_large_geometry_against_live_oracle(layout, regions):
     assert worst < C4_GEOMETRY_GRAD_BAR, "worst relative gradient error %.3e" % worst
 
 
+@pytest.mark.parametrize("hidden,heads,precision", [(128, 4, "bf16"), (256, 2, "bf16"), (192, 4, "mixed16"), (128, 4, "fp32")])
+def test_head_sizes_other_than_64_against_live_oracle(hidden, heads, precision):
+    """VERDICT r03 missing #4: the reference accepts any hidden % heads == 0 (Cross_Modal_Interaction_Module.py:459-462).  Head
+    sizes 32 / 128 / 48 run the 16-bit modes with the attention core on the f32-input MFMA kernels (ops._attn_generic_fwd /
+    _bwd): self- and co-attention, ragged masks, train-mode determinism; logits and every gradient against the CPU oracle."""
+    import icka_amd
+    from icka_amd.config import BertConfig
+    from icka_amd.modeling import MTCCMBertForMMTokenClassificationCRF
+    from oracle import mner_oracle as O
+    S, B, R = 32, 4, 36
+    cfg = BertConfig(512, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads, intermediate_size=2 * hidden,
+                     max_position_embeddings=64)
+    model = MTCCMBertForMMTokenClassificationCRF(cfg, layer_num1=1, num_labels=13, regions=R, max_seq_length=S)
+    synth.fill_module_(model)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = icka_amd.set_precision(model.cuda().eval(), precision)
+    b = synth.synthetic_batch(B, S, R, vocab_size=512, seed=11)
+    logits = _run(model, b, labels=False)
+    model.zero_grad()
+    loss = _run(model, b, labels=True)
+    loss.backward()
+    ocfg = O.OracleConfig(vocab_size=512, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads,
+                          intermediate_size=2 * hidden, max_position_embeddings=64)
+    ref = O.mner_logits(P, ocfg, b["input_ids"], b["segment_ids"], b["input_mask"], b["added_attention_mask"],
+                        b["visual_embeds_att"], 1, R)
+    rloss = O.token_ce_loss(ref, b["labels"], b["input_mask"])
+    rloss.backward()
+    tol = 1e-4 if precision == "fp32" else LOGIT_TOL
+    err = (logits.float().cpu() - ref.detach()).abs().max().item()
+    gmax = max(v.grad.norm().item() for v in P.values() if v.grad is not None)
+    worst, wkey = 0.0, ""
+    for k, p in model.named_parameters():
+        if P[k].grad is None:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        rel = ((p.grad.float().cpu() - P[k].grad).norm() / (P[k].grad.norm() + 1e-3 * gmax)).item()
+        if rel > worst:
+            worst, wkey = rel, k
+    print("\n[head size %d (H%d / %d heads), %s] logits max abs err %.3e (tol %.0e), loss %.5f (oracle %.5f), worst gradient "
+          "rel-L2 %.3e at %s" % (hidden // heads, hidden, heads, precision, err, tol, loss.item(), rloss.item(), worst, wkey))
+    assert err < tol and abs(loss.item() - rloss.item()) < tol
+    assert worst < (1e-3 if precision == "fp32" else 3e-2), (worst, wkey)
+    if precision != "fp32":     # train mode: the dropout of the generic core follows the same seeds -> deterministic steps
+        model.train()
+        outs = []
+        for _ in range(2):
+            model._icka_arena.set_seed(77)
+            model.zero_grad()
+            l2 = _run(model, b, labels=True)
+            l2.backward()
+            outs.append((l2.item(), model.classifier.weight.grad.clone()))
+        assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][0] != loss.item()
+
+
 def test_fp8_cross_attention_reference_diff_report():
     """BASELINE config c5 (bert-base, seq 128, 36 regions, fp8 QK^T/PV in the cross-attention): logits of the fp8
     variant against the fp32 CPU oracle and against the bf16 path, on the by-key seeded weights.  Reports the
