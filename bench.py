@@ -329,6 +329,9 @@ def main():
                          "stays one forward+backward of one batch per GPU; with k > 1 the captured step accumulates and, "
                          "data-parallel, only every k-th step exchanges (graph.FlaggedStep(accumulate=k))")
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager (no hipGraph) timing of the same step")
+    ap.add_argument("--eager-leg-dist", action="store_true",
+                    help="run the eager leg at N > 1 as well (default: N = 1 only -- it is a report about the import swap, and a "
+                         "side leg must not put a multi-rank run at risk)")
     ap.add_argument("--eager-steps", type=int, default=10, help="steps of the eager leg (bounded: it is a side report)")
     ap.add_argument("--optimizer-steps", type=int, default=20, help="steps of the optimizer leg (bounded: it is a side report)")
     ap.add_argument("--shadow-always", action="store_true",
@@ -547,33 +550,38 @@ def main():
     # ---- what the import swap of INTEGRATION.md section 1 costs WITHOUT the capture harness: the same step launched eagerly
     #      from Python (autograd + ctypes launches), bounded steps; and what the per-call input refresh of the harness costs
     eager_ms, refresh_us = None, None
-    if not args.no_eager_leg:
-        n_eager = max(2, min(args.steps, args.eager_steps))
-        for i in range(2):
-            model.zero_grad()
-            step(*pool[i % POOL])
-        sync()
-        t1 = time.perf_counter()
-        for i in range(n_eager):
-            model.zero_grad()
-            step(*pool[i % POOL])
-        sync()
-        te = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        eager_ms = 1e3 * te.item() / n_eager
-        log("eager launches (no hipGraph): %.3f ms/step over %d steps" % (eager_ms, n_eager))
-    static = getattr(run_step, "inputs", None)
-    if static is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        static.refresh(pool[1], {})
+    try:       # side reports: never allowed to take the headline down with them
+        if not args.no_eager_leg and (world == 1 or args.eager_leg_dist):
+            n_eager = max(2, min(args.steps, args.eager_steps))
+            for i in range(2):
+                model.zero_grad()
+                step(*pool[i % POOL])
+            sync()
+            t1 = time.perf_counter()
+            for i in range(n_eager):
+                model.zero_grad()
+                step(*pool[i % POOL])
+            sync()
+            te = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            eager_ms = 1e3 * te.item() / n_eager
+            log("eager launches (no hipGraph): %.3f ms/step over %d steps" % (eager_ms, n_eager))
+        static = getattr(run_step, "inputs", None)
+        if static is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            static.refresh(pool[1], {})
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(20):
+                static.refresh(pool[i % POOL], {})
+            e1.record()
+            torch.cuda.synchronize()
+            refresh_us = 50.0 * e0.elapsed_time(e1)
+
+    except Exception as e:  # noqa: BLE001
+        log("eager / refresh side report failed (%s: %s): reported as null" % (type(e).__name__, e))
         torch.cuda.synchronize()
-        e0.record()
-        for i in range(20):
-            static.refresh(pool[i % POOL], {})
-        e1.record()
-        torch.cuda.synchronize()
-        refresh_us = 50.0 * e0.elapsed_time(e1)
 
     # what the default ("always") shadow policy adds to a step: one f32 -> bf16 cast of the GEMM weights
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

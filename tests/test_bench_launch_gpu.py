@@ -24,7 +24,7 @@ def test_bench_gpus_n_launches_its_own_ranks(n):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-roofline", "--optimizer-steps", "2", "--eager-steps", "2"],
+                        "--no-cpu-baseline", "--no-roofline", "--optimizer-steps", "2", "--eager-steps", "2", "--eager-leg-dist"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
     err = p.stderr.decode("utf-8", "replace")
     assert p.returncode == 0, err[-4000:]
