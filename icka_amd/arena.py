@@ -86,6 +86,9 @@ class ParamArena(object):
         # hook) or mark_dirty() was called -- the caller promises not to write parameters through ``.data``
         self.shadow_policy = "always"
         self._ws: Dict[Tuple[str, int], torch.Tensor] = {}
+        # views of the flat buffers per parameter (group): the storage never moves while the arena lives, and building a
+        # slice + view pair costs ~2-3 us of host time -- ~10 of them per GEMM call in an eager step (tools/eager_profile.py)
+        self._vc: Dict[tuple, torch.Tensor] = {}
         # autograd anchor: a leaf that requires grad, passed to every Function so that backward runs even when
         # no *tensor input* requires grad (parameters are read from the arena, not passed through autograd)
         self.anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
@@ -129,10 +132,14 @@ class ParamArena(object):
 
     def w(self, p: nn.Parameter) -> torch.Tensor:
         """bf16 shadow view of a parameter."""
-        s = self.slots[id(p)]
-        if s.is_table:
-            raise RuntimeError("%s is an embedding table: it has no bf16 shadow (kernels gather the f32 master)" % s.name)
-        return self.shadow[s.off:s.off + s.numel].view(s.shape)
+        key = ("w", id(p))
+        v = self._vc.get(key)
+        if v is None:
+            s = self.slots[id(p)]
+            if s.is_table:
+                raise RuntimeError("%s is an embedding table: it has no bf16 shadow (kernels gather the f32 master)" % s.name)
+            v = self._vc[key] = self.shadow[s.off:s.off + s.numel].view(s.shape)
+        return v
 
     # -- "mixed16": fp16 shadow for the forward GEMMs (the bf16 shadow keeps serving dgrad in backward)
     def enable_fp16_shadow(self) -> None:
@@ -144,36 +151,62 @@ class ParamArena(object):
 
     def w16(self, p: nn.Parameter) -> torch.Tensor:
         """fp16 shadow view of a parameter (enable_fp16_shadow first)."""
-        s = self.slots[id(p)]
-        if s.is_table or self.shadow16 is None:
-            raise RuntimeError("%s has no fp16 shadow (embedding table, or enable_fp16_shadow() was not called)" % s.name)
-        return self.shadow16[s.off:s.off + s.numel].view(s.shape)
+        key = ("w16", id(p))
+        v = self._vc.get(key)
+        if v is None:
+            s = self.slots[id(p)]
+            if s.is_table or self.shadow16 is None:
+                raise RuntimeError("%s has no fp16 shadow (embedding table, or enable_fp16_shadow() was not called)" % s.name)
+            v = self._vc[key] = self.shadow16[s.off:s.off + s.numel].view(s.shape)
+        return v
 
     def w16_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
-        first, rows = self._adjacent(ps)
-        if self.shadow16 is None:
-            raise RuntimeError("enable_fp16_shadow() was not called")
-        return self.shadow16[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+        key = ("w16c",) + tuple(id(p) for p in ps)
+        v = self._vc.get(key)
+        if v is None:
+            first, rows = self._adjacent(ps)
+            if self.shadow16 is None:
+                raise RuntimeError("enable_fp16_shadow() was not called")
+            v = self._vc[key] = self.shadow16[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+        return v
 
     def w_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
         """bf16 view of several 2-D [o_i, in] parameters as ONE [sum o_i, in] matrix (must be adjacent slots)."""
-        first, rows = self._adjacent(ps)
-        return self.shadow[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+        key = ("wc",) + tuple(id(p) for p in ps)
+        v = self._vc.get(key)
+        if v is None:
+            first, rows = self._adjacent(ps)
+            v = self._vc[key] = self.shadow[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+        return v
 
     def f_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
         """fp32 master view of adjacent 1-D parameters as one vector (fused biases)."""
-        first, n = self._adjacent(ps)
-        return self.flat[first.off:first.off + n]
+        key = ("fc",) + tuple(id(p) for p in ps)
+        v = self._vc.get(key)
+        if v is None:
+            first, n = self._adjacent(ps)
+            v = self._vc[key] = self.flat[first.off:first.off + n]
+        return v
 
     def g(self, p: nn.Parameter) -> torch.Tensor:
-        s = self.slots[id(p)]
-        return self.gflat[s.off:s.off + s.numel].view(s.shape)
+        key = ("g", id(p))
+        v = self._vc.get(key)
+        if v is None:
+            s = self.slots[id(p)]
+            v = self._vc[key] = self.gflat[s.off:s.off + s.numel].view(s.shape)
+        return v
 
     def g_cat(self, ps: Sequence[nn.Parameter]) -> torch.Tensor:
-        first, rows = self._adjacent(ps)
-        if len(first.shape) == 2:
-            return self.gflat[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
-        return self.gflat[first.off:first.off + rows]
+        key = ("gc",) + tuple(id(p) for p in ps)
+        v = self._vc.get(key)
+        if v is None:
+            first, rows = self._adjacent(ps)
+            if len(first.shape) == 2:
+                v = self.gflat[first.off:first.off + rows * first.shape[-1]].view(rows, first.shape[-1])
+            else:
+                v = self.gflat[first.off:first.off + rows]
+            self._vc[key] = v
+        return v
 
     def wire_of(self, gview: torch.Tensor, beta: float = 0.0):
         """Data parallel with bf16 buckets (dp.GradReducer): ``{"out3": wire, "out3_only": only}`` for kernels.gemm_desc --
@@ -248,7 +281,7 @@ class ParamArena(object):
                 if mixed:
                     self.gflat[s.off:s.off + s.numel].zero_()
                 s.live = True
-                s.param.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
+                s.param.grad = self.g(s.param)
             self._pending_final.append(s)
         return 1.0 if live[0] or mixed else 0.0
 
@@ -268,7 +301,7 @@ class ParamArena(object):
         for s in (self.order if slots is None else slots):
             g = s.param.grad
             if g is None or g.data_ptr() != self.gflat.data_ptr() + 4 * s.off:
-                s.param.grad = self.gflat[s.off:s.off + s.numel].view(s.shape)
+                s.param.grad = self.g(s.param)
             s.live = True
 
     # ------------------------------------------------------------------------------------------ workspace
