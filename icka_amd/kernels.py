@@ -39,6 +39,9 @@ def _dev(t: torch.Tensor, name: str) -> None:
 
 
 def _mat(t: torch.Tensor, name: str, dtype=BF16) -> None:
+    # one-expression fast path (this runs ~700 times per eager c2 step); the slow path below words the error
+    if t.is_cuda and t.dtype is dtype and t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1):
+        return
     _dev(t, name)
     if t.dtype != dtype:
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
@@ -145,34 +148,41 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
     d = GemmDesc()
     d.op, d.M, d.N, d.K, d.K1 = op, M, N, K, K1
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
-    d.A2, d.lda2, d.B2, d.ldb2 = _ptr(A2), _ld(A2), _ptr(B2), _ld(B2)
+    if A2 is not None:       # (ctypes zero-initialises the struct: optional fields are only written when present)
+        d.A2, d.lda2, d.B2, d.ldb2 = A2.data_ptr(), A2.stride(0), B2.data_ptr(), B2.stride(0)
     d.C, d.ldc, d.c_is_f32 = out.data_ptr(), out.stride(0), {BF16: 0, F32: 1, F16: 2}[out.dtype]
-    d.ab_f16, d.C3, d.ldc3 = int(odt == F16), _ptr(out3), _ld(out3)
-    if out3_only and not (out3 is not None and out.dtype == F32 and beta == 0.0 and epilogue == EPI_NONE):
-        raise ValueError("out3_only: an f32 output with a wire copy, beta == 0, no epilogue")
-    d.c3_only = int(bool(out3_only))
+    if odt == F16:
+        d.ab_f16 = 1
+    if out3 is not None:
+        d.C3, d.ldc3 = out3.data_ptr(), out3.stride(0)
+    if out3_only:
+        if not (out3 is not None and out.dtype == F32 and beta == 0.0 and epilogue == EPI_NONE):
+            raise ValueError("out3_only: an f32 output with a wire copy, beta == 0, no epilogue")
+        d.c3_only = 1
     if out2 is not None:
         _mat(out2, "out2")
-    d.C2, d.ldc2 = _ptr(out2), _ld(out2)
+        d.C2, d.ldc2 = out2.data_ptr(), out2.stride(0)
     if aux is not None:
         _mat(aux, "aux", F16 if aux.dtype == F16 else BF16)
-    d.aux, d.ldaux = _ptr(aux), _ld(aux)
-    d.aux_f16 = int(aux is not None and aux.dtype == F16)
+        d.aux, d.ldaux = aux.data_ptr(), aux.stride(0)
+        if aux.dtype == F16:
+            d.aux_f16 = 1
     if bias is not None:
-        _dev(bias, "bias")
-        if bias.dtype != F32 or bias.numel() != N or not bias.is_contiguous():
+        if not bias.is_cuda or bias.dtype != F32 or bias.numel() != N or not bias.is_contiguous():
+            _dev(bias, "bias")
             raise ValueError("bias must be contiguous f32 [N]")
-    d.bias = _ptr(bias)
-    if bias2 is not None and (bias2.dtype != F32 or bias2.numel() != N or not bias2.is_contiguous() or not bias2.is_cuda):
-        raise ValueError("bias2 must be contiguous device f32 [N]")
-    d.bias2 = _ptr(bias2)
+        d.bias = bias.data_ptr()
+    if bias2 is not None:
+        if bias2.dtype != F32 or bias2.numel() != N or not bias2.is_contiguous() or not bias2.is_cuda:
+            raise ValueError("bias2 must be contiguous device f32 [N]")
+        d.bias2 = bias2.data_ptr()
     d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
     if colsum_out is not None:
         if op != GEMM_TN or colsum_out.dtype != F32 or colsum_out.numel() != M or not colsum_out.is_contiguous():
             raise ValueError("colsum_out: contiguous f32 [M] with op TN")
         if M % 128 or N % 128 or K % 64:
             raise ValueError("fused column sums need the aligned fast path (M, N % 128 == 0, K % 64 == 0)")
-    d.colsum_out, d.colsum_accumulate = _ptr(colsum_out), int(colsum_accumulate)
+        d.colsum_out, d.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
     if _PROF is not None:   # the recorded launch is re-issued later: its operands must outlive the step
         d._keep = (A, B, out, bias, aux, out2, A2, B2, bias2, colsum_out, out3)
     return d
