@@ -52,3 +52,21 @@ def test_bench_exit_status_of_a_failing_rank_is_relayed():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
     assert p.returncode != 0
     assert p.stdout.decode().strip() == ""
+
+
+def test_bench_accumulate_runs_the_flagged_step_with_one_exchange_per_cycle():
+    """`bench.py --accumulate 3` over RCCL at world size 1 (--force-dist): the data-parallel step accumulates three micro-batches
+    per gradient exchange (graph.FlaggedStep(accumulate=3); the reference's gradient_accumulation_steps, My_cross_attention.py:
+    587-590) -- the JSON line says so and the step is still one forward + backward per GPU."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--accumulate", "3", "--steps", "6",
+                        "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--no-optimizer-leg", "--no-eager-leg"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = p.stderr.decode("utf-8", "replace")
+    assert p.returncode == 0, err[-4000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1])
+    assert out["config"]["accumulate"] == 3 and out["config"]["launch"].startswith("hipgraph+flag-waits"), out["config"]
+    assert out["n_gpus"] == 1 and out["value"] == pytest.approx(32 / (out["ms_per_step"] * 1e-3), rel=1e-3)
+    print("\n[bench --force-dist --accumulate 3] %.3f ms/step, %s" % (out["ms_per_step"], out["config"]["launch"]))
