@@ -1260,7 +1260,8 @@ int g_abl = 0;
 unsigned long long* g_stamp = nullptr;
 int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
 int g_direct = 1;  // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
-int g_sq = 0;    // 256x256 tiles of the 8-wave load+compute kernel: OFF by default (icka_gemm_set_square_tiles; 96 vs 99 us
+int g_sq = [] { const char* e = getenv("ICKA_GEMM_SQ"); return e ? atoi(e) : 0; }();   // (env: same-box A/B)
+// 256x256 tiles of the 8-wave load+compute kernel: OFF by default (icka_gemm_set_square_tiles; 96 vs 99 us
                  // at 8192 x 4096 x 1024 cold, ahead only from K = 2048 on, where no shape of the path qualifies)
 int g_w3p = [] { const char* e = getenv("ICKA_GEMM_W3P"); return e ? atoi(e) : 0; }();   // (env: same-box A/B)
 // persistent form of the 12-wave kernel (icka_gemm_set_persistent), OFF by default: 1 = for the 256x128 tile where an output has
