@@ -132,6 +132,7 @@ class GradReducer(object):
         # graph capture (graph.SegmentedStep / graph.FlaggedStep): while ``capture`` is set, a bucket that becomes ready is
         # not launched but reported to it (``bucket_ready(idx)``, then ``after_mark()`` once per mark_final call)
         self.capture = None
+        self.muted = False       # graph.FlaggedStep, captures of the micro-batches that do not exchange: finish() is a no-op
         # ---- bf16 wire buffer (module docstring)
         self.gwire = None
         self._wire_ranges = set()                 # (offset, numel) of gradients whose wire copy a GEMM epilogue writes
@@ -347,6 +348,8 @@ class GradReducer(object):
     def finish(self) -> None:
         """Launch every bucket not launched yet (parameters that got no gradient this step keep their bucket
         waiting until here) and make the compute stream wait for the reductions."""
+        if self.muted:
+            return
         if not self._calibrated and self.gwire is not None:
             self._build_tables()      # the calibration step has shown which gradients GEMM epilogues copy to the wire:
                                       # the casts below (and of every later step) leave those ranges alone

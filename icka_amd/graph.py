@@ -429,9 +429,9 @@ class FlaggedStep(_StepBase):
                 reducer._sparse = None
         else:
             # a micro-batch that is not the last of its cycle: the same step with the reducer detached (no wire copies, no
-            # flags; the step_fn's reducer.finish() is made a no-op for the duration of the capture)
+            # flags) and muted (the step_fn's reducer.finish() returns at once for the duration of the capture)
             arena.reducer = None
-            reducer.finish = lambda: None       # (instance attribute shadowing the method; removed below)
+            reducer.muted = True                # finish() returns at once: nothing is exchanged, no bucket state moves
             try:
                 with torch.autograd.set_multithreading_enabled(False), \
                         torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
@@ -439,7 +439,7 @@ class FlaggedStep(_StepBase):
                     self._loss[key] = self._step()
             finally:
                 arena.reducer = reducer
-                del reducer.finish
+                reducer.muted = False
             torch.cuda.synchronize()
         self._graphs[key] = g
 
