@@ -549,7 +549,7 @@ def main():
 
     # ---- what the import swap of INTEGRATION.md section 1 costs WITHOUT the capture harness: the same step launched eagerly
     #      from Python (autograd + ctypes launches), bounded steps; and what the per-call input refresh of the harness costs
-    eager_ms, refresh_us = None, None
+    eager_ms, refresh_us, wrapped_ms = None, None, None
     try:       # side reports: never allowed to take the headline down with them
         if not args.no_eager_leg and (world == 1 or args.eager_leg_dist):
             n_eager = max(2, min(args.steps, args.eager_steps))
@@ -567,6 +567,26 @@ def main():
                 dist.all_reduce(te, op=dist.ReduceOp.MAX)
             eager_ms = 1e3 * te.item() / n_eager
             log("eager launches (no hipGraph): %.3f ms/step over %d steps" % (eager_ms, n_eager))
+        if not args.no_eager_leg and world == 1 and not args.no_graph:
+            # the same loop body as the eager leg -- loss = model(...); loss.backward() -- through graph.GraphedModule (a forward
+            # and a backward hipGraph behind the module's own call): what the import swap + ONE wrapping line gets
+            from icka_amd.graph import GraphedModule
+            gm = GraphedModule(model, pool[0][:6], {"labels": pool[0][6]})
+            n_w = max(2, min(args.steps, 2 * args.eager_steps))
+            for i in range(3):
+                model.zero_grad()
+                gm(*pool[i % POOL][:6], labels=pool[i % POOL][6]).backward(gradient=one)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(n_w):
+                model.zero_grad()
+                gm(*pool[i % POOL][:6], labels=pool[i % POOL][6]).backward(gradient=one)
+            sync()
+            wrapped_ms = 1e3 * (time.perf_counter() - t1) / n_w
+            gm.close()
+            if getattr(run_step, "nonce", None) is not None:       # the timed step's dropout nonce is the registered one again
+                K.set_dropout_nonce(run_step.nonce)
+            log("GraphedModule (loop body unchanged): %.3f ms/step over %d steps" % (wrapped_ms, n_w))
         static = getattr(run_step, "inputs", None)
         if static is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -730,6 +750,8 @@ def main():
             "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
             "eager_samples_per_s": None if eager_ms is None else round(args.batch * world / (eager_ms * 1e-3), 2),
             "refresh_us": None if refresh_us is None else round(refresh_us, 1),
+            # loss = model(...); loss.backward() unchanged, the module wrapped once in icka_amd.graph.GraphedModule
+            "wrapped_module_ms_per_step": None if wrapped_ms is None else round(wrapped_ms, 3),
             "inputs": "%d different synthetic batches per rank, resident in HBM, rotated: every timed step copies the next one "
                       "into the captured step's static input buffers" % POOL,
             "loss": round(final_loss, 5),

@@ -92,6 +92,8 @@ class ParamArena(object):
         # autograd anchor: a leaf that requires grad, passed to every Function so that backward runs even when
         # no *tensor input* requires grad (parameters are read from the arena, not passed through autograd)
         self.anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+        self.keep_saved = False      # graph.GraphedModule: the backward of one recorded forward is captured twice (overwrite and
+                                     # accumulate forms): the layer Functions keep their saved state across backward runs
         self.reducer = None          # optional dp.GradReducer: overlaps bucket all-reduces with backward
         self._pending_final: List[Slot] = []
         self.pending_wgrad = []      # queued weight-gradient GEMM descriptors (+ keep-alive tensors), see ops._wgrad

@@ -405,7 +405,8 @@ class BertLayerFn(torch.autograd.Function):
         layer, A, d = ctx.layer, ctx.A, ctx.d
         dx1 = _ffn_bwd(A, layer, x1, d, ctx.s_ffn, _cf(dy))
         dx, _ = _attn_bwd(A, layer.attention, x, None, d, d.S, ctx.s_att, dx1, False)
-        ctx.s_att = ctx.s_ffn = None
+        if not ctx.A.keep_saved:
+            ctx.s_att = ctx.s_ffn = None
         A.flush_final()
         return None, dx, None, None, None, None
 
@@ -429,7 +430,8 @@ class CrossLayerFn(torch.autograd.Function):
         layer, A, d = ctx.layer, ctx.A, ctx.d
         dx1 = _ffn_bwd(A, layer, x1, d, ctx.s_ffn, _cf(dy))
         ds1, ds2 = _attn_bwd(A, layer.attention, s1, s2, d, d.R, ctx.s_att, dx1, ctx.need_s2)
-        ctx.s_att = ctx.s_ffn = None
+        if not ctx.A.keep_saved:
+            ctx.s_att = ctx.s_ffn = None
         A.flush_final()
         return None, ds1, ds2, None, None, None, None
 
@@ -450,7 +452,8 @@ class AttnCoreFn(torch.autograd.Function):
     def backward(ctx, dc):
         x, kv_src = ctx.saved_tensors
         dx, dsrc = _attn_core_bwd(ctx.A, ctx.sa, x, kv_src, ctx.d, ctx.Skv, ctx.saved, _cf(dc), None, ctx.need_kv)
-        ctx.saved = None
+        if not ctx.A.keep_saved:
+            ctx.saved = None
         ctx.A.flush_final()
         return None, dx, dsrc, None, None, None, None, None
 
@@ -472,7 +475,8 @@ class DenseResidualNormFn(torch.autograd.Function):
         mod, A = ctx.mod, ctx.A
         do, dres = _dense_norm_bwd(A, mod, h, ctx.d, ctx.saved, _cf(dy))
         dh = gemm(GEMM_NN, do, _fw(A, mod.dense.weight), torch.empty_like(h))
-        ctx.saved = None
+        if not ctx.A.keep_saved:
+            ctx.saved = None
         A.flush_final()
         return None, dh, dres, None, None, None
 

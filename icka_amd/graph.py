@@ -24,6 +24,9 @@ What the reference's loop does around a step (My_cross_attention.py:797-844) and
     the first kernel inside the captured forward; with "tracked" it runs before the replay when a change was seen.
   * ``close()`` (also run by ``__del__``) unregisters the dropout nonce, whose device memory this object owns.
 
+``GraphedModule`` is the same machinery behind the module's own call: ``model(...)`` replays a forward graph, ``loss.backward()`` a
+backward graph, so the reference's loop body does not change at all (it costs one more graph boundary per step).
+
 Data parallel: ``FlaggedStep`` (one graph, bucket-ready flag words, eager all-reduces behind flag-wait kernels on the
 communication stream) is the default; with ``accumulate=k`` only the k-th micro-batch of a cycle exchanges gradients (apex
 DDP's delay_allreduce under accumulation; the first k-1 replay graphs captured without the reducer).  ``SegmentedStep`` is
@@ -220,6 +223,132 @@ class GraphedStep(_StepBase):
         """Release the graphs and unregister the dropout nonce (the kernels keep a raw pointer to it)."""
         self._close_nonce()
         self._graphs = None
+
+
+class GraphedModule(_StepBase):
+    """The import swap with NO change to the loop body: wraps a drop-in module so that the reference's own two lines
+
+        loss = model(input_ids, segment_ids, input_mask, added_input_mask, imgs_f, img_att, labels=label_ids)   # :814-817
+        loss.backward()                                                                                          # :827
+
+    replay hipGraphs -- one for the forward, one for the backward -- instead of launching ~230 kernels from Python:
+
+        model = icka_amd.graph.GraphedModule(model, example_args, example_kwargs)     # once, after model.train() / .eval()
+        loss = model(*batch_args, labels=label_ids); (loss / k).backward(); ...       # the loop stays as it is
+
+    ``model(...)`` copies the tensors into static buffers (shape / dtype checked), replays the captured forward and returns the
+    static output (a tensor; overwritten by the next call, like any graphed callable) hooked into autograd through one
+    Function; its backward copies the incoming gradient (the ``1 / k`` of the accumulation scaling arrives here), picks the
+    overwrite or the accumulate capture of the backward by the same rule ``GraphedStep`` uses (are the gradients of this cycle
+    still held?), replays it and re-attaches ``p.grad``.  Both backward captures read the activations of the ONE captured
+    forward (the layer Functions keep their saved state while ``ParamArena.keep_saved`` is set).  One wrapper = one call
+    signature and one train / eval mode (a call in the other mode raises); calls under ``torch.no_grad()`` replay the forward
+    only.  No gradient flows to the inputs.  Not for data-parallel steps (use ``FlaggedStep``)."""
+
+    def __init__(self, module: torch.nn.Module, example_args=(), example_kwargs=None, warmup: int = 3):
+        example_kwargs = dict(example_kwargs or {})
+        self._nargs = len(example_args)
+        self._kwkeys = list(example_kwargs)
+        flat = list(example_args) + [example_kwargs[k] for k in self._kwkeys]
+        self._setup(module, None, tuple(flat))
+        self.training = module.training
+        model = module
+
+        def fwd():
+            st = self.inputs.static
+            return model(*st[:self._nargs], **dict(zip(self._kwkeys, st[self._nargs:])))
+
+        self._fwd = fwd
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            for _ in range(max(1, warmup)):
+                model.zero_grad()
+                K.bump_dropout_nonce(self.nonce)
+                out = fwd()
+                if not (isinstance(out, torch.Tensor) and out.is_floating_point()):
+                    raise TypeError("GraphedModule wraps calls that return ONE floating-point tensor (loss or logits), got %s"
+                                    % type(out).__name__)
+                if out.requires_grad:
+                    out.backward(torch.ones_like(out))
+        torch.cuda.current_stream().wait_stream(self.side)
+        torch.cuda.synchronize()
+        self.arena = model._icka_arena
+        if self.arena.reducer is not None:
+            raise RuntimeError("GraphedModule is for single-process training; data-parallel steps go through FlaggedStep")
+        model.zero_grad()
+        self.gf = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gf, capture_error_mode="thread_local"):
+            K.bump_dropout_nonce(self.nonce)
+            self.out = fwd()
+        self._bwd = {}
+        self._grad_slots = []
+        self.gout = torch.zeros_like(self.out)
+        if self.out.requires_grad:
+            self.arena.keep_saved = True
+            try:
+                for accumulate in (False, True):
+                    if accumulate:
+                        self.arena.attach_grads(self._grad_slots)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.autograd.set_multithreading_enabled(False), \
+                            torch.cuda.graph(g, pool=self.gf.pool(), capture_error_mode="thread_local"):
+                        self.out.backward(self.gout, retain_graph=True)
+                    self._bwd[accumulate] = g
+                    if not accumulate:
+                        self._grad_slots = [s for s in self.arena.order if s.live]
+            finally:
+                self.arena.keep_saved = False
+        model.zero_grad()                       # captures execute nothing
+        outer = self
+
+        class _Replay(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, anchor):
+                outer.gf.replay()
+                return outer.out.detach()
+
+            @staticmethod
+            def backward(ctx, g):
+                outer._replay_backward(g)
+                return None
+
+        self._fn = _Replay
+
+    def _replay_backward(self, g: torch.Tensor) -> None:
+        if not self._bwd:
+            raise RuntimeError("this GraphedModule was captured without a backward (its output did not require grad)")
+        self.gout.copy_(g.expand_as(self.gout) if g.shape != self.gout.shape else g, non_blocking=True)
+        accumulate, stale = self._cycle_state()
+        self._zero(stale)
+        self._bwd[accumulate].replay()
+        self.arena.attach_grads(self._grad_slots)
+
+    def __call__(self, *args, **kwargs) -> torch.Tensor:
+        if self.gf is None:
+            raise RuntimeError("GraphedModule is closed")
+        if self.model.training != self.training:
+            raise RuntimeError("GraphedModule was captured in %s mode; build another wrapper for the other mode"
+                               % ("train" if self.training else "eval"))
+        if len(args) != self._nargs or sorted(kwargs) != sorted(self._kwkeys):
+            raise TypeError("GraphedModule: expected %d positional arguments and keywords %s (the captured call signature), got %d "
+                            "and %s" % (self._nargs, sorted(self._kwkeys), len(args), sorted(kwargs)))
+        self.inputs.refresh(tuple(args) + tuple(kwargs[k] for k in self._kwkeys), {})
+        if self.arena.shadow_policy != "always":
+            self.arena.sync()
+        K.lstm_check_error("detected before a GraphedModule replay")
+        if torch.is_grad_enabled() and self._bwd:
+            return self._fn.apply(self.arena.anchor)
+        self.gf.replay()
+        return self.out.detach()
+
+    # the wrapped module stays reachable (optimizers, state_dict, zero_grad, train / eval)
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "model"), name)
+
+    def close(self) -> None:
+        self._close_nonce()
+        self.gf = None
+        self._bwd = {}
 
 
 class _Capture(object):

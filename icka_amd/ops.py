@@ -450,7 +450,8 @@ class BertLayerFn(torch.autograd.Function):
         layer, A, d = ctx.layer, ctx.A, ctx.d
         dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
         dx, _ = _attn_block_bwd(A, layer.attention, x, None, add_mask, d, d.S, ctx.s_att, dx1, None, False)
-        ctx.s_att = ctx.s_ffn = None
+        if not A.keep_saved:
+            ctx.s_att = ctx.s_ffn = None
         _flush_wgrad(A)
         A.flush_final()
         return None, dx, None, None, None, None, None
@@ -478,7 +479,8 @@ class CrossLayerFn(torch.autograd.Function):
         layer, A, d = ctx.layer, ctx.A, ctx.d
         dx1 = _ffn_block_bwd(A, layer, x1, d, ctx.s_ffn, _c(dy))
         ds1, ds2 = _attn_block_bwd(A, layer.attention, s1, s2, add_mask, d, d.R, ctx.s_att, dx1, None, ctx.need_s2)
-        ctx.s_att = ctx.s_ffn = None
+        if not A.keep_saved:
+            ctx.s_att = ctx.s_ffn = None
         _flush_wgrad(A)
         A.flush_final()
         return None, ds1, None, ds2, None, None, None, None, None
@@ -502,7 +504,8 @@ class AttnCoreFn(torch.autograd.Function):
         x, kv_src, add_mask, c = ctx.saved_tensors
         A = ctx.A
         dx, dsrc = _attn_core_bwd(A, ctx.sa, x, kv_src, add_mask, ctx.d, ctx.Skv, ctx.saved, c, _c(dc), None, ctx.need_kv)
-        ctx.saved = None
+        if not A.keep_saved:
+            ctx.saved = None
         _flush_wgrad(A)
         A.flush_final()
         return None, dx, dsrc, None, None, None, None, None
@@ -529,7 +532,8 @@ class DenseResidualNormFn(torch.autograd.Function):
         do, dres = _dense_norm_bwd(A, "ln_sub", mod, h, ctx.d, ctx.saved, _c(dy), None)
         dh = torch.empty_like(h)
         K.gemm(K.GEMM_NN, do, A.w(mod.dense.weight), dh)
-        ctx.saved = None
+        if not A.keep_saved:
+            ctx.saved = None
         _flush_wgrad(A)
         A.flush_final()
         return None, dh, dres, None, None, None, None

@@ -177,3 +177,55 @@ def test_refresh_checks_shapes_dtypes_and_arity():
         gk(*b)
     for g in (gs, no_inputs, gk):
         g.close()
+
+
+@pytest.mark.parametrize("precision,bar", [("fp32", 2e-6), ("bf16", 2e-4)])
+def test_graphed_module_keeps_the_reference_loop_body(precision, bar):
+    """graph.GraphedModule: the reference's two lines -- ``loss = model(...)`` (:814-817) and ``loss.backward()`` (:827) -- stay as
+    they are and replay a forward and a backward hipGraph.  The recipe of this file (5 micro-batches of different inputs,
+    loss / 5 applied OUTSIDE the wrapper, clip, AdamW, schedule, zero_grad) eager vs wrapped: same losses and parameters; a
+    no_grad call replays the forward only; zero_grad between forward and backward is honoured; the other train / eval mode and
+    another call signature raise."""
+    from icka_amd.graph import GraphedModule
+    base = _model(precision)
+    batches = _batches(K_ACC * OPT_STEPS)
+    results = []
+    for wrapped in (False, True):
+        model = copy.deepcopy(base)
+        call = GraphedModule(model, batches[0][:6], {"labels": batches[0][6]}) if wrapped else model
+
+        def run(b):
+            loss = call(*b[:6], labels=b[6]) / K_ACC            # the reference's own lines: forward ...
+            loss.backward()                                     # ... and backward
+            return loss.detach().clone()
+
+        results.append(_recipe(model, run, batches, False))
+        if wrapped:
+            gm = call
+    (le, pe), (lg, pg) = results
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= bar * max(1.0, abs(a)), (le, lg)
+    worst = max((pe[n] - pg[n]).abs().max().item() / (pe[n].abs().max().item() + 1e-6) for n in pe)
+    print("\n[%s, GraphedModule] losses %s; worst parameter difference vs the eager loop %.3e" % (precision, ["%.6f" % x for x in lg], worst))
+    assert worst <= bar, worst
+    b = batches[0]
+    with torch.no_grad():
+        l0 = gm(*b[:6], labels=b[6]).item()
+    assert abs(l0 - gm.model(*b[:6], labels=b[6]).item()) <= bar * max(1.0, abs(l0))
+    # loss = model(x); optimizer.zero_grad(); loss.backward()  -> the backward overwrites
+    gm.model.zero_grad()
+    gm(*b[:6], labels=b[6]).backward()
+    g1 = gm.model.classifier.weight.grad.clone()
+    loss = gm(*b[:6], labels=b[6])
+    gm.model.zero_grad()
+    loss.backward()
+    assert torch.equal(gm.model.classifier.weight.grad, g1)
+    loss = gm(*b[:6], labels=b[6])
+    loss.backward()                                             # gradients still held: accumulates
+    assert torch.allclose(gm.model.classifier.weight.grad, 2 * g1, rtol=1e-3, atol=1e-7)
+    with pytest.raises(TypeError):
+        gm(*b[:6])
+    gm.model.train()
+    with pytest.raises(RuntimeError, match="eval mode"):
+        gm(*b[:6], labels=b[6])
+    gm.close()
