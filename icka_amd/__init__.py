@@ -14,6 +14,8 @@ from .crf import CRF
 from .lstm import BiLSTM
 from .modeling import MTCCMBertForMMTokenClassificationCRF_gate_1
 from .dp import GradReducer
+from . import graph
+from .graph import GraphedModule, GraphedStep
 from . import cross_modal
 from .cross_modal import PromptRobertaModel
 
@@ -22,4 +24,4 @@ __all__ = ["CRF", "BiLSTM", "MTCCMBertForMMTokenClassificationCRF_gate_1", "Bert
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
            "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",
            "token_ce_loss", "set_precision", "resolved_precision", "ParamArena", "cross_modal", "PromptRobertaModel",
-           "GradReducer"]
+           "GradReducer", "graph", "GraphedModule", "GraphedStep"]

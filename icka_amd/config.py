@@ -11,56 +11,66 @@ import copy
 import json
 
 
+# field -> default, in the positional order of the reference constructor (after the vocabulary size / JSON path)
+_FIELDS = (("hidden_size", 768), ("num_hidden_layers", 12), ("num_attention_heads", 12), ("intermediate_size", 3072),
+           ("hidden_act", "gelu"), ("hidden_dropout_prob", 0.1), ("attention_probs_dropout_prob", 0.1),
+           ("max_position_embeddings", 512), ("type_vocab_size", 2), ("initializer_range", 0.02), ("layer_norm_eps", 1e-12))
+
+
 class BertConfig(object):
-    def __init__(self, vocab_size_or_config_json_file, hidden_size=768, num_hidden_layers=12,
-                 num_attention_heads=12, intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1,
-                 attention_probs_dropout_prob=0.1, max_position_embeddings=512, type_vocab_size=2,
-                 initializer_range=0.02, layer_norm_eps=1e-12):
-        if isinstance(vocab_size_or_config_json_file, str):
-            with open(vocab_size_or_config_json_file, "r", encoding="utf-8") as reader:
-                for key, value in json.loads(reader.read()).items():
-                    self.__dict__[key] = value
-        elif isinstance(vocab_size_or_config_json_file, int):
-            self.vocab_size = vocab_size_or_config_json_file
-            self.hidden_size = hidden_size
-            self.num_hidden_layers = num_hidden_layers
-            self.num_attention_heads = num_attention_heads
-            self.hidden_act = hidden_act
-            self.intermediate_size = intermediate_size
-            self.hidden_dropout_prob = hidden_dropout_prob
-            self.attention_probs_dropout_prob = attention_probs_dropout_prob
-            self.max_position_embeddings = max_position_embeddings
-            self.type_vocab_size = type_vocab_size
-            self.initializer_range = initializer_range
-            self.layer_norm_eps = layer_norm_eps
-        else:
-            raise ValueError("First argument must be either a vocabulary size (int) "
-                             "or the path to a pretrained model config file (str)")
+    """Plain attribute bag.  ``BertConfig(30522, hidden_size=768, ...)`` or ``BertConfig("config.json")``; fields arrive
+    positionally or by keyword in the reference's order (``_FIELDS``); a JSON file may carry additional keys, which become
+    attributes as well."""
+
+    def __init__(self, vocab_size_or_config_json_file, *args, **kwargs):
+        first = vocab_size_or_config_json_file
+        if isinstance(first, str):
+            self._absorb(_read_json(first))
+            return
+        if isinstance(first, bool) or not isinstance(first, int):
+            raise ValueError("First argument must be either a vocabulary size (int) or the path to a pretrained model config "
+                             "file (str)")
+        if len(args) > len(_FIELDS):
+            raise TypeError("BertConfig takes at most %d positional arguments" % (1 + len(_FIELDS)))
+        values = dict(_FIELDS)
+        values.update(zip((name for name, _ in _FIELDS), args))
+        unknown = set(kwargs) - set(values)
+        if unknown:
+            raise TypeError("BertConfig got unexpected keyword arguments %s" % sorted(unknown))
+        values.update(kwargs)
+        self.vocab_size = first
+        self._absorb(values)
+
+    def _absorb(self, mapping) -> None:
+        for key, value in mapping.items():
+            setattr(self, key, value)
 
     @classmethod
     def from_dict(cls, json_object):
-        config = BertConfig(vocab_size_or_config_json_file=-1)
-        for key, value in json_object.items():
-            config.__dict__[key] = value
+        config = cls(-1)
+        config._absorb(json_object)
         return config
 
     @classmethod
     def from_json_file(cls, json_file):
-        with open(json_file, "r", encoding="utf-8") as reader:
-            return cls.from_dict(json.loads(reader.read()))
-
-    def __repr__(self):
-        return str(self.to_json_string())
+        return cls.from_dict(_read_json(json_file))
 
     def to_dict(self):
-        return copy.deepcopy(self.__dict__)
+        return copy.deepcopy(vars(self))
 
     def to_json_string(self):
         return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
 
     def to_json_file(self, json_file_path):
-        with open(json_file_path, "w", encoding="utf-8") as writer:
-            writer.write(self.to_json_string())
+        with open(json_file_path, "w", encoding="utf-8") as fh:
+            fh.write(self.to_json_string())
+
+    __repr__ = to_json_string
+
+
+def _read_json(path):
+    with open(path, "r", encoding="utf-8") as fh:
+        return json.load(fh)
 
 
 def check_config(config) -> None:
