@@ -549,7 +549,7 @@ def main():
 
     # ---- what the import swap of INTEGRATION.md section 1 costs WITHOUT the capture harness: the same step launched eagerly
     #      from Python (autograd + ctypes launches), bounded steps; and what the per-call input refresh of the harness costs
-    eager_ms, refresh_us, wrapped_ms = None, None, None
+    eager_ms, refresh_us, wrapped_ms, host_ms, host_pf_ms, host_bytes = None, None, None, None, None, 0
     try:       # side reports: never allowed to take the headline down with them
         if not args.no_eager_leg and (world == 1 or args.eager_leg_dist):
             n_eager = max(2, min(args.steps, args.eager_steps))
@@ -598,6 +598,38 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             refresh_us = 50.0 * e0.elapsed_time(e1)
+            if world == 1 and hasattr(run_step, "inputs"):
+                # the PCIe-inclusive rate: the reference's loop moves every batch from the host inside the step
+                # (My_cross_attention.py:797-798); here the POOL batches sit in pinned host memory and each timed call hands
+                # the host tensors to the captured step (copy_ on the step's stream, then the replay).  Never the headline.
+                host_pool = [tuple(t.cpu().pin_memory() for t in b) for b in pool]
+                n_h = max(2, min(args.steps, 20))
+                for i in range(2):
+                    model.zero_grad()
+                    run_step(*host_pool[i % POOL])
+                sync()
+                t1 = time.perf_counter()
+                for i in range(n_h):
+                    model.zero_grad()
+                    run_step(*host_pool[i % POOL])
+                sync()
+                host_ms = 1e3 * (time.perf_counter() - t1) / n_h
+                host_bytes = sum(t.numel() * t.element_size() for t in host_pool[0])
+                log("host-resident (pinned) batches, %.1f MB over PCIe per step: %.3f ms/step" % (host_bytes / 1e6, host_ms))
+                # the same host batches one step ahead on a copy stream (graph.DevicePrefetcher): PCIe off the critical path
+                from icka_amd.graph import DevicePrefetcher
+                feed = iter(DevicePrefetcher((host_pool[i % POOL] for i in range(n_h + 2)), dev))
+                for _ in range(2):
+                    model.zero_grad()
+                    run_step(*next(feed))
+                sync()
+                t1 = time.perf_counter()
+                for b in feed:
+                    model.zero_grad()
+                    run_step(*b)
+                sync()
+                host_pf_ms = 1e3 * (time.perf_counter() - t1) / n_h
+                log("the same through DevicePrefetcher (next batch copied under the current step): %.3f ms/step" % host_pf_ms)
 
     except Exception as e:  # noqa: BLE001
         log("eager / refresh side report failed (%s: %s): reported as null" % (type(e).__name__, e))
@@ -752,6 +784,11 @@ def main():
             "refresh_us": None if refresh_us is None else round(refresh_us, 1),
             # loss = model(...); loss.backward() unchanged, the module wrapped once in icka_amd.graph.GraphedModule
             "wrapped_module_ms_per_step": None if wrapped_ms is None else round(wrapped_ms, 3),
+            # PCIe-inclusive: the same captured step fed from pinned HOST tensors (H2D copies on the step's stream, serial with it)
+            "host_inputs_ms_per_step": None if host_ms is None else round(host_ms, 3),
+            "host_inputs_samples_per_s": None if host_ms is None else round(args.batch / (host_ms * 1e-3), 2),
+            "host_inputs_prefetched_ms_per_step": None if host_pf_ms is None else round(host_pf_ms, 3),
+            "host_input_bytes_per_step": host_bytes or None,
             "inputs": "%d different synthetic batches per rank, resident in HBM, rotated: every timed step copies the next one "
                       "into the captured step's static input buffers" % POOL,
             "loss": round(final_loss, 5),

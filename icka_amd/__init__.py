@@ -15,7 +15,7 @@ from .lstm import BiLSTM
 from .modeling import MTCCMBertForMMTokenClassificationCRF_gate_1
 from .dp import GradReducer
 from . import graph
-from .graph import GraphedModule, GraphedStep
+from .graph import DevicePrefetcher, GraphedModule, GraphedStep
 from . import cross_modal
 from .cross_modal import PromptRobertaModel
 
@@ -24,4 +24,4 @@ __all__ = ["CRF", "BiLSTM", "MTCCMBertForMMTokenClassificationCRF_gate_1", "Bert
            "BertSelfAttention", "BertCoAttention", "BertSelfOutput", "BertIntermediate", "BertOutput",
            "BertPreTrainedModel", "MTCCMBertForMMTokenClassificationCRF", "cls_layer_both", "scalar_gate_fusion",
            "token_ce_loss", "set_precision", "resolved_precision", "ParamArena", "cross_modal", "PromptRobertaModel",
-           "GradReducer", "graph", "GraphedModule", "GraphedStep"]
+           "GradReducer", "graph", "DevicePrefetcher", "GraphedModule", "GraphedStep"]

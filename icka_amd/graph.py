@@ -110,6 +110,80 @@ class StaticInputs(object):
             K.copy_many(dev_src[i:i + 8], dev_dst[i:i + 8])
 
 
+class DevicePrefetcher(object):
+    """Iterate a host-side batch source (the reference's DataLoader loop, My_cross_attention.py:795-798) one batch AHEAD: while
+    step i runs, batch i + 1 is copied host -> device on a copy stream of its own, through a pinned staging copy when the source
+    tensors are pageable.  Each item is a tuple of device tensors in one of ``depth`` rotating buffer sets; the consumer's stream
+    is made to wait for the copy, and the copy stream waits for the consumer before a set is overwritten, so ``gs(*batch)`` sees
+    device sources (one icka_copy_many launch into the captured step's static buffers) and PCIe is off the step's critical path.
+
+        for batch in DevicePrefetcher(train_dataloader, "cuda"):
+            loss = gs(*batch)
+    """
+
+    def __init__(self, source, device, depth: int = 2):
+        if depth < 2:
+            raise ValueError("DevicePrefetcher needs at least two buffer sets")
+        self.source, self.device, self.depth = source, torch.device(device), depth
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._sig = None
+
+    def __len__(self):
+        return len(self.source)
+
+    def _issue(self, slot, batch):
+        if isinstance(batch, torch.Tensor):
+            batch = (batch,)
+        if slot["done"] is not None:
+            self.stream.wait_event(slot["done"])            # the consumer is finished with this set
+        sig = [(tuple(t.shape), t.dtype) for t in batch]
+        if self._sig is None:
+            self._sig = sig
+        if len(sig) != len(self._sig):
+            raise ValueError("DevicePrefetcher: batches must keep their arity")
+        for (shape, dtype), (shape0, dtype0) in zip(sig, self._sig):
+            if shape != shape0 or dtype != dtype0:
+                raise ValueError("DevicePrefetcher: batches must keep their shapes (got %s %s, the first batch had %s %s)"
+                                 % (shape, dtype, shape0, dtype0))
+        with torch.cuda.stream(self.stream):
+            if slot["dev"] is None:
+                slot["dev"] = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in batch]
+                slot["pin"] = [None if (t.is_cuda or t.is_pinned()) else torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in batch]
+            for t, d, pin in zip(batch, slot["dev"], slot["pin"]):
+                if pin is not None:
+                    if slot["staged"] is not None:
+                        slot["staged"].synchronize()        # the previous copy out of this pinned buffer has left the host
+                    pin.copy_(t)
+                    t = pin
+                d.copy_(t, non_blocking=True)
+            slot["staged"] = torch.cuda.Event()
+            slot["staged"].record(self.stream)
+        return slot
+
+    def __iter__(self):
+        slots = [{"dev": None, "pin": None, "done": None, "staged": None} for _ in range(self.depth)]
+        self._sig = None
+        it = iter(self.source)
+        pending = []
+        i = 0
+        try:
+            pending.append(self._issue(slots[0], next(it)))
+        except StopIteration:
+            return
+        while pending:
+            slot = pending.pop(0)
+            i += 1
+            try:
+                pending.append(self._issue(slots[i % self.depth], next(it)))
+            except StopIteration:
+                pass
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(slot["staged"])
+            yield tuple(slot["dev"])
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(torch.cuda.current_stream(self.device))
+
+
 class _StepBase(object):
     """Shared by the step objects: the dropout nonce, the static inputs, warm-up, and which capture a call replays."""
 

@@ -229,3 +229,46 @@ def test_graphed_module_keeps_the_reference_loop_body(precision, bar):
     with pytest.raises(RuntimeError, match="eval mode"):
         gm(*b[:6], labels=b[6])
     gm.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
+def test_device_prefetcher_feeds_the_captured_step_in_order(pinned):
+    """graph.DevicePrefetcher: host batches (the reference's loader hands over host tensors, My_cross_attention.py:795-798) arrive
+    as device tuples one step ahead, in order, bit for bit, through two rotating buffer sets; a captured step fed from it gives the
+    losses of the same step fed the device batches directly; arity / shape changes raise."""
+    from icka_amd.graph import DevicePrefetcher, GraphedStep
+    host = _batches(7, device="cpu")
+    if pinned:
+        host = [tuple(t.pin_memory() for t in b) for b in host]
+    seen = 0
+    for i, b in enumerate(DevicePrefetcher(host, "cuda")):
+        assert all(t.is_cuda for t in b)
+        for got, want in zip(b, host[i]):
+            assert torch.equal(got.cpu(), want), i
+        seen += 1
+    assert seen == len(host) and len(DevicePrefetcher(host, "cuda")) == len(host)
+    assert list(DevicePrefetcher([], "cuda")) == []
+    model = _model("bf16")
+
+    def micro(ids, seg, mask, added, vmean, vatt, labels):
+        loss = model(ids, seg, mask, added, vmean, vatt, labels=labels)
+        loss.backward()
+        return loss
+
+    gs = GraphedStep(model, micro, inputs=tuple(t.cuda() for t in host[0]), warmup=1)
+    direct = []
+    for b in host:
+        model.zero_grad()
+        direct.append(gs(*(t.cuda() for t in b)).item())
+    fed = []
+    for b in DevicePrefetcher(host, "cuda", depth=3):
+        model.zero_grad()
+        fed.append(gs(*b).item())
+    assert fed == direct and len(set(fed)) > 1
+    gs.close()
+    with pytest.raises(ValueError, match="shapes"):
+        list(DevicePrefetcher([host[0], tuple(t[:2] for t in host[1])], "cuda"))
+    with pytest.raises(ValueError, match="arity"):
+        list(DevicePrefetcher([host[0], host[1][:-1]], "cuda"))
+    with pytest.raises(ValueError):
+        DevicePrefetcher(host, "cuda", depth=1)
