@@ -25,7 +25,8 @@ What the reference's loop does around a step (My_cross_attention.py:797-844) and
   * ``close()`` (also run by ``__del__``) unregisters the dropout nonce, whose device memory this object owns.
 
 ``GraphedModule`` is the same machinery behind the module's own call: ``model(...)`` replays a forward graph, ``loss.backward()`` a
-backward graph, so the reference's loop body does not change at all (it costs one more graph boundary per step).
+backward graph, so the reference's loop body does not change at all (it costs one more graph boundary per step); with
+``reducer=`` its backward also exchanges the gradients (the flag-word protocol below), as a DDP-wrapped module's does.
 
 Data parallel: ``FlaggedStep`` (one graph, bucket-ready flag words, eager all-reduces behind flag-wait kernels on the
 communication stream) is the default; with ``accumulate=k`` only the k-th micro-batch of a cycle exchanges gradients (apex
@@ -317,9 +318,29 @@ class GraphedModule(_StepBase):
     still held?), replays it and re-attaches ``p.grad``.  Both backward captures read the activations of the ONE captured
     forward (the layer Functions keep their saved state while ``ParamArena.keep_saved`` is set).  One wrapper = one call
     signature and one train / eval mode (a call in the other mode raises); calls under ``torch.no_grad()`` replay the forward
-    only.  No gradient flows to the inputs.  Not for data-parallel steps (use ``FlaggedStep``)."""
+    only.  No gradient flows to the inputs.
 
-    def __init__(self, module: torch.nn.Module, example_args=(), example_kwargs=None, warmup: int = 3):
+    Data parallel (the reference wraps the model in apex DDP and keeps the same two lines, My_cross_attention.py:768-776):
+    ``GraphedModule(model, args, kwargs, reducer=GradReducer(...), accumulate=k)`` -- the backward capture carries the
+    bucket-ready flag nodes of ``FlaggedStep``, and ``loss.backward()`` replays it, then enqueues the flag waits and the eager
+    all-reduces on the reducer's communication stream and joins: when ``backward()`` returns (stream-ordered) ``p.grad`` holds
+    the exchanged gradients, as after a DDP backward.  With ``accumulate=k`` only the k-th backward of a cycle (a cycle
+    restarts at ``zero_grad``) exchanges, the others replay captures without the reducer."""
+
+    def __init__(self, module: torch.nn.Module, example_args=(), example_kwargs=None, warmup: int = 3, reducer=None,
+                 accumulate: int = 1):
+        if accumulate < 1:
+            raise ValueError("accumulate must be >= 1")
+        if reducer is None and accumulate != 1:
+            raise ValueError("accumulate=k only changes WHEN gradients are exchanged: it needs reducer=")
+        if reducer is not None:
+            if not (reducer.is_cuda and reducer.backend == "nccl"):
+                raise RuntimeError("GraphedModule(reducer=) needs the nccl (= RCCL) backend on a ROCm device")
+            if getattr(reducer, "sparse_word", None) is not None:
+                raise ValueError("GraphedModule(reducer=) does not take GradReducer(sparse_embeddings=True): use FlaggedStep")
+            reducer.arena.reducer = reducer     # attached from the first warm-up backward on (it calibrates there)
+        self.reducer = reducer
+        self.accumulate = int(accumulate)
         example_kwargs = dict(example_kwargs or {})
         self._nargs = len(example_args)
         self._kwkeys = list(example_kwargs)
@@ -344,34 +365,43 @@ class GraphedModule(_StepBase):
                                     % type(out).__name__)
                 if out.requires_grad:
                     out.backward(torch.ones_like(out))
+                    if reducer is not None:
+                        reducer.finish()       # (eager exchange: the first of these steps calibrates its write counts)
         torch.cuda.current_stream().wait_stream(self.side)
         torch.cuda.synchronize()
         self.arena = model._icka_arena
-        if self.arena.reducer is not None:
-            raise RuntimeError("GraphedModule is for single-process training; data-parallel steps go through FlaggedStep")
+        if reducer is None and self.arena.reducer is not None:
+            raise RuntimeError("this model's arena has a GradReducer attached: pass it as GraphedModule(..., reducer=) so that "
+                               "backward() exchanges the gradients (or detach it: arena.reducer = None)")
+        if reducer is not None:
+            if reducer.arena is not self.arena:
+                raise ValueError("GraphedModule(reducer=): the reducer belongs to another model's arena")
+            self.arena.reducer = reducer
+            self._xch = _FlagExchange(reducer, self.arena, self.device)
         model.zero_grad()
         self.gf = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gf, capture_error_mode="thread_local"):
             K.bump_dropout_nonce(self.nonce)
             self.out = fwd()
-        self._bwd = {}
+        self._bwd = {}                          # (accumulate, exchange) -> backward graph
+        self._order = {}                        # exchanging captures: the order their bucket flags rise in
+        self._micro = 0
         self._grad_slots = []
         self.gout = torch.zeros_like(self.out)
         if self.out.requires_grad:
-            self.arena.keep_saved = True
-            try:
-                for accumulate in (False, True):
-                    if accumulate:
-                        self.arena.attach_grads(self._grad_slots)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.autograd.set_multithreading_enabled(False), \
-                            torch.cuda.graph(g, pool=self.gf.pool(), capture_error_mode="thread_local"):
-                        self.out.backward(self.gout, retain_graph=True)
-                    self._bwd[accumulate] = g
-                    if not accumulate:
-                        self._grad_slots = [s for s in self.arena.order if s.live]
-            finally:
-                self.arena.keep_saved = False
+            # every capture a backward() can ask for is taken NOW: a capture runs autograd itself and must not start from inside
+            # the autograd call that replays it
+            k = self.accumulate
+            if reducer is None:
+                keys = [(False, False), (True, False)]
+            elif k == 1:
+                keys = [(False, True), (True, True)]
+            else:
+                keys = [(False, False), (True, False), (True, True)]
+            for i, key in enumerate(keys):
+                self._capture_bwd(*key)
+                if i == 0:
+                    self._grad_slots = [s for s in self.arena.order if s.live]
         model.zero_grad()                       # captures execute nothing
         outer = self
 
@@ -393,9 +423,64 @@ class GraphedModule(_StepBase):
             raise RuntimeError("this GraphedModule was captured without a backward (its output did not require grad)")
         self.gout.copy_(g.expand_as(self.gout) if g.shape != self.gout.shape else g, non_blocking=True)
         accumulate, stale = self._cycle_state()
+        exchange = False
+        if self.reducer is not None:
+            if not accumulate:
+                self._micro = 0                 # the caller dropped the gradients: a new cycle starts here
+            exchange = self._micro == self.accumulate - 1
+        key = (accumulate, exchange)
+        if key not in self._bwd:                # (accumulate = k > 1 and the first backward of a cycle is also its last: k == 1 only)
+            raise RuntimeError("GraphedModule: no backward capture for accumulate=%s, exchange=%s" % key)
         self._zero(stale)
-        self._bwd[accumulate].replay()
+        if exchange:
+            self._xch.before_replay()
+        self._bwd[key].replay()
+        if exchange:
+            self._xch.after_replay(self._order[key])
+            self._micro = 0
+        elif self.reducer is not None:
+            self._micro += 1
         self.arena.attach_grads(self._grad_slots)
+
+    def _capture_bwd(self, accumulate: bool, exchange: bool) -> None:
+        arena, r = self.arena, self.reducer
+        if accumulate:
+            arena.attach_grads(self._grad_slots)
+        g = torch.cuda.CUDAGraph()
+        key = (accumulate, exchange)
+        arena.keep_saved = True
+        try:
+            if exchange:
+                cap = _FlagCapture(self._xch.sync)
+                r.capture = cap
+                arena.reducer = r
+                try:
+                    with torch.autograd.set_multithreading_enabled(False), \
+                            torch.cuda.graph(g, pool=self.gf.pool(), capture_error_mode="thread_local"):
+                        self._xch.first_node()
+                        self.out.backward(self.gout, retain_graph=True)
+                        r.finish()              # reports the remaining buckets (their flags rise at the end of the graph)
+                finally:
+                    r.capture = None
+                torch.cuda.synchronize()
+                if sorted(cap.order) != list(range(len(r.buckets))):
+                    raise RuntimeError("GraphedModule: buckets flagged during capture %s != all %d buckets" % (cap.order, len(r.buckets)))
+                self._order[key] = cap.order
+            else:
+                if r is not None:               # a backward that does not exchange: reducer detached, no wire copies, no flags
+                    arena.reducer = None
+                    r.muted = True
+                try:
+                    with torch.autograd.set_multithreading_enabled(False), \
+                            torch.cuda.graph(g, pool=self.gf.pool(), capture_error_mode="thread_local"):
+                        self.out.backward(self.gout, retain_graph=True)
+                finally:
+                    if r is not None:
+                        arena.reducer = r
+                        r.muted = False
+        finally:
+            arena.keep_saved = False
+        self._bwd[key] = g
 
     def __call__(self, *args, **kwargs) -> torch.Tensor:
         if self.gf is None:
@@ -410,6 +495,8 @@ class GraphedModule(_StepBase):
         if self.arena.shadow_policy != "always":
             self.arena.sync()
         K.lstm_check_error("detected before a GraphedModule replay")
+        if self.reducer is not None:
+            K.dp_check_error("detected before a GraphedModule replay")
         if torch.is_grad_enabled() and self._bwd:
             return self._fn.apply(self.arena.anchor)
         self.gf.replay()
@@ -533,6 +620,38 @@ class _FlagCapture(object):
 
     def after_mark(self) -> None:
         pass
+
+
+class _FlagExchange(object):
+    """The replay-side half of the flag-word protocol (``FlaggedStep`` docstring) for a capture that is not a whole step
+    (``GraphedModule``'s backward): the sync words, the tag of the next exchanging replay, and the flag waits + eager all-reduces
+    + join + final poison pass behind a replay."""
+
+    def __init__(self, reducer, arena, device):
+        import os
+        nb = len(reducer.buckets)
+        self.reducer, self.arena = reducer, arena
+        self.sync = torch.zeros(FlaggedStep.FLAG0 + 2 * nb + 16, dtype=torch.int32, device=device)
+        self.starts = torch.tensor([lo for lo, _ in reducer.buckets], dtype=torch.int64, device=device)
+        K.check(K._lib.load().icka_dp_init(), "icka_dp_init")
+        self.polls = int(os.environ.get("ICKA_DP_WAIT_POLLS", FlaggedStep.WAIT_POLLS))
+        self.flag_ptr = [self.sync.data_ptr() + 4 * (FlaggedStep.FLAG0 + i) for i in range(nb)]
+        self.bad_ptr = [self.sync.data_ptr() + 4 * (FlaggedStep.FLAG0 + nb + i) for i in range(nb)]
+        self.tag = 0
+
+    def first_node(self) -> None:
+        K.check(K._lib.load().icka_dp_step_bump(self.sync.data_ptr(), K._stream()), "icka_dp_step_bump")
+
+    def before_replay(self) -> None:
+        self.tag += 1                           # == the step counter the capture's first node is about to write
+
+    def after_replay(self, order) -> None:
+        r = self.reducer
+        for idx in order:
+            r.launch_now(idx, wait=(self.flag_ptr[idx], self.tag, self.polls, self.bad_ptr[idx]))
+        r.join()
+        K.check(K._lib.load().icka_dp_poison_final(self.bad_ptr[0], len(r.buckets), self.tag & 0xFFFFFFFF, self.arena.gflat.data_ptr(),
+                                                  self.starts.data_ptr(), 8, K._stream()), "icka_dp_poison_final")
 
 
 class FlaggedStep(_StepBase):

@@ -103,6 +103,31 @@ def test_flagged_step_accumulates_and_exchanges_on_the_last_micro_batch(tmp_path
     assert res["graphs"] == [(False, False), (True, False), (True, True)], res
 
 
+@pytest.mark.parametrize("acc,comm,bar", [(1, "f32", 2e-6), (1, "bf16", 6e-3), (3, "f32", 2e-6), (3, "bf16", 6e-3)])
+def test_graphed_module_exchanges_behind_backward(tmp_path, acc, comm, bar):
+    """``GraphedModule(model, ..., reducer=, accumulate=k)`` over RCCL at world 1: the reference's loop body unchanged under data
+    parallelism (its apex DDP exchanges inside ``backward()``, My_cross_attention.py:768-776).  Gradients after each cycle == the
+    eager sum of the cycle's micro-batches; the step word rises on the k-th backward of a cycle only, a ``zero_grad`` restarts
+    the cycle, a ``no_grad`` forward exchanges nothing."""
+    out = str(tmp_path / "gm.pt")
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_module_worker.py"), str(_free_port()), out, str(acc), comm])
+    try:
+        assert p.wait(timeout=300) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+    res = torch.load(out)
+    print("\n[GraphedModule(reducer=, accumulate=%d), %s buckets] worst gradient rel-L2 vs eager sum %.3e; step word after each "
+          "backward %s; captures %s" % (acc, comm, res["worst"], res["step_words"], res["captures"]))
+    assert res["worst"] < bar and res["error_word"] == 0, res
+    if acc == 1:
+        assert res["step_words"] == [1, 2, 3, 4, 4], res
+        assert res["captures"] == [(False, True), (True, True)], res
+    else:
+        assert res["step_words"] == [0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3], res
+        assert res["captures"] == [(False, False), (True, False), (True, True)], res
+
+
 @pytest.mark.parametrize("comm", ["f32", "bf16"])
 def test_flag_wait_that_gives_up_poisons_the_bucket_and_raises(tmp_path, comm):
     """the NaN of a wait that gave up must survive the bucket's chunk cast and late gradient stores -- for the
