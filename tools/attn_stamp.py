@@ -17,8 +17,10 @@ lib = _lib.load()
 setbuf = lib.icka_attn_set_stamp_buffer
 setbuf.argtypes = [C.c_void_p]
 setbuf.restype = None
-B, h, H = 32, 12, 768
-for Sq, Skv, p in ((128, 128, 0.1), (128, 128, 0.0), (128, 36, 0.1)):
+CASES = [(32, 12, 128, 128, 0.1), (32, 12, 128, 128, 0.0), (32, 12, 128, 36, 0.1),
+         (32, 16, 256, 256, 0.1), (32, 16, 256, 256, 0.0)]          # the last two: bert-large at seq 256 (c4)
+for B, h, Sq, Skv, p in CASES:
+    H = 64 * h
     qkv = torch.randn(B * Sq, 3 * H, device="cuda").to(BF16)
     kv = torch.randn(B * Skv, 2 * H, device="cuda").to(BF16) if Skv != Sq else qkv[:, H:]
     q, k, v = qkv[:, :H], kv[:, :H], kv[:, H:2 * H]
@@ -29,12 +31,13 @@ for Sq, Skv, p in ((128, 128, 0.1), (128, 128, 0.0), (128, 36, 0.1)):
     dqkv = torch.empty(B * Sq, 3 * H, dtype=BF16, device="cuda")
     dkv = torch.empty(B * Skv, 2 * H, dtype=BF16, device="cuda") if Skv != Sq else dqkv[:, H:]
     delta = torch.empty(B, h, Sq, dtype=F32, device="cuda")
-    K.attn_fwd(q, k, v, mask, out, lse, B, h, Sq, Skv, p_drop=p, seed=1)
+    kb = K.attn_keepbits(B, h, Sq, Skv, q.device) if (p > 0 and Skv > 128) else None     # as ops.py does beyond 128 keys
+    K.attn_fwd(q, k, v, mask, out, lse, B, h, Sq, Skv, p_drop=p, seed=1, keepbits=kb)
     buf = torch.zeros(B * h, 4, 16, dtype=torch.int64, device="cuda")
 
     def bwd():
         K.attn_bwd(q, k, v, mask, out, dout, lse, delta, dqkv[:, :H], dkv[:, :H], dkv[:, H:2 * H], B, h, Sq, Skv,
-                   p_drop=p, seed=1)
+                   p_drop=p, seed=1, keepbits=kb)
     for _ in range(20):
         bwd()
     setbuf(buf.data_ptr())
