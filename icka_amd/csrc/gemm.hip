@@ -2187,6 +2187,38 @@ __global__ __launch_bounds__(512) void slab_reduce_kernel(const SlabRed r) {
     __shared__ __attribute__((aligned(16))) char smem[8 * 64 * 4];
     slab_reduce_block(r, smem, blockIdx.x);
 }
+// The 128x128 group kernel with slab reductions riding along as extra blocks at the end of the grid (as on the 256x128 launch):
+// a group of few tiles (the two gate weight gradients of the head: 72 tiles) leaves most CUs idle, the reductions run there.
+struct GroupArgsRed { GroupArgs ga; SlabRed red[MAX_RED]; int red_start[MAX_RED + 1]; };
+template <bool A_KM, bool B_KM, int NBUF>
+__global__ __launch_bounds__(512) void gemm_ws_group_red_kernel(const GroupArgsRed gr) {
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
+    const int bid = blockIdx.x;
+    const int tiles = gr.ga.start[MAX_GROUP];
+    if (bid >= tiles) {
+        const int rb = bid - tiles;
+        int ri = 0;
+#pragma unroll
+        for (int i = 1; i < MAX_RED; ++i) ri += rb >= gr.red_start[i] ? 1 : 0;
+        slab_reduce_block(gr.red[ri], smem, rb - gr.red_start[ri]);
+        return;
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) pi += bid >= gr.ga.start[i] ? 1 : 0;
+    const GemmArgs g = gr.ga.p[pi];
+    gemm_ws_body<A_KM, B_KM, NBUF>(g, smem, bid - gr.ga.start[pi], gr.ga.start[pi + 1] - gr.ga.start[pi]);
+}
+// several reductions in ONE launch (the slabs no weight-gradient launch took along: each used to pay its own launch)
+struct SlabRedMulti { SlabRed red[MAX_RED]; int red_start[MAX_RED + 1]; };
+__global__ __launch_bounds__(512) void slab_reduce_multi_kernel(const SlabRedMulti m) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * 64 * 4];
+    const int rb = blockIdx.x;
+    int ri = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_RED; ++i) ri += rb >= m.red_start[i] ? 1 : 0;
+    slab_reduce_block(m.red[ri], smem, rb - m.red_start[ri]);
+}
 
 template <bool WIRE>
 __device__ __forceinline__ void gemm_big_tn_body(const GemmArgs& g, char* smem, const int m0, const int n0) {
@@ -2609,7 +2641,22 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
             for (int k = cnt; k <= MAX_GROUP; ++k) ga.start[k] = total;
             for (int k = cnt; k < MAX_GROUP; ++k) ga.p[k] = ga.p[0];
             int rc;
-            if (op == ICKA_GEMM_NT) rc = launch_group<false, false>(ga, total, st);
+            if (op == ICKA_GEMM_TN && !reds_done && g_ws) {
+                // the pending slab reductions ride on this launch (extra blocks behind the tiles)
+                GroupArgsRed gr;
+                gr.ga = ga;
+                int red_total = 0;
+                for (int r = 0; r < MAX_RED; ++r) {
+                    gr.red_start[r] = red_total;
+                    if (r < n_red) { gr.red[r] = to_red(reds[r]); red_total += gr.red[r].blocks; }
+                    else gr.red[r] = SlabRed{};
+                }
+                gr.red_start[MAX_RED] = red_total;
+                hipLaunchKernelGGL((gemm_ws_group_red_kernel<true, true, 3>), dim3(total + red_total), dim3(512), 0, st, gr);
+                ICKA_CHECK_LAUNCH();
+                reds_done = true;
+                rc = 0;
+            } else if (op == ICKA_GEMM_NT) rc = launch_group<false, false>(ga, total, st);
             else if (op == ICKA_GEMM_NN) rc = launch_group<false, true>(ga, total, st);
             else rc = launch_group<true, true>(ga, total, st);
             if (rc) return rc;
@@ -2621,11 +2668,22 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
         }
     }
     if (!reds_done) {   // no 256x128 launch took them along: reduce the slabs with their own small launches
-        for (int r = 0; r < n_red; ++r) {
-            const SlabRed sr = to_red(reds[r]);
+        if (n_red == 1) {
+            const SlabRed sr = to_red(reds[0]);
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr.blocks), dim3(512), 0, st, sr);
-            ICKA_CHECK_LAUNCH();
+        } else {
+            SlabRedMulti m;
+            int total = 0;
+            for (int r = 0; r < MAX_RED; ++r) {
+                m.red_start[r] = total;
+                if (r < n_red) { m.red[r] = to_red(reds[r]); total += m.red[r].blocks; }
+                else m.red[r] = SlabRed{};
+            }
+            m.red_start[MAX_RED] = total;
+            for (int r = n_red; r < MAX_RED; ++r) m.red_start[r] = total;   // (empty ranges behind the last real one)
+            hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(total), dim3(512), 0, st, m);
         }
+        ICKA_CHECK_LAUNCH();
     }
     return 0;
 }
