@@ -100,7 +100,7 @@ int icka_gemm_grouped(const icka_gemm_desc* descs, int32_t n, void* stream);
 /* Same, plus up to 4 slab reductions  out[slot][c] (+)= sum_b partials[b*slab_stride + slot*H + c]  (b < nslab,
  * slot < nslots <= 4, c < H; fixed summation order) that ride on the launch: the LayerNorm dgamma / dbeta slabs left
  * by icka_ln_bwd_slabs are summed by extra blocks of the layer's weight-gradient grid instead of a launch of their
- * own.  Without an eligible 256x128 launch (or with n == 0) they are reduced by small launches of their own. */
+ * own.  A 128x128 TN group takes them along the same way; without any eligible launch (or with n == 0) they share ONE small launch. */
 typedef struct icka_slab_reduction {
     const float* partials; int64_t slab_stride; int32_t nslab, H, nslots, accumulate;
     float* out[4];
