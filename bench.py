@@ -268,7 +268,8 @@ def dry_rank(args, json_fd, world, rank, local_rank):
         time.sleep(0.2)                              # rank-0-only legs (roofline, cpu baseline): the others wait below
     dist.barrier()
     if rank == 0:
-        out = {"metric": "MNER samples/sec (fwd+bwd) at seq=%d, %d regions, bs=%d per GPU" % (args.seq, args.regions, args.batch),
+        # NOT the headline metric's name: a harness that ignores "dry" must not book a sleep as a throughput
+        out = {"metric": "DRY RUN of the bench.py launch flow (sleeps, no kernels): ranks x batch %d / slowest rank's sleep" % args.batch,
                "value": round(args.batch * world * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)", "data": "none",
@@ -284,6 +285,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the block of --steps timed steps is run this many times back to back (same graph, same batch pool, each "
+                         "block bracketed by barrier + synchronize and reduced by MAX over ranks); value / ms_per_step come from "
+                         "the MEDIAN block, ms_per_step_min / _max give the run's own spread")
     ap.add_argument("--config", choices=sorted(PRESETS), default=None,
                     help="BASELINE.json configuration preset (default: c2, the configuration the metric is quoted on); "
                          "explicit shape flags override the preset")
@@ -446,77 +451,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- whole-step hipGraph (falls back to eager launches if capture is not possible, e.g. an RCCL build that
-    #      cannot be captured): the timed region then replays the graph
-    mode = "eager"
-    run_step = step
-    if not args.no_graph and reducer is not None and not args.capture_collectives and args.dp_step == "flagged" \
-            and reducer.backend == "nccl":
-        # data parallel: ONE graph, bucket-ready flag words, eager all-reduces behind flag waits on the communication stream
-        try:
-            from icka_amd.graph import FlaggedStep
-            log("capturing the step as one hipGraph with bucket-ready flags (eager all-reduces on the communication stream)")
-            if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallbacks below
-                raise RuntimeError("simulated capture failure")
-            fstep = FlaggedStep(model, step, reducer, inputs=pool[0], accumulate=args.accumulate)
-            run_step = fstep
-            mode = "hipgraph+flag-waits+eager-allreduce(%d buckets, overlapped)" % len(reducer.buckets)
-        except Exception as e:  # noqa: BLE001
-            log("flagged capture failed (%s: %s)" % (type(e).__name__, e))
-            torch.cuda.synchronize()
-            reducer.capture = None
-            arena.reducer = reducer
-    if not args.no_graph and mode == "eager" and reducer is not None and not args.capture_collectives:
-        # fallback: linear graph segments with the bucket all-reduces issued eagerly between them (graph.SegmentedStep)
-        try:
-            from icka_amd.graph import SegmentedStep
-            log("capturing the step as linear hipGraph segments (eager all-reduces in between)")
-            if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallbacks below
-                raise RuntimeError("simulated capture failure")
-            sstep = SegmentedStep(model, step, reducer, inputs=pool[0])
-            run_step = sstep
-            mode = "hipgraph-segments(%d)+eager-allreduce(%d buckets, overlapped)" % (len(sstep.segments), len(reducer.buckets))
-        except Exception as e:  # noqa: BLE001
-            log("segmented capture failed (%s: %s)" % (type(e).__name__, e))
-            torch.cuda.synchronize()
-            reducer.capture = None
-            arena.reducer = reducer
-    if not args.no_graph and mode == "eager":
-        try:
-            from icka_amd.graph import GraphedStep
-            log("capturing the step into a hipGraph")
-            if os.environ.get("ICKA_BENCH_FAIL_FIRST_CAPTURE"):   # test hook for the fallback below
-                raise RuntimeError("simulated capture failure")
-            gstep = GraphedStep(model, step, inputs=pool[0])
-            run_step = gstep
-            mode = "hipgraph"
-        except Exception as e:  # noqa: BLE001
-            log("graph capture failed (%s: %s)" % (type(e).__name__, e))
-            torch.cuda.synchronize()
-            run_step = step
-            if reducer is not None:
-                # last graph attempt: capture forward + backward only and launch the bucket all-reduces eagerly after each
-                # replay (no overlap, but no host-bound step)
-                try:
-                    arena.reducer = None
-
-                    def compute_only(ids, seg, mask, added, vmean, vatt, labels):
-                        loss = model(ids, seg, mask, added, vmean, vatt, labels=labels)
-                        loss.backward(gradient=one)
-                        return loss
-                    gcomp = GraphedStep(model, compute_only, inputs=pool[0])
-
-                    def run_step(*b):
-                        loss = gcomp(*b)
-                        reducer.reduce_all()
-                        return loss
-                    mode = "hipgraph(compute)+eager-allreduce"
-                    log("captured forward+backward only; gradient all-reduce runs eagerly after each replay")
-                except Exception as e2:  # noqa: BLE001
-                    log("compute-only capture failed too (%s: %s); running eagerly" % (type(e2).__name__, e2))
-                    torch.cuda.synchronize()
-                    arena.reducer = reducer
-                    run_step = step
+    # ---- the form the step runs in: ONE decision point (graph.build_step).  At N = 1: one hipGraph, else eager launches.
+    #      Under data parallelism the chain flagged -> segmented -> captured compute + eager all-reduces -> eager is walked by
+    #      ALL ranks together: each form warms up (collectives, identical on every rank), captures in a phase without
+    #      process-group traffic, and the ranks vote over the c10d store before anyone uses the result
+    from icka_amd.graph import build_step
+    run_step, mode = build_step(model, step, inputs=pool[0], reducer=reducer, accumulate=args.accumulate,
+                                prefer=args.dp_step, graph=not args.no_graph, capture_collectives=args.capture_collectives,
+                                log=log)
 
     log("warm-up %d steps" % args.warmup)
     acc_k = max(1, args.accumulate)
@@ -528,24 +470,34 @@ def main():
         step_loss = run_step(*pool[i % POOL])
     model.zero_grad()
     sync()
-    log("timing %d steps (%s)" % (args.steps, mode))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # the reference drops the gradients after every optimisation step (:843); set_to_none: the next backward overwrites
-        # the gradient arena (no memset) -- a captured step replays its overwrite capture
-        if i % acc_k == 0:
-            model.zero_grad()
-        step_loss = run_step(*pool[i % POOL])
-    sync()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    repeats = max(1, args.repeats)
+    log("timing %d x %d steps (%s)" % (repeats, args.steps, mode))
+    blocks = []
+    ctr = 0
+    for rep in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            # the reference drops the gradients after every optimisation step (:843); set_to_none: the next backward overwrites
+            # the gradient arena (no memset) -- a captured step replays its overwrite capture
+            if ctr % acc_k == 0:
+                model.zero_grad()
+            step_loss = run_step(*pool[ctr % POOL])
+            ctr += 1
+        sync()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        blocks.append(tmax.item())
+    order = sorted(blocks)
+    dt = order[(len(order) - 1) // 2]            # the median block (the lower one of an even count)
     ms_per_step = 1e3 * dt / args.steps
+    ms_blocks = [round(1e3 * b / args.steps, 4) for b in blocks]
     samples_per_s = args.batch * world * args.steps / dt
     final_loss = float(step_loss.item())
-    log("%.3f ms/step, %.1f samples/s, loss %.4f" % (ms_per_step, samples_per_s, final_loss))
+    log("%.3f ms/step (median of %d blocks: %s), %.1f samples/s, loss %.4f"
+        % (ms_per_step, repeats, " ".join("%.3f" % m for m in ms_blocks), samples_per_s, final_loss))
 
     # ---- what the import swap of INTEGRATION.md section 1 costs WITHOUT the capture harness: the same step launched eagerly
     #      from Python (autograd + ctypes launches), bounded steps; and what the per-call input refresh of the harness costs
@@ -571,22 +523,26 @@ def main():
             # the same loop body as the eager leg -- loss = model(...); loss.backward() -- through graph.GraphedModule (a forward
             # and a backward hipGraph behind the module's own call): what the import swap + ONE wrapping line gets
             from icka_amd.graph import GraphedModule
-            gm = GraphedModule(model, pool[0][:6], {"labels": pool[0][6]})
-            n_w = max(2, min(args.steps, 2 * args.eager_steps))
-            for i in range(3):
-                model.zero_grad()
-                gm(*pool[i % POOL][:6], labels=pool[i % POOL][6]).backward(gradient=one)
-            sync()
-            t1 = time.perf_counter()
-            for i in range(n_w):
-                model.zero_grad()
-                gm(*pool[i % POOL][:6], labels=pool[i % POOL][6]).backward(gradient=one)
-            sync()
-            wrapped_ms = 1e3 * (time.perf_counter() - t1) / n_w
-            gm.close()
-            if getattr(run_step, "nonce", None) is not None:       # the timed step's dropout nonce is the registered one again
-                K.set_dropout_nonce(run_step.nonce)
-            log("GraphedModule (loop body unchanged): %.3f ms/step over %d steps" % (wrapped_ms, n_w))
+            gm = None
+            try:
+                gm = GraphedModule(model, pool[0][:6], {"labels": pool[0][6]})
+                n_w = max(2, min(args.steps, 2 * args.eager_steps))
+                for i in range(3):
+                    model.zero_grad()
+                    gm(*pool[i % POOL][:6], labels=pool[i % POOL][6]).backward(gradient=one)
+                sync()
+                t1 = time.perf_counter()
+                for i in range(n_w):
+                    model.zero_grad()
+                    gm(*pool[i % POOL][:6], labels=pool[i % POOL][6]).backward(gradient=one)
+                sync()
+                wrapped_ms = 1e3 * (time.perf_counter() - t1) / n_w
+                log("GraphedModule (loop body unchanged): %.3f ms/step over %d steps" % (wrapped_ms, n_w))
+            finally:
+                if gm is not None:
+                    gm.close()
+                if getattr(run_step, "nonce", None) is not None:   # the timed step's dropout nonce is the registered one again,
+                    K.set_dropout_nonce(run_step.nonce)            # also when this side leg failed half-way
         static = getattr(run_step, "inputs", None)
         if static is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -757,7 +713,11 @@ def main():
         out = {
             "metric": "MNER samples/sec (fwd+bwd) at seq=%d, %d regions, bs=%d per GPU" % (args.seq, args.regions, args.batch),
             "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            # the run's own noise bar: `repeats` blocks of `steps` steps each, value / ms_per_step from the MEDIAN block
+            "repeats": repeats, "ms_per_step_min": round(min(ms_blocks), 3), "ms_per_step_max": round(max(ms_blocks), 3),
+            "ms_per_step_blocks": ms_blocks,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "fp16 forward operands + bf16 backward (16-bit MFMA, f32 accumulate)",
             "data": "synthetic",

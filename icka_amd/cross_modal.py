@@ -18,7 +18,7 @@ stack (RoBERTa's layer is the BERT layer):
 """
 from __future__ import annotations
 
-from typing import Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -238,12 +238,34 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
                       ops.LinearFn.apply(A.anchor, flat, self.lastproj, A, False, K.EPI_NONE)).view(B, 2 * self.prompt_len, 1024)
         return prefix
 
+    def resolve_offset(self, offsets) -> int:
+        """The host integer the reference reads back from the device EVERY step (``offsets.tolist()[0]``, :949; SURVEY section 7
+        lists that sync under quirks not to copy).  The offset is a property of the prompt template, the same for every sample
+        of a data set (the reference's loop asserts it, My_cross_attention.py:803): an ``int`` or a host tensor is used as it is;
+        a device tensor is read back ONCE per model (``set_offset(k)`` states it up front or changes it) -- no per-step sync,
+        and the step can be captured (a device tensor with nothing resolved yet raises under capture instead of syncing)."""
+        if isinstance(offsets, int):
+            return offsets
+        if isinstance(offsets, torch.Tensor) and not offsets.is_cuda:
+            return int(offsets.reshape(-1)[0])
+        off = getattr(self, "_offset_host", None)
+        if off is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("offsets is a device tensor and no offset has been resolved yet: pass an int / host tensor, "
+                                   "call model.set_offset(k), or run one eager step before capturing")
+            off = self._offset_host = int(offsets.reshape(-1)[0].item())
+        return off
+
+    def set_offset(self, offset: Optional[int]) -> None:
+        """State the prompt template's offset (None: resolve it again from the next device tensor)."""
+        self._offset_host = None if offset is None else int(offset)
+
     def emissions(self, input_ids, segment_ids, input_mask, ori_input_ids, ori_input_mask, ori_segment_ids,
                   added_attention_mask, clip_features, visual_embeds_mean, visual_embeds_att, offsets):
         B, S = ori_input_ids.shape
         H = self.hidden_size
         dev = ori_input_ids.device
-        offset = int(offsets.tolist()[0])                                                   # :949
+        offset = self.resolve_offset(offsets)                                               # :949, without its per-step sync
         # ---- trunk: text encoder -> dropout -> regions -> vismap2text -> text->image cross encoder (:950-969)
         A, _, _, cross, _ = _mner_trunk(self, ori_input_ids, ori_segment_ids, ori_input_mask, added_attention_mask,
                                         visual_embeds_att)

@@ -48,6 +48,52 @@ import torch.distributed as dist
 from .arena import ParamArena
 
 
+_GATHER_SEQ: Dict[str, int] = {}
+
+
+def all_ranks_gather(value, group=None, what: str = "value", timeout: float = 600.0) -> list:
+    """Every rank's ``value`` (JSON-serialisable: bool / int / str / list), in rank order, exchanged over the c10d key-value
+    STORE of the process group -- not over a collective.  Host-only: nothing is enqueued on a GPU stream and nothing travels over
+    the backend, so ranks may call it while their device state differs (one of them has just failed a stream capture, another
+    still holds a finished one) -- the situation in which a backend collective pairs with the wrong call and aborts
+    (gloo ``collective mismatch``; a hang under RCCL).  The ranks must call it the same number of times in the same order
+    (a per-group call counter names the keys); a rank that does not arrive within ``timeout`` seconds raises here on the others."""
+    if not dist.is_initialized():
+        return [value]
+    world = dist.get_world_size(group)
+    if world == 1:
+        return [value]
+    import json
+    from datetime import timedelta
+    from torch.distributed import distributed_c10d as c10d
+    rank = dist.get_rank(group)
+    store = c10d._get_default_store()
+    members = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+    gkey = "-".join(str(r) for r in members)
+    seq = _GATHER_SEQ[gkey] = _GATHER_SEQ.get(gkey, 0) + 1
+    base = "icka_amd/gather/%s/%d" % (gkey, seq)
+    store.set("%s/%d" % (base, rank), json.dumps(value))
+    keys = ["%s/%d" % (base, r) for r in range(world)]
+    try:
+        store.wait(keys, timedelta(seconds=timeout))
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError("icka_amd.dp: not every rank reached the agreement point %r (#%d) within %.0f s: %s"
+                           % (what, seq, timeout, e)) from e
+    return [json.loads(store.get(k).decode()) for k in keys]
+
+
+def all_ranks_agree(ok: bool, group=None, what: str = "vote") -> bool:
+    """True iff ``ok`` holds on EVERY rank of the group (``all_ranks_gather`` over the store: no collective, no device work).
+    The single decision point of everything that may succeed on one rank and fail on another -- above all a hipGraph capture:
+    each rank tries in a phase that issues no process-group traffic, then all vote, then all build the agreed form."""
+    return all(bool(v) for v in all_ranks_gather(bool(ok), group, what))
+
+
+class CaptureDisagreement(RuntimeError):
+    """A captured data-parallel step could not be built on EVERY rank (raised on all of them, also on those whose own capture
+    succeeded): the ranks take the same fallback together."""
+
+
 class _NullCtx(object):
     def __enter__(self):
         return self
@@ -124,6 +170,9 @@ class GradReducer(object):
                 if lo <= s.off < hi:
                     self._bucket_of[id(s)] = bi
                     break
+        self._word_written = False   # the sparse word table's slot received a (dense) gradient write in the step in flight
+        self._agreed_T = set()       # local row counts whose path / buffer sizes the ranks have agreed on (exchange_sparse)
+        self._poison_off = [lo for lo, _ in self.buckets]   # where a bucket's give-up NaN goes (see _build_tables)
         self._calibrated = False
         self._expected: Dict[int, int] = {}       # slot -> gradient writes per step (counted in the calibration step)
         self._seen: Dict[int, int] = {}
@@ -150,6 +199,19 @@ class GradReducer(object):
         if (self.is_cuda and self.backend == "nccl" and self.world > 1) or lstm_reserved_cus is not None:
             from . import kernels as K
             self._prev_reserved = K.lstm_set_reserved_cus(LSTM_RESERVED_CUS if lstm_reserved_cus is None else lstm_reserved_cus)
+
+    def abort_step(self) -> None:
+        """Forget the step in flight (a capture or an eager step that raised half-way): no bucket is marked launched, no
+        write counted, no rows pending, no capture protocol attached.  The calibration is kept."""
+        self.capture = None
+        self.muted = False
+        self._sparse = None
+        self._word_written = False
+        self._seen = {}
+        self._waiting = [0] * len(self.buckets)
+        for sid in self._expected:
+            self._waiting[self._bucket_of[sid]] += 1
+        self._launched = [False] * len(self.buckets)
 
     def close(self) -> None:
         """Detach from the arena and give back the CU reservation taken for the persistent BiLSTM kernels."""
@@ -207,6 +269,14 @@ class GradReducer(object):
             if cur < hi:
                 ranges.append((cur, hi))
             self._tables[bi] = K.dp_chunk_table(ranges, self.arena.device)
+            # the NaN of a flag wait that gave up goes where NO GEMM epilogue writes its wire copy (a bias / LayerNorm / table
+            # range: their wire values come from the cast launch, which runs on the communication stream BEFORE the poison), so
+            # a weight-gradient store of the still-running graph cannot overwrite it before RCCL reads the bucket: every rank
+            # receives the NaN through the sum
+            for a, b in ranges:
+                if b - a >= 8:
+                    self._poison_off[bi] = a
+                    break
         # gradients written exactly once per step may drop their f32 store (wire_view)
         once = {}
         for s in self.arena.order:
@@ -222,6 +292,15 @@ class GradReducer(object):
                 cur += (ent[0].numel + 7) // 8 * 8
             if ok and cur >= off + n:
                 self._wire_only.add((off, n))
+
+    def forget_wire_copies(self) -> None:
+        """From now on the cast launches cover the WHOLE of every bucket and no GEMM may drop its f32 store: for a step whose
+        weight-gradient GEMMs run without this reducer attached (graph.build_step's compute-only capture) and therefore write
+        no wire copies."""
+        self._wire_ranges = set()
+        self._wire_only = set()
+        if self.gwire is not None:
+            self._build_tables()
 
     def cast_elements(self) -> int:
         """Elements per step that still go through the cast launches (diagnostics / DESIGN.md)."""
@@ -279,8 +358,8 @@ class GradReducer(object):
                 from . import kernels as K
                 K.dp_cast_chunks(self.arena.gflat, self.gwire, self._tables[idx])
                 w = self.gwire[s:e]
-                if bad is not None:
-                    self._poison_if(bad, w)      # after the cast (which rewrites un-wired slots), before the sum
+                if bad is not None:              # after the cast (which rewrites un-wired slots), before the sum
+                    self._poison_if(bad, self.gwire[self._poison_off[idx]:e])
                 dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
                 K.dp_cast_back_scaled(w, buf, 1.0 / self.world)
             else:
@@ -317,7 +396,10 @@ class GradReducer(object):
         the calibration step: a data-dependent branch, a module applied more often) would be lost or race with the
         in-place reduction: it raises."""
         if self.sparse_word is not None:
+            n_all = len(slots)
             slots = [s for s in slots if s is not self.sparse_word]
+            if len(slots) != n_all:
+                self._word_written = True     # exchange_sparse: rows registered -> row exchange, else dense all-reduce of the slot
         if not self._calibrated:
             for s in slots:
                 self._expected[id(s)] = self._expected.get(id(s), 0) + 1
@@ -372,6 +454,15 @@ class GradReducer(object):
         if self.is_cuda and self.backend == "nccl":
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
+    def share_bad_words(self, words: torch.Tensor) -> None:
+        """f32 wire format only: make a flag wait that gave up on ONE rank known to all -- a MAX all-reduce of the buckets' bad
+        words (they hold the step number of the give-up) on the communication stream behind the last bucket, so that the final
+        poison pass (icka_dp_poison_final) writes the NaN on every rank and no replica takes an optimizer step on the partial
+        sums it received.  (With bf16 buckets the NaN itself travels through the sum: ``_poison_off``.)"""
+        if self.is_cuda and self.backend == "nccl" and self.world > 1 and not self.comm_bf16:
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(words, op=dist.ReduceOp.MAX, group=self.group)
+
     def reduce_all(self) -> None:
         """Non-overlapped form: all-reduce every bucket now (after backward)."""
         self.finish()
@@ -385,6 +476,9 @@ class GradReducer(object):
             raise RuntimeError("GradReducer was built without sparse_embeddings=True (or the table is not at a bucket edge)")
         if rows.dim() != 2 or rows.shape[1] != self.sparse_word.shape[1] or ids.numel() != rows.shape[0]:
             raise ValueError("sparse rows must be [T, %d] with one id per row" % self.sparse_word.shape[1])
+        if self._sparse is not None:
+            raise RuntimeError("GradReducer.set_sparse_rows: the rows of an earlier embedding backward of this step have not been "
+                               "exchanged yet (finish() / exchange_sparse() consumes them); a second set would replace them silently")
         self._sparse = (rows, ids, bool(accumulate))
 
     def _sparse_buffers(self, T: int, H: int, dtype, device):
@@ -397,18 +491,54 @@ class GradReducer(object):
             self._sparse_ws[key] = ws
         return ws
 
-    def exchange_sparse(self) -> None:
+    def _exchange_word_dense(self) -> None:
+        """The word table's slot was written DENSELY in this step (an embedding backward that does not know the row path: the
+        fp32-exact mode, the prompt embeddings of cross_modal): mean all-reduce of the slot, like any bucket."""
+        w = self.sparse_word
+        g = self.arena.gflat[w.off:w.off + w.numel]
+        self.sparse_stats["dense_slot"] = self.sparse_stats.get("dense_slot", 0) + 1
+        if self.is_cuda and self.backend == "nccl":
+            on_current = getattr(self, "_exchange_on_current", False)
+            if not on_current:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with (_NullCtx() if on_current else torch.cuda.stream(self.comm_stream)):
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            return
+        host = g.cpu() if self.is_cuda else g
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        host.mul_(1.0 / self.world)
+        if self.is_cuda:
+            g.copy_(host)
+
+    def exchange_sparse(self, word_written: Optional[bool] = None) -> None:
         """All-gather every rank's token rows + ids and add (1 / world) * rows into the word table's gradient slot; dense
         fallback (local scatter + all-reduce of the slot) when a rank brings at least vocab / 4 rows.  On devices with RCCL the
         work goes to the communication stream (after everything already on the current stream); ``join`` orders it before the
-        consumers of the gradient."""
-        if self.sparse_word is None or self._sparse is None:
+        consumers of the gradient.  A step whose embedding backward registered NO rows but wrote the slot densely
+        (``word_written``; default: what ``mark_final`` saw in the step in flight) gets a plain mean all-reduce of the slot, so
+        no path leaves the replicas with local word gradients.  The row count T and with it the path (rows / dense) and the
+        all-gather sizes are agreed across the ranks the first time each T is seen (host-side, over the store): ragged counts
+        raise on every rank instead of pairing an all-reduce with an all-gather."""
+        if self.sparse_word is None:
+            return
+        written = self._word_written if word_written is None else bool(word_written)
+        self._word_written = False
+        if self._sparse is None:
+            if written:
+                self._exchange_word_dense()
             return
         rows, ids, accumulate = self._sparse
         self._sparse = None
         w = self.sparse_word
         V, H = w.shape
         T = rows.shape[0]
+        if T not in self._agreed_T:
+            Ts = all_ranks_gather(int(T), self.group, "row count of the sparse word-embedding exchange")
+            if len(set(Ts)) != 1:
+                raise RuntimeError("icka_amd.dp.GradReducer(sparse_embeddings=True): the ranks bring different numbers of token rows "
+                                   "%s -- the row exchange needs the same batch x sequence shape on every rank (pad the last batch "
+                                   "as the reference's sampler does, or use the dense exchange)" % Ts)
+            self._agreed_T.add(T)
         g = self.arena.gflat[w.off:w.off + w.numel].view(V, H)
         inv = 1.0 / self.world
         dense = T * 4 >= V

@@ -808,8 +808,36 @@ class MTCCMBertForMMTokenClassificationCRF(BertPreTrainedModel):
         logits = ops.GatedHeadFn.apply(A.anchor, seq, cross, self, A, seq16, cross16)
         return logits.view(B, S, self.num_labels)
 
-    def forward(self, input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_mean=None,
-                visual_embeds_att=None, temp=None, temp_lamb=None, lamb=None, labels=None, negative_rate=None):
+    def forward(self, input_ids, segment_ids=None, input_mask=None, added_attention_mask=None, visual_embeds_mean=None,
+                visual_embeds_att=None, temp=None, temp_lamb=None, lamb=None, labels=None, negative_rate=None, *,
+                attention_mask=None, visual_feats=None, token_type_ids=None):
+        """Positional form = the reference's (gate_cl_modeling.py:1319-1320).  Keyword aliases for the signature BASELINE.json's
+        north_star names, ``forward(input_ids, attention_mask, visual_feats, ...)``: ``attention_mask`` = ``input_mask``,
+        ``visual_feats`` = ``visual_embeds_att`` ([B,2048,7,7] or [B,R,2048]), ``token_type_ids`` = ``segment_ids``.  What such a
+        caller leaves out gets the value the reference's feature builder gives it: segment ids all zero
+        (My_cross_attention.py:362), every token valid, and ``added_attention_mask`` = ones[R] followed by the text mask (:373)."""
+        if attention_mask is not None:
+            if input_mask is not None:
+                raise TypeError("forward() got both input_mask and its alias attention_mask")
+            input_mask = attention_mask
+        if visual_feats is not None:
+            if visual_embeds_att is not None:
+                raise TypeError("forward() got both visual_embeds_att and its alias visual_feats")
+            visual_embeds_att = visual_feats
+        if token_type_ids is not None:
+            if segment_ids is not None:
+                raise TypeError("forward() got both segment_ids and its alias token_type_ids")
+            segment_ids = token_type_ids
+        if visual_embeds_att is None:
+            raise TypeError("forward() needs the region features (visual_embeds_att / visual_feats)")
+        if segment_ids is None:
+            segment_ids = torch.zeros_like(input_ids)
+        if input_mask is None:
+            input_mask = torch.ones_like(input_ids)
+        if added_attention_mask is None:
+            R = visual_embeds_att.shape[1] if visual_embeds_att.dim() == 3 else visual_embeds_att.shape[2] * visual_embeds_att.shape[3]
+            added_attention_mask = torch.cat([torch.ones(input_ids.shape[0], R, dtype=input_mask.dtype, device=input_mask.device),
+                                              input_mask], dim=1)
         logits = self.logits(input_ids, segment_ids, input_mask, added_attention_mask, visual_embeds_att)
         if labels is None:
             if self.crf is not None:   # cl_modeling.py:1386: pred_tags = self.crf.decode(feats, mask=input_mask.byte())

@@ -37,6 +37,10 @@ def test_default_bench_line_keeps_the_contract():
     assert cfg["launch"] == "hipgraph" and "model" not in cfg
     assert d["value"] == pytest.approx(32 / (d["ms_per_step"] * 1e-3), rel=1e-3)
     assert 1.0 < d["ms_per_step"] < 50.0
+    # the run's own noise bar: 5 blocks of `steps` steps, the headline from the median block
+    assert d["repeats"] == 5 and len(d["ms_per_step_blocks"]) == 5
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert sorted(d["ms_per_step_blocks"])[2] == pytest.approx(d["ms_per_step"], abs=2e-3)
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4) and 0.02 < r["frac"] < 1.0

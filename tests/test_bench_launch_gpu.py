@@ -70,3 +70,52 @@ def test_bench_accumulate_runs_the_flagged_step_with_one_exchange_per_cycle():
     assert out["config"]["accumulate"] == 3 and out["config"]["launch"].startswith("hipgraph+flag-waits"), out["config"]
     assert out["n_gpus"] == 1 and out["value"] == pytest.approx(32 / (out["ms_per_step"] * 1e-3), rel=1e-3)
     print("\n[bench --force-dist --accumulate 3] %.3f ms/step, %s" % (out["ms_per_step"], out["config"]["launch"]))
+
+
+def _rehearsal(n, fail, extra=()):
+    env = dict(os.environ, ICKA_BENCH_BACKEND="gloo", ICKA_BENCH_ONE_GPU="1", ICKA_TEST_FAIL_CAPTURE=fail)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                        "--repeats", "2", "--no-cpu-baseline", "--no-roofline", "--no-optimizer-leg", "--no-eager-leg"] + list(extra),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = p.stderr.decode("utf-8", "replace")
+    assert p.returncode == 0, err[-6000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, (lines, err[-2000:])
+    return json.loads(lines[0]), err
+
+
+def test_ranks_agree_on_the_capture_form_when_one_of_them_cannot_capture():
+    """VERDICT r04 item 1 (the abort recorded in round 4: rank 1's capture failed, rank 0 went on into a form whose construction
+    issues collectives, rank 1 into a vote taken as a collective -> gloo 'collective mismatch', rank 1 exit -6).  Now every form's
+    constructor captures in a phase WITHOUT process-group traffic and the ranks vote over the c10d store before anyone uses the
+    result: rank 1 alone fails the segmented capture (ICKA_TEST_FAIL_CAPTURE=rank1:segmented, raised inside the capture after
+    kernels were recorded), BOTH ranks drop that form and build the next one together, and the run completes."""
+    out, err = _rehearsal(2, "rank1:segmented")
+    assert out["config"]["launch"] == "hipgraph(compute)+eager-allreduce", out["config"]
+    assert "this rank could not capture the step" in err and "another rank could not capture the step" in err, err[-3000:]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["repeats"] == 2 and len(out["ms_per_step_blocks"]) == 2
+    assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    print("\n[rank 1 cannot capture the segmented step] both ranks ran: %s" % out["config"]["launch"])
+
+
+def test_ranks_fall_back_to_eager_together_when_one_of_them_cannot_capture_anything():
+    out, err = _rehearsal(2, "rank1:segmented+step")
+    assert out["config"]["launch"] == "eager", out["config"]
+    assert "compute-only capture failed on this rank" in err and "compute-only capture failed on another rank" in err, err[-3000:]
+
+
+def test_flagged_capture_failure_over_rccl_falls_back_to_segments():
+    """World 1 over RCCL (--force-dist): the flagged capture fails (on all ranks = the one rank), the segmented form is built."""
+    env = dict(os.environ, ICKA_TEST_FAIL_CAPTURE="all:flagged")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--repeats", "1", "--no-cpu-baseline", "--no-roofline", "--no-optimizer-leg", "--no-eager-leg"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = p.stderr.decode("utf-8", "replace")
+    assert p.returncode == 0, err[-4000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1])
+    assert out["config"]["launch"].startswith("hipgraph-segments("), out["config"]
+    assert "flagged capture not taken" in err

@@ -328,3 +328,97 @@ def test_row_sparse_word_embedding_exchange_equals_the_dense_mean(tmp_path, worl
             assert res[kind]["row0"] == 0.0 and res[kind]["dense_ok"], res
         assert res["sparse"]["stats"]["sparse"] >= 2 and res["sparse"]["stats"]["dense_fallback"] == 0, res
         assert res["dense_fallback"]["stats"]["dense_fallback"] >= 2, res
+
+
+def _agree_worker(rank, world, port, tmp):
+    """dp.all_ranks_gather / all_ranks_agree: the vote that decides which form of a step ALL ranks build.
+    It runs over the c10d store, so it pairs correctly even while the ranks' collective streams are at different points: here
+    rank 0 has an all-reduce IN FLIGHT (async, not yet matched by rank 1) when both vote."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from icka_amd.dp import all_ranks_agree, all_ranks_gather
+    out = {}
+    out["gather"] = all_ranks_gather(10 + rank, what="test")
+    pending = dist.all_reduce(torch.ones(4), async_op=True) if rank == 0 else None      # unmatched so far on rank 1
+    out["one_fails"] = all_ranks_agree(rank != 1, what="capture")                        # rank 1 "could not capture"
+    out["all_ok"] = all_ranks_agree(True, what="capture")
+    if rank != 0:
+        pending = dist.all_reduce(torch.ones(4), async_op=True)                           # now the collective pairs up
+    pending.wait()
+    out["strings"] = all_ranks_gather("r%d" % rank)
+    torch.save(out, os.path.join(tmp, "a%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_vote_over_the_store_not_over_a_collective(tmp_path, world):
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), "a%d.pt" % r))
+        assert res["gather"] == [10 + i for i in range(world)], res
+        assert res["one_fails"] is False and res["all_ok"] is True, res       # every rank sees the same verdict
+        assert res["strings"] == ["r%d" % i for i in range(world)], res
+
+
+def _sparse_dense_write_worker(rank, world, port, tmp):
+    """GradReducer(sparse_embeddings=True) with an embedding backward that does NOT know the row path (the
+    fp32-exact mode, the prompt embeddings): the word table's slot is written densely and no rows are registered -- the slot must
+    still be averaged (dense all-reduce of the slot), never left local.  Also: ragged row counts raise on every rank, and a second
+    set of rows before the first was exchanged raises."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from icka_amd.dp import GradReducer
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.word = torch.nn.Embedding(96, 16, padding_idx=0)
+            self.lin = torch.nn.Linear(16, 16)
+
+    model = Tiny()
+    arena = ParamArena(model)
+    red = GradReducer(arena, bucket_mb=1e-4, sparse_embeddings=True)
+    assert red.sparse_word is arena.slot(model.word.weight)
+    arena.reducer = red
+    out = {}
+    for step in range(2):
+        for p in model.parameters():
+            p.grad = None
+        for s in reversed(arena.order):
+            arena.grad_beta(s.param)
+            arena.g(s.param).fill_(float(rank + 1))            # dense write, also into the word table; no set_sparse_rows
+            arena.flush_final()
+        red.finish()
+        out["word_mean_%d" % step] = arena.g(model.word.weight).mean().item()
+        out["lin_mean_%d" % step] = arena.g(model.lin.weight).mean().item()
+    out["stats"] = dict(red.sparse_stats)
+    # ragged row counts: rank r brings 4 + r rows
+    rows = torch.zeros(4 + rank, 16)
+    ids = torch.ones(4 + rank, dtype=torch.int64)
+    red.set_sparse_rows(rows, ids)
+    try:
+        red.set_sparse_rows(rows, ids)
+        out["pending_raises"] = False
+    except RuntimeError as e:
+        out["pending_raises"] = "have not been exchanged" in str(e)
+    try:
+        red.exchange_sparse()
+        out["ragged_raises"] = False
+    except RuntimeError as e:
+        out["ragged_raises"] = "different numbers of token rows" in str(e)
+    torch.save(out, os.path.join(tmp, "w%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_sparse_reducer_averages_a_densely_written_word_table_and_refuses_ragged_rows(tmp_path):
+    world = 2
+    mp.spawn(_sparse_dense_write_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), "w%d.pt" % r))
+        for step in range(2):
+            assert abs(res["word_mean_%d" % step] - 1.5) < 1e-6 and abs(res["lin_mean_%d" % step] - 1.5) < 1e-6, res
+        assert res["stats"].get("dense_slot", 0) >= 2, res
+        assert res["pending_raises"] and res["ragged_raises"], res

@@ -120,6 +120,12 @@ def test_graphed_module_exchanges_behind_backward(tmp_path, acc, comm, bar):
     print("\n[GraphedModule(reducer=, accumulate=%d), %s buckets] worst gradient rel-L2 vs eager sum %.3e; step word after each "
           "backward %s; captures %s" % (acc, comm, res["worst"], res["step_words"], res["captures"]))
     assert res["worst"] < bar and res["error_word"] == 0, res
+    # a batch of another shape: captured on first sight (cache entry 2 of 2); the next new shape runs eagerly with the exchange
+    # behind backward -- both equal the eager step
+    print("    other batch shapes vs eager: captured %.3e, eager fallback %.3e; %s" % (res["other_shapes"]["captured"],
+                                                                                    res["other_shapes"]["eager"], res["stats"]))
+    assert res["other_shapes"]["captured"] < bar and res["other_shapes"]["eager"] < bar, res
+    assert res["n_captures"] == 2 and res["stats"]["eager_calls"] == 2 * acc, res
     if acc == 1:
         assert res["step_words"] == [1, 2, 3, 4, 4], res
         assert res["captures"] == [(False, True), (True, True)], res

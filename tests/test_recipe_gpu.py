@@ -141,7 +141,10 @@ def test_accumulated_gradients_equal_the_sum_of_micro_batches():
     gs.close()
 
 
-def test_refresh_checks_shapes_dtypes_and_arity():
+def test_other_shapes_are_captured_on_first_sight_and_arity_is_checked():
+    """A batch of another shape (the short last batch of an epoch, My_cross_attention.py:708) gets a capture of its own the first
+    time it is seen and replays it afterwards; past ``max_captures`` the call runs ``step_fn`` eagerly -- in both cases the
+    loss and the gradients of the eager step, never an exception.  Wrong arity stays a TypeError (a wrong call, not a new shape)."""
     from icka_amd.graph import GraphedStep
     model = _model("bf16")
     b = _batches(1)[0]
@@ -151,13 +154,25 @@ def test_refresh_checks_shapes_dtypes_and_arity():
         loss.backward()
         return loss
 
-    gs = GraphedStep(model, micro, inputs=b, warmup=1)
-    with pytest.raises(ValueError, match="static shapes"):
-        gs(*(t[:2] for t in b))
-    with pytest.raises(ValueError, match="static shapes"):
-        gs(*([b[0].int()] + list(b[1:])))
+    small = tuple(t[:2].contiguous() for t in b)
+    model.zero_grad()
+    ref = micro(*small).item()
+    gref = model.classifier.weight.grad.clone()
+    gs = GraphedStep(model, micro, inputs=b, warmup=1, max_captures=2)
+    model.zero_grad()
+    assert gs(*small).item() == pytest.approx(ref, rel=1e-6)          # first sight: captured (2 of 2)
+    assert torch.allclose(model.classifier.weight.grad, gref, rtol=1e-4, atol=1e-7)
+    model.zero_grad()
+    assert gs(*small).item() == pytest.approx(ref, rel=1e-6) and gs.stats["captures"] == 2 and gs.captures == 2
+    one = tuple(t[:1].contiguous() for t in b)
+    model.zero_grad()
+    l_one = gs(*one).item()                                           # a third shape: past the cap -> eager
+    assert gs.stats["eager_calls"] == 1 and gs.captures == 2
+    model.zero_grad()
+    assert micro(*one).item() == pytest.approx(l_one, rel=1e-6)
     with pytest.raises(TypeError):
         gs(*b[:-1])
+    model.zero_grad()
     l0 = gs(*b).item()
     l1 = gs(b).item()                 # a single tuple is unpacked
     assert l0 == l1
@@ -185,7 +200,7 @@ def test_graphed_module_keeps_the_reference_loop_body(precision, bar):
     they are and replay a forward and a backward hipGraph.  The recipe of this file (5 micro-batches of different inputs,
     loss / 5 applied OUTSIDE the wrapper, clip, AdamW, schedule, zero_grad) eager vs wrapped: same losses and parameters; a
     no_grad call replays the forward only; zero_grad between forward and backward is honoured; the other train / eval mode and
-    another call signature raise."""
+    another call signature get captures of their own."""
     from icka_amd.graph import GraphedModule
     base = _model(precision)
     batches = _batches(K_ACC * OPT_STEPS)
@@ -223,11 +238,14 @@ def test_graphed_module_keeps_the_reference_loop_body(precision, bar):
     loss = gm(*b[:6], labels=b[6])
     loss.backward()                                             # gradients still held: accumulates
     assert torch.allclose(gm.model.classifier.weight.grad, 2 * g1, rtol=1e-3, atol=1e-7)
-    with pytest.raises(TypeError):
-        gm(*b[:6])
+    # another call signature (no labels -> logits) and the other train / eval mode: captures of their own, no exception
+    n0 = gm.captures
+    logits = gm(*b[:6])
+    assert logits.shape == (4, 32, 13) and gm.captures == n0 + 1
+    assert torch.allclose(logits, gm.model(*b[:6]), rtol=0, atol=bar * 10)
     gm.model.train()
-    with pytest.raises(RuntimeError, match="eval mode"):
-        gm(*b[:6], labels=b[6])
+    lt = gm(*b[:6], labels=b[6])
+    assert torch.isfinite(lt).item() and gm.captures == n0 + 2
     gm.close()
 
 
@@ -266,8 +284,10 @@ def test_device_prefetcher_feeds_the_captured_step_in_order(pinned):
         fed.append(gs(*b).item())
     assert fed == direct and len(set(fed)) > 1
     gs.close()
-    with pytest.raises(ValueError, match="shapes"):
-        list(DevicePrefetcher([host[0], tuple(t[:2] for t in host[1])], "cuda"))
+    # the short last batch of an epoch (no drop_last, :708) passes through with buffers of its own
+    ragged = [host[0], tuple(t[:2] for t in host[1]), host[2]]
+    for got, want in zip(DevicePrefetcher(ragged, "cuda"), ragged):
+        assert all(torch.equal(g.cpu(), w) for g, w in zip(got, want))
     with pytest.raises(ValueError, match="arity"):
         list(DevicePrefetcher([host[0], host[1][:-1]], "cuda"))
     with pytest.raises(ValueError):
