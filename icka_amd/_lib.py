@@ -15,8 +15,10 @@ LIB_PATH = os.path.join(_HERE, "libicka_hip.so")
 
 c_vp, c_i32, c_i64, c_u64, c_f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
-ABI_VERSION = 5   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
+ABI_VERSION = 6   # include/icka_hip.h: ICKA_ABI_VERSION (load() refuses a library built from another header)
 GEMM_NT, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3
+ATTN_FP8, ATTN_TILED = 1, 2                               # flags of icka_attn_fwd_ex / icka_attn_bwd
+LSTM_PER_STEP, LSTM_TICKETS, LSTM_NO_BATCH_SPLIT = 1, 2, 4   # flags of icka_lstm_fwd / icka_lstm_bwd
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_GATE, EPI_TANH, EPI_RELU, EPI_ADD_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -34,6 +36,7 @@ class GemmDesc(C.Structure):
         ("epilogue", c_i32),
         ("colsum_out", c_vp), ("colsum_accumulate", c_i32),
         ("ab_f16", c_i32), ("C3", c_vp), ("ldc3", c_i64), ("aux_f16", c_i32), ("c3_only", c_i32),
+        ("tune", c_u64),
     ]
 
 
@@ -60,22 +63,10 @@ class XGemmDesc(C.Structure):
 PROTOTYPES = {
     "icka_abi_version": (c_i32, []),
     "icka_copy_many": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
-    "icka_ln_set_rows_per_wave": (c_i32, [c_i32]),
     "icka_build_arch": (C.c_char_p, []),
     "icka_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "icka_gemm_grouped": (c_i32, [C.POINTER(GemmDesc), c_i32, c_vp]),
     "icka_gemm_grouped_ex": (c_i32, [C.POINTER(GemmDesc), c_i32, C.POINTER(SlabReduction), c_i32, c_vp]),
-    "icka_gemm_set_ring": (c_i32, [c_i32]),
-    "icka_gemm_set_tile_n": (c_i32, [c_i32]),
-    "icka_gemm_set_wide_tiles": (c_i32, [c_i32]),
-    "icka_gemm_set_persistent": (c_i32, [c_i32]),
-    "icka_gemm_set_square_tiles": (c_i32, [c_i32]),
-    "icka_gemm_set_direct_epilogue": (c_i32, [c_i32]),
-    "icka_gemm_set_big_tiles": (c_i32, [c_i32]),
-    "icka_gemm_set_ablation": (c_i32, [c_i32]),
-    "icka_gemm_set_warp_specialized": (c_i32, [c_i32]),
-    "icka_gemm_set_w3_grid": (c_i32, [c_i32]),
-    "icka_gemm_set_stamp_buffer": (c_i32, [c_vp]),
     "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
                             c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
     "icka_ln_fwd_h": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
@@ -103,7 +94,6 @@ PROTOTYPES = {
     "icka_attn_keepbits_words": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "icka_attn_fwd_fp8": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                               c_i32, c_f32, c_f32, c_u64, c_vp]),
-    "icka_attn_set_whole_head": (None, [c_i32]),
     "icka_cls_head_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_cls_head_fwd_h": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_cls_head_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
@@ -117,11 +107,8 @@ PROTOTYPES = {
     "icka_conv_subsample": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "icka_conv_maxpool3x3s2": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "icka_conv_features_out": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "icka_lstm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "icka_lstm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "icka_lstm_set_persistent": (c_i32, [c_i32]),
-    "icka_lstm_set_handoff": (c_i32, [c_i32]),
-    "icka_lstm_set_batch_split": (c_i32, [c_i32]),
+    "icka_lstm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "icka_lstm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "icka_lstm_barrier_error": (c_i32, []),
     "icka_lstm_clear_error": (c_i32, []),
     "icka_lstm_set_reserved_cus": (c_i32, [c_i32]),
@@ -134,7 +121,7 @@ PROTOTYPES = {
     "icka_crf_decode": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "icka_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
-                              c_vp, c_vp]),
+                              c_vp, c_i32, c_vp]),
     "icka_cast_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "icka_cast_to_f16": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp]),
     "icka_cast_f32_to_bf16_f16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -861,8 +861,11 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
                 const float pv = __expf(sc[r] * a.scale + mkv[r] - lse_q);   // mask -inf (key >= Skv) -> exactly 0
                 float dm;
                 if constexpr (DROP_BITS) {
+                    // bit -> all-ones / zero by ONE signed bit-field extract (the position is a compile-time constant of the
+                    // unrolled loops), AND with the bits of 1 / (1 - p): two vector operations per element where shift, and,
+                    // compare and select took ~4 (profiles/r04_attn_bwd_stamps.txt: 7.9 k of phase A's 49 k cycles at c4)
                     const int bit = (qi * KT + kt) * 4 + r;
-                    dm = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? a.drop.scale : 0.f;
+                    dm = __uint_as_float(__float_as_uint(a.drop.scale) & (uint32_t)__builtin_amdgcn_sbfe((int)dbits[bit >> 5], bit & 31, 1));
                 } else {
                     dm = dm4[r];
                 }
@@ -947,7 +950,8 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int bit = (qi * KT + kt) * 4 + r;
-                                pd4[r] = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? bf2f(pb[r]) * a.drop.scale : 0.f;
+                                pd4[r] = bf2f(pb[r]) * __uint_as_float(__float_as_uint(a.drop.scale) &
+                                                                       (uint32_t)__builtin_amdgcn_sbfe((int)dbits[bit >> 5], bit & 31, 1));
                             }
                             val = pack4(pd4[0], pd4[1], pd4[2], pd4[3]);
                         }
@@ -1066,15 +1070,13 @@ static bool try_small(const AttnArgs& a, int mode, hipStream_t st) {
 inline bool ok16(const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; }
 
 #ifdef ICKA_ATTN_STAMP
-unsigned long long* g_attn_stamp = nullptr;
+unsigned long long* g_attn_stamp = nullptr;   // diagnostic builds only (tools/attn_stamp.py)
 #endif
-int g_small = 1;   // icka_attn_set_whole_head: 0 forces the tiled kernels (tests exercise both)
 
 }  // namespace
 
-extern "C" void icka_attn_set_whole_head(int32_t on) { g_small = on ? 1 : 0; }
 #ifdef ICKA_ATTN_STAMP
-extern "C" void icka_attn_set_stamp_buffer(void* p) { g_attn_stamp = (unsigned long long*)p; }
+extern "C" void icka_diag_attn_stamp_buffer(void* p) { g_attn_stamp = (unsigned long long*)p; }
 #endif
 
 extern "C" int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
@@ -1088,7 +1090,7 @@ extern "C" int icka_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
     a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
     a.mask = add_mask; a.Ow = (bf16_t*)O; a.ldo = ldo; a.lse = lse;
     a.B = B; a.h = heads; a.Sq = Sq; a.Skv = Skv; a.scale = scale; a.drop = make_drop(p_drop, seed);
-    if (g_small && try_small(a, 0, (hipStream_t)stream)) {
+    if (try_small(a, 0, (hipStream_t)stream)) {
         ICKA_CHECK_LAUNCH();
         return 0;
     }
@@ -1115,12 +1117,16 @@ extern "C" int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int6
 }
 
 // Forward with an additional fp16 copy of the context ("mixed16": fp16 operand of the out-proj GEMM; the bf16 copy stays
-// the operand of the weight-gradient GEMM and of the attention backward).  fp8 != 0 selects the fp8 QK^T / PV form.
+// the operand of the weight-gradient GEMM and of the attention backward).  flags: ICKA_ATTN_FP8 selects the fp8 QK^T / PV
+// form, ICKA_ATTN_TILED forces the tiled flash-style kernels for every shape (per call: no process-wide switch).
 extern "C" int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                                 const float* add_mask, void* O, void* O_f16, int64_t ldo, float* lse, int32_t B,
                                 int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed,
-                                int32_t fp8, void* keep_bits, void* stream) {
+                                int32_t flags, void* keep_bits, void* stream) {
     if (!Q || !K || !V || !add_mask || !O) return ICKA_E_ARG;
+    if (flags & ~(ICKA_ATTN_FP8 | ICKA_ATTN_TILED)) return ICKA_E_ARG;
+    const bool fp8 = (flags & ICKA_ATTN_FP8) != 0, tiled = (flags & ICKA_ATTN_TILED) != 0;
+    if (fp8 && tiled) return ICKA_E_ARG;    // the fp8 form exists as a whole-head kernel only
     if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) return ICKA_E_SHAPE;
     if (fp8 && (Sq > 128 || Skv > 128)) return ICKA_E_SHAPE;
     if ((int64_t)B * heads * Sq * Skv >= (1ll << 32)) return ICKA_E_SHAPE;
@@ -1135,7 +1141,7 @@ extern "C" int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64
         ICKA_CHECK_LAUNCH();
         return 0;
     }
-    if (g_small && try_small(a, 0, (hipStream_t)stream)) {
+    if (!tiled && try_small(a, 0, (hipStream_t)stream)) {
         ICKA_CHECK_LAUNCH();
         return 0;
     }
@@ -1160,8 +1166,9 @@ extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              const float* add_mask, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                              const float* lse, float* delta, void* dQ, int64_t lddq, void* dK, int64_t lddk,
                              void* dV, int64_t lddv, int32_t B, int32_t heads, int32_t Sq, int32_t Skv, float scale,
-                             float p_drop, uint64_t seed, const void* keep_bits, void* stream) {
+                             float p_drop, uint64_t seed, const void* keep_bits, int32_t flags, void* stream) {
     if (!Q || !K || !V || !add_mask || !O || !dO || !lse || !delta || !dQ || !dK || !dV) return ICKA_E_ARG;
+    if (flags & ~ICKA_ATTN_TILED) return ICKA_E_ARG;
     if (B <= 0 || heads <= 0 || Sq <= 0 || Skv <= 0) return ICKA_E_SHAPE;
     if ((int64_t)B * heads * Sq * Skv >= (1ll << 32)) return ICKA_E_SHAPE;
     if (!ok16(Q, ldq) || !ok16(K, ldk) || !ok16(V, ldv) || !ok16(O, ldo) || !ok16(dO, lddo) || !ok16(dQ, lddq) ||
@@ -1178,7 +1185,7 @@ extern "C" int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
 #ifdef ICKA_ATTN_STAMP
     a.stamp = g_attn_stamp;
 #endif
-    if (g_small && try_small(a, 1, st)) {
+    if (!(flags & ICKA_ATTN_TILED) && try_small(a, 1, st)) {
         ICKA_CHECK_LAUNCH();
         return 0;
     }

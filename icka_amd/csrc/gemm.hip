@@ -43,7 +43,7 @@ struct GemmArgs {
     float* colsum; int colsum_acc;  // TN fast path: colsum[m] (+)= sum_k A[k,m] (bias gradient fused into dW = dY^T.X)
     int n96ok;                  // fast path + N % 96 == 0: the 128x96 tile is an option
     int n64ok;                  // everything aligned except N % 128: N % 64 == 0 -> the 128x64 tile (NT only)
-    int direct;                 // plain outputs skip the LDS-staged epilogue (icka_gemm_set_direct_epilogue)
+    int direct;                 // plain outputs skip the LDS-staged epilogue (Tune::direct)
     unsigned long long* stamp;  // diagnostic: [block][8] cycle sums (ICKA_GEMM_STAMP builds)
     int ksplit;        // general path: blockIdx.y splits the k-tiles; partial sums are atomically added to f32 C
     int f16;           // operands are IEEE fp16 (v_mfma_f32_16x16x32_f16; NT only): the "mixed16" forward GEMMs
@@ -56,7 +56,7 @@ struct GemmArgs {
     int c3_only;       // f32 C + C3 + beta == 0: write ONLY the bf16 wire copy C3 (the f32 value is produced later, from the
                        // reduced wire buffer, by icka_dp_cast_back_scaled): the epilogue stores 2 bytes per element, not 4 + 2
     int plain;         // the MAIN 16-bit output is stored with ordinary stores instead of streaming ones (st_main): per launch,
-                       // from icka_gemm_desc.store_plain or the diagnostic site mask ICKA_GEMM_PLAIN_MASK (site_bit)
+                       // from the diagnostic site mask ICKA_GEMM_PLAIN_MASK (site_bit)
     // implicit 3x3 / pad 1 convolution (icka_conv3x3_gemm): A is an NHWC activation [B, cvH, cvW, cvC], the A "row" m is
     // output pixel m and the reduction index is k = tap * cvC + c -- the loader waves compute the patch addresses, no
     // patch matrix exists.  cvZero: at least 128 B of zeros for the taps that fall off the image / rows past cvRows.
@@ -492,7 +492,7 @@ __device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
     for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
     st_out(reinterpret_cast<u32x4*>(p), as_u32x4(o));
 }
-// MAIN activation output with a per-launch store policy (GemmArgs.plain, icka_gemm_desc.store_plain): plain = an ordinary
+// MAIN activation output with a per-launch store policy (GemmArgs.plain: the ICKA_GEMM_PLAIN_MASK diagnostic): plain = an ordinary
 // store, the line stays in the L2 / Infinity Cache for the consumer kernel; else the streaming store of st_out
 template <typename T>
 __device__ __forceinline__ void st_main(T* p, const T v, int plain) {
@@ -549,11 +549,9 @@ __device__ __forceinline__ void tile_origin(int bid, int nb, int nbm, int nbn, i
 // WIRE: the instance may be asked for the data-parallel wire copy of an f32 output (C3 / c3_only): weight-gradient (TN)
 // instances only -- compiled out everywhere else (as a run-time test in every instance it cost the 12-wave kernels, which run
 // at their register cap, 5 % and showed up in kernels that never see a wire copy)
-// ROWS: rows of the staged tile (128; 64 for the passes of gemm_sq_kernel).  PREB: the bias of the thread's 8 columns was loaded
-// by the caller (``pre``) -- gemm_sq_kernel keeps the epilogue free of loads while the next tile's LDS-DMA is in flight.
-template <int RSTEP, int NC8 = 16, int WIDE = 0, bool WIRE = false, int ROWS = 128, bool PREB = false>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid,
-                                              const float* pre = nullptr) {
+template <int RSTEP, int NC8 = 16, int WIDE = 0, bool WIRE = false>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* smem, int m0, int n0, int tid) {
+    constexpr int ROWS = 128;   // rows of the staged tile
     // NC8 = 8-column groups per tile row: 16 (128-wide tile), 12 (96-wide: 384 of 512 threads) or 24 (192-wide, 768 threads)
     if (tid >= RSTEP * NC8) return;
     const int c8 = NC8 == 16 ? (tid & 15) : tid % NC8;   // 8-column group of the row
@@ -561,13 +559,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
     const int n = n0 + 8 * c8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = PREB ? pre[e] : 0.f;
-    if (!PREB && g.bias) {
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (g.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
     }
-    if (!PREB && g.bias2) {
+    if (g.bias2) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias2 + n), b1 = *reinterpret_cast<const f32x4*>(g.bias2 + n + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias[e] += b0[e]; bias[4 + e] += b1[e]; }
@@ -582,8 +580,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
 #pragma unroll
     for (int i = 0; i < NROW; ++i) {
         const int row = rb + RSTEP * i;
-        const int m = (WIDE == 1 || WIDE == 2) ? m0 + ((row >> 5) << 6) + (row & 31)
-                      : ((WIDE == 4 || WIDE == 5) ? m0 + ((row >> 4) << 6) + (row & 15) : m0 + row);
+        const int m = (WIDE == 1 || WIDE == 2) ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
         araw[i] = u32x4{0u, 0u, 0u, 0u};
         if (use_aux) araw[i] = ld_once(reinterpret_cast<const u32x4*>(g.aux + (int64_t)m * g.ldaux + n));
     }
@@ -593,14 +590,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, const char* sme
     for (int i = 0; i < ROWS / RSTEP; ++i) {
         const int row = rb + RSTEP * i;
         // WIDE: the staged tile holds 32-row slabs of four 64-row wave tiles (gemm_w3_kernel): slab q -> rows 64 q + 0..31
-        // (3: 192-wide image, plain rows; 4 / 5: 16-row slabs of four 64-row wave tiles, 192- / 128-wide image: gemm_w3p_kernel)
-        const int m = (WIDE == 1 || WIDE == 2) ? m0 + ((row >> 5) << 6) + (row & 31)
-                      : ((WIDE == 4 || WIDE == 5) ? m0 + ((row >> 4) << 6) + (row & 15) : m0 + row);
+        const int m = (WIDE == 1 || WIDE == 2) ? m0 + ((row >> 5) << 6) + (row & 31) : m0 + row;
         const u32x4 acur = araw[0];   // (constant indices: the queue stays in registers when the loop is rolled)
 #pragma unroll
         for (int q = 0; q + 1 < NROW; ++q) araw[q] = araw[q + 1];
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + ((WIDE == 1 || WIDE == 3 || WIDE == 4) ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + ((WIDE == 1 || WIDE == 3 || WIDE == 4) ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8) : off_c(row, 2 * c8)));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + (WIDE == 1 ? off_cw(row, 2 * c8 + 1) : off_c(row, 2 * c8 + 1)));
         float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
                       hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
         float a[8];
@@ -1256,20 +1251,62 @@ __global__ __launch_bounds__(256) void gemm_dma_group_kernel(const GroupArgs ga)
 }
 
 
-int g_abl = 0;
-unsigned long long* g_stamp = nullptr;
-int g_ws = 1;  // warp-specialised (loader + compute waves) fast path  // diagnostic build only (ICKA_GEMM_STAMP): per-segment cycle sums
-int g_direct = 1;  // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
-int g_sq = [] { const char* e = getenv("ICKA_GEMM_SQ"); return e ? atoi(e) : 0; }();   // (env: same-box A/B)
-// 256x256 tiles of the 8-wave load+compute kernel: OFF by default (icka_gemm_set_square_tiles; 96 vs 99 us
-                 // at 8192 x 4096 x 1024 cold, ahead only from K = 2048 on, where no shape of the path qualifies)
-int g_w3p = [] { const char* e = getenv("ICKA_GEMM_W3P"); return e ? atoi(e) : 0; }();   // (env: same-box A/B)
-// persistent form of the 12-wave kernel (icka_gemm_set_persistent), OFF by default: 1 = for the 256x128 tile where an output has
-// whole multiples of 256 tiles and K <= 1024 (bert-large ffn-up / d(ffn-down): 92 vs 99 us stand-alone, but the c4 STEP is
-// 2.6 % slower with it: profiles/NEGATIVE_RESULTS.md), 2 = also 256x192 (tests; 69 vs 65 us)
-int g_w3 = 1;    // 256x192 tiles for wide / short-K outputs (icka_gemm_set_wide_tiles)
-int g_bn = 0;    // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced (icka_gemm_set_tile_n)
-int g_nbuf = 0;  // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 / 3 / 4 (icka_gemm_set_ring)
+// ---- launch-heuristic overrides.  NO mutable process state (launchers are re-entrant and do not rely on
+// hidden state; the autograd thread and a second model see exactly what the first one does): kTuneEnv is the ICKA_TUNE_GEMM_*
+// environment read ONCE when the library is loaded (same-box A/B runs: tools/ab_env.sh), and a single launch may override fields
+// through icka_gemm_desc.tune (tests of the alternative kernels, tools/gemm_*.py).  Results never depend on any of it.
+struct Tune {
+    int abl;      // diagnostic builds (-DICKA_GEMM_ABLATE): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging (wrong results)
+    int ws;       // 1: warp-specialised fast path (two blocks per CU for large grids), 0: single-role kernel, 2: force two blocks, 3: never two
+    int direct;   // 1: plain outputs are stored straight from the accumulators (0: always through the LDS C tile)
+    int w3;       // 1: 256x192 / 256x128 tiles (12-wave kernel) for wide / short-K outputs
+    int bn;       // tile width of the warp-specialised path: 0 = heuristic, 128 / 96 forced
+    int nbuf;     // LDS ring depth of the fast path: 0 = per-shape heuristic, or forced 2 .. 5
+    int w3grid;   // XCD cut of the 12-wave kernel's tile grid: 0 = per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
+    int big;      // grouped TN launches: 2 = 256x128 tiles / 12 waves, 1 = 8 waves, 0 = 128x128 group kernel
+};
+static int tune_env_int(const char* name, int dflt, int lo, int hi) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo || v > hi ? dflt : v;
+}
+static const Tune kTuneEnv = [] {
+    Tune t;
+    t.abl = tune_env_int("ICKA_TUNE_GEMM_ABLATION", 0, 0, 3);
+    t.ws = tune_env_int("ICKA_TUNE_GEMM_WARP_SPECIALIZED", 1, 0, 3);
+    t.direct = tune_env_int("ICKA_TUNE_GEMM_DIRECT_EPILOGUE", 1, 0, 1);
+    t.w3 = tune_env_int("ICKA_TUNE_GEMM_WIDE_TILES", 1, 0, 1);
+    t.bn = tune_env_int("ICKA_TUNE_GEMM_TILE_N", 0, 0, 128);
+    if (t.bn != 0 && t.bn != 96 && t.bn != 128) t.bn = 0;
+    t.nbuf = tune_env_int("ICKA_TUNE_GEMM_RING", 0, 0, 5);
+    if (t.nbuf == 1) t.nbuf = 0;
+    t.w3grid = tune_env_int("ICKA_TUNE_GEMM_W3_GRID", 0, 0, 8);
+    if (t.w3grid != 0 && t.w3grid != 1 && t.w3grid != 2 && t.w3grid != 4 && t.w3grid != 8) t.w3grid = 0;
+    t.big = tune_env_int("ICKA_TUNE_GEMM_BIG_TILES", 2, 0, 2);
+    return t;
+}();
+// icka_gemm_desc.tune (include/icka_hip.h, ICKA_TUNE_*): 4 bits per field, 0 = keep the default, else the field's code.
+// Returns false for a code outside a field's range (-> ICKA_E_ARG).
+static bool tune_of(uint64_t bits, Tune& t) {
+    t = kTuneEnv;
+    if (!bits) return true;
+    const int ring = (int)(bits & 15), tile = (int)((bits >> 4) & 15), wide = (int)((bits >> 8) & 15), dir = (int)((bits >> 12) & 15),
+              ws = (int)((bits >> 16) & 15), grid = (int)((bits >> 20) & 15), big = (int)((bits >> 24) & 15), abl = (int)((bits >> 28) & 15);
+    if (bits >> 32) return false;
+    if (ring) { if (ring < 2 || ring > 5) return false; t.nbuf = ring; }
+    if (tile) { if (tile > 2) return false; t.bn = tile == 1 ? 96 : 128; }
+    if (wide) { if (wide > 2) return false; t.w3 = wide - 1; }
+    if (dir) { if (dir > 2) return false; t.direct = dir - 1; }
+    if (ws) { if (ws > 4) return false; t.ws = ws - 1; }
+    if (grid) { if (grid != 1 && grid != 2 && grid != 4 && grid != 8) return false; t.w3grid = grid; }
+    if (big) { if (big > 3) return false; t.big = big - 1; }
+    if (abl) { if (abl > 3) return false; t.abl = abl; }
+    return true;
+}
+#ifdef ICKA_GEMM_STAMP
+static unsigned long long* g_stamp = nullptr;   // diagnostic build only: per-segment cycle sums (icka_diag_gemm_stamp_buffer)
+#endif
 
 __global__ void scale_c_kernel(float* C, int64_t ldc, int M, int N, float beta) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1410,346 +1447,16 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
-// =====================================================================================================================
-// PERSISTENT form of the 12-wave kernel for outputs of more than one tile per CU (M = 8192: bert-large / batch-64 shapes).
-// One block per CU walks tiles b, b + grid, ...  What it buys: a tile's epilogue (LDS passes + a store burst of the whole
-// chip: 33 - 67 MB per round) no longer runs with the matrix pipe idle and the next tile's first loads still to be issued --
-// the LOADER waves, which never store (so their counted vmcnt sees LDS-DMA only), issue the next tile's A(0), B(0), A(1)
-// right after the last k-tile has been read, the compute waves run the epilogue out of ONE A-ring slot (8 passes of 32 rows)
-// and return to a ring that is already filling, and their stores drain under the next tile's MFMAs (compute waves never
-// wait on vmcnt).  Ring slots are numbered continuously across tiles (A: 3 slots, B: 2); the staging slot of a tile's
-// epilogue is the A slot the next tile's first two k-tiles do not use.
-template <bool B_KM, bool F16 = false, int BNW = 192>
-__global__ __launch_bounds__(768) void gemm_w3p_kernel(const GemmArgs gp, const int ntiles) {
-    const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
-    constexpr int BH = BNW / 2, NB16 = BH / 16;
-    static_assert(BNW == 192 || BNW == 128, "tile width");
-    const int nk = g.K / BK;
-    const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block
-    auto origin = [&](int t, int& m0, int& n0) {
-        const int xcd = t & 7, li = t >> 3;
-        const int xi = xcd >> g.w3_pnlog, xj = xcd & ((1 << g.w3_pnlog) - 1);
-        const int r = li / g.w3_sn, c = li - r * g.w3_sn;
-        m0 = (xi * ((ntiles >> 3) / g.w3_sn) + r) * 256;
-        n0 = (xj * g.w3_sn + c) * BNW;
-    };
-    // Every tile numbers its ring from A slot 0 and B slot 1 (after the barrier E0 the whole ring is free): the next tile's
-    // A(0), B(0), A(1) go to A slots 0, 1 and B slot 1, which leaves [A slot 2 | B slot 0] = 64 KiB of CONTIGUOUS LDS for the
-    // epilogue's staging tile (64 rows x 192 or 128 columns of f32).
-    if (wave >= 8) {
-        // ------------------------------------------------------------------------------------------- loader waves
-        const int lw = wave - 8;
-        const bf16_t* pa0[4];
-        const bf16_t* pa1[4];
-        const bf16_t* pb0[4];
-        const bf16_t* pb1[4];
-        const int64_t sa = BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
-        constexpr int NJB = B_KM ? 4 : BH / 32;
-        const uint32_t ldsB = lds0 + W3_NA * W3_A;
-#define ICKA_W3P_A(SLOT)                                                         \
-    do {                                                                         \
-        dma_issue(pa0, sa, lds0 + (SLOT) * W3_A + lw * 1024);                    \
-        dma_issue(pa1, sa, lds0 + (SLOT) * W3_A + TILE_BYTES + lw * 1024);       \
-    } while (0)
-#define ICKA_W3P_B(SLOT)                                                         \
-    do {                                                                         \
-        dma_issue<NJB>(pb0, sb, ldsB + (SLOT) * W3_B + lw * 1024);               \
-        dma_issue<NJB>(pb1, sb, ldsB + (SLOT) * W3_B + TILE_BYTES + lw * 1024);  \
-    } while (0)
-#define ICKA_W3P_FIRST(T)                                                        \
-    do {                                                                         \
-        int m0_, n0_;                                                            \
-        origin((T), m0_, n0_);                                                   \
-        dma_init<false>(pa0, g.A, g.lda, m0_, lw, lane);                         \
-        dma_init<false>(pa1, g.A, g.lda, m0_ + 128, lw, lane);                   \
-        dma_init<B_KM, BH>(pb0, g.B, g.ldb, n0_, lw, lane);                      \
-        dma_init<B_KM, BH>(pb1, g.B, g.ldb, n0_ + BH, lw, lane);                 \
-        ICKA_W3P_A(0);                                                           \
-        ICKA_W3P_B(1);                                                           \
-        if (nk > 1) ICKA_W3P_A(1);                                               \
-    } while (0)
-        ICKA_W3P_FIRST((int)blockIdx.x);
-        for (int i = 0; i < ntl; ++i) {
-            int sa3 = 2;   // A slot of k-tile kt + 2
-            for (int kt = 0; kt < nk; ++kt) {
-                if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();   // A(kt+1) may still be in flight (8 pieces)
-                __builtin_amdgcn_s_barrier();        // k-tile kt published; every compute wave is done with k-tile kt-1
-                if (kt + 1 < nk) ICKA_W3P_B(kt & 1);                     // B(kt+1) -> slot (1 + kt + 1) & 1
-                if (kt + 2 < nk) ICKA_W3P_A(sa3);
-                sa3 = sa3 == 2 ? 0 : sa3 + 1;
-            }
-            __builtin_amdgcn_s_barrier();            // E0: every compute wave has read the tile's last k-tile
-            if (i + 1 < ntl) ICKA_W3P_FIRST((int)blockIdx.x + (i + 1) * (int)gridDim.x);   // under this tile's epilogue
-#pragma unroll 1
-            for (int b = 0; b < 8; ++b) __builtin_amdgcn_s_barrier();   // the compute waves' 4 passes x 2 barriers
-        }
-#undef ICKA_W3P_A
-#undef ICKA_W3P_B
-#undef ICKA_W3P_FIRST
-        return;
-    }
-    // ---------------------------------------------------------------------------------------------- compute waves
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * BH;
-    char* const ctile = smem + 2 * W3_A;       // [A slot 2 | B slot 0]
-    for (int i = 0; i < ntl; ++i) {
-        int m0, n0;
-        origin((int)blockIdx.x + i * (int)gridDim.x, m0, n0);
-        f32x4 acc[4][NB16];
-#pragma unroll
-        for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-            for (int j = 0; j < NB16; ++j) acc[a_][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const char* sA = smem + (kt % W3_NA) * W3_A + (wr >> 7) * TILE_BYTES;
-            const char* sB = smem + W3_NA * W3_A + ((kt + 1) & 1) * W3_B + (wave & 1) * TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[4], fb[NB16];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fa[t] = read_frag<false>(sA, (wr & 127) + 16 * t, ks, lane);
-#pragma unroll
-                for (int t = 0; t < NB16; ++t) fb[t] = read_frag<B_KM>(sB, 16 * t, ks, lane);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NB16; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
-            }
-        }
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // E0 (all 12 waves): the ring's last k-tile is in registers
-        // ---- 4 passes of 64 rows x BNW: in pass j EVERY compute wave deposits the 16-row group j of its 64 x BH tile
-        //      (staged row 16 q + r = tile row 64 q + 16 j + r for wave row q), then the 8 compute waves finish the rows
-#define ICKA_W3P_PASS(J)                                                                                              \
-        do {                                                                                                          \
-            const int row_ = (wave >> 1) * 16 + (lane & 15);                                                          \
-            _Pragma("unroll") for (int ni = 0; ni < NB16; ++ni) {                                                     \
-                const int ch_ = (wc >> 2) + 4 * ni + (lane >> 4);                                                     \
-                *reinterpret_cast<f32x4*>(ctile + (BNW == 192 ? off_cw(row_, ch_) : off_c(row_, ch_))) = acc[J][ni] * g.alpha; \
-            }                                                                                                         \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-            __builtin_amdgcn_s_barrier();                                                                             \
-            asm volatile("" ::: "memory");                                                                            \
-            epilogue_rows<(BNW == 192 ? 16 : 32), BNW / 8, (BNW == 192 ? 4 : 5), false, 64>(g, ctile, m0 + 16 * (J), n0, tid); \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-            __builtin_amdgcn_s_barrier();                  /* staging tile consumed */                                \
-        } while (0)
-        ICKA_W3P_PASS(0);
-        ICKA_W3P_PASS(1);
-        ICKA_W3P_PASS(2);
-        ICKA_W3P_PASS(3);
-#undef ICKA_W3P_PASS
-    }
-}
-
-// =====================================================================================================================
-// 256 x 256 output tiles, 8 waves that ALL load and compute (2 x 4 wave tiles of 128 x 64, two waves per SIMD, 256 registers
-// each), for large outputs with N % 256 == 0 whose tile grid fills whole rounds of the CUs: bert-large's ffn-up and
-// d(ffn-down) (8192 x 4096 x 1024: 512 tiles = two rounds), where the 128 x 128 two-blocks-per-CU kernel measured 758 TFLOP/s
-// against 1211 for the vendor library (profiles/r04_gemm_vs_hipblaslt.txt).  Per FLOP the tile moves half the operand bytes
-// of a 128 x 128 one through L2 -> LDS and through the LDS read port (a wave tile of 128 x 64 reads 24 KiB of fragments per
-// 64-deep k-tile for 64 MFMAs).  LDS: ring of TWO stages of [A rows 0..127 | A rows 128..255 | B 0..127 | B 128..255]
-// (4 x 16 KiB images each, the usual swizzled layouts) = 128 KiB; waves 0-3 stage the first A and B images of a k-tile, waves
-// 4-7 the second ones (8 LDS-DMA instructions per wave and k-tile).  ONE barrier per k-tile, in the middle of it: by then the
-// wave holds all fragments of stage kt & 1 in registers and has waited for its pieces of tile kt + 1, so the barrier both
-// publishes tile kt + 1 and frees the stage for tile kt + 2, whose DMA is issued right behind it and lands under the MFMAs
-// of tile kt + 1; fragment reads always run under the MFMAs of the other register set (as gemm_big_tn_body).  Epilogue: four passes of a
-// 128 x 128 f32 tile through the (dead) ring, finished by all 512 threads in 16-byte row-contiguous accesses (epilogue_rows).
-constexpr int SQ_STAGE = 4 * TILE_BYTES;
-constexpr int SQ_CTILE = 64 * 128 * 4;     // epilogue staging: 64 rows x 128 columns of f32 behind the ring
-// tile t of nb (w3_origin with an explicit tile count: the kernel is persistent, gridDim.x is the number of CUs it runs on)
-__device__ __forceinline__ void sq_origin(int t, int nb, int sn, int pnlog, int& m0, int& n0) {
-    const int xcd = t & 7, li = t >> 3;
-    const int xi = xcd >> pnlog, xj = xcd & ((1 << pnlog) - 1);
-    const int r = li / sn, c = li - r * sn;
-    m0 = (xi * ((nb >> 3) / sn) + r) * 256;
-    n0 = (xj * sn + c) * 256;
-}
-template <bool B_KM, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_sq_kernel(const GemmArgs gp, const int ntiles) {
-    const GemmArgs g = gp;
-    __shared__ __attribute__((aligned(16))) char smem[2 * SQ_STAGE + SQ_CTILE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
-    const int nk = g.K / BK;
-    // ---- this wave's share of the staging: image pair (A half hf, B half hf), pieces lw, lw + 4, lw + 8, lw + 12 of each
-    const int lw = wave & 3, hf = wave >> 2;
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
-    const int64_t sa = BK, sb = B_KM ? (int64_t)BK * g.ldb : BK;
-#define ICKA_SQ_STAGE(BUF)                                                                  \
-    do {                                                                                    \
-        dma_issue(pa, sa, lds0 + (BUF) * SQ_STAGE + hf * TILE_BYTES + lw * 1024);           \
-        dma_issue(pb, sb, lds0 + (BUF) * SQ_STAGE + (2 + hf) * TILE_BYTES + lw * 1024);     \
-    } while (0)
-    // ---- this wave's output: rows 128 * wsub .., columns 64 * wq ..
-    const int wsub = wave >> 2, wq = wave & 3;
-    const int bimg = 2 + (wq >> 1), wc = (wq & 1) * 64;
-    const bool use_aux = g.epi == ICKA_EPI_DGELU || g.epi == ICKA_EPI_ADD || g.epi == ICKA_EPI_GATE || g.epi == ICKA_EPI_ADD_RELU;
-    char* const ctile = smem + 2 * SQ_STAGE;
-    int t = blockIdx.x;
-    int m0, n0;
-    sq_origin(t, ntiles, g.w3_sn, g.w3_pnlog, m0, n0);
-    dma_init<false>(pa, g.A, g.lda, m0 + 128 * hf, lw, lane);
-    dma_init<B_KM>(pb, g.B, g.ldb, n0 + 128 * hf, lw, lane);
-    ICKA_SQ_STAGE(0);
-    if (nk > 1) ICKA_SQ_STAGE(1);
-#define ICKA_SQ_READ(FA, FB, BUFI, KS)                                                                      \
-    do {                                                                                                    \
-        const char* b_ = smem + (BUFI) * SQ_STAGE;                                                          \
-        int l_ = lane;                                                                                      \
-        asm volatile("" : "+v"(l_)); /* opaque: LDS addresses recomputed per read, not held across the loop */ \
-        _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) FA[t_] = read_frag<false>(b_ + wsub * TILE_BYTES, 16 * t_, KS, l_); \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) FB[t_] = read_frag<B_KM>(b_ + bimg * TILE_BYTES, wc + 16 * t_, KS, l_); \
-    } while (0)
-#define ICKA_SQ_MMA(FA, FB)                                                                                 \
-    do {                                                                                                    \
-        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                    \
-            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16t<F16>(FB[ni], FA[mi], acc[mi][ni]); \
-    } while (0)
-#define ICKA_SQ_INTERLEAVE()                                                                                \
-    do { /* fragment reads into the idle register set spread between the 32 MFMAs of the other set */       \
-        _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
-        }                                                                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-    } while (0)
-    for (;;) {
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
-        // (from the second tile on, the stores of the previous epilogue are still counted in vmcnt: these waits then also
-        //  cover the tail of that store burst, which has had the whole epilogue to drain)
-        if (nk > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();   // my pieces of tile 0 landed (tile 1: 8 in flight)
-        __builtin_amdgcn_s_barrier();                          // ... and everyone else's
-        asm volatile("" ::: "memory");
-        ICKA_SQ_READ(fa0, fb0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            const int buf = kt & 1;
-            ICKA_SQ_READ(fa1, fb1, buf, 1);
-            ICKA_SQ_MMA(fa0, fb0);
-            ICKA_SQ_INTERLEAVE();
-            // stage `buf` is completely in registers; my pieces of tile kt + 1 (the only DMA in flight) must have landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();      // tile kt + 1 published AND every wave is done with stage `buf`
-            asm volatile("" ::: "memory");
-            if (kt + 2 < nk) ICKA_SQ_STAGE(buf);   // tile kt + 2: lands under the MFMAs of tile kt + 1
-            ICKA_SQ_READ(fa0, fb0, buf ^ 1, 0);
-            ICKA_SQ_MMA(fa1, fb1);
-            ICKA_SQ_INTERLEAVE();
-        }
-        ICKA_SQ_READ(fa1, fb1, (nk - 1) & 1, 1);   // last k-tile
-        ICKA_SQ_MMA(fa0, fb0);
-        ICKA_SQ_INTERLEAVE();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        ICKA_SQ_MMA(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states (see gemm_ws_body)
-        // ---- the bias of this thread's epilogue columns (both column halves), loaded BEFORE the next tile's DMA is issued:
-        //      nothing in the epilogue passes waits on vmcnt any more (aux-operand epilogues excepted, see below)
-        float bq[2][8];
-        {
-            const int c8 = tid & 15;
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int n = n0 + 128 * pc + 8 * c8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bq[pc][e] = 0.f;
-                if (g.bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n), b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bq[pc][e] = b0[e]; bq[pc][4 + e] = b1[e]; }
-                }
-                if (g.bias2) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias2 + n), b1 = *reinterpret_cast<const f32x4*>(g.bias2 + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bq[pc][e] += b0[e]; bq[pc][4 + e] += b1[e]; }
-                }
-            }
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bq[pc][e]));   // (materialise: the loads complete here)
-        }
-        // ---- next tile of this block: its first two k-tiles go into the ring while the epilogue runs out of the staging
-        //      tile behind it.  (With an aux-operand epilogue the DMA is issued after the passes instead: their aux loads
-        //      return in order behind anything issued earlier.)
-        const int m0c = m0, n0c = n0;
-        const int tn = t + (int)gridDim.x;
-        __builtin_amdgcn_s_barrier();          // every wave has read the last stage
-        if (tn < ntiles) {
-            sq_origin(tn, ntiles, g.w3_sn, g.w3_pnlog, m0, n0);
-            dma_init<false>(pa, g.A, g.lda, m0 + 128 * hf, lw, lane);
-            dma_init<B_KM>(pb, g.B, g.ldb, n0 + 128 * hf, lw, lane);
-            if (!use_aux) {
-                ICKA_SQ_STAGE(0);
-                if (nk > 1) ICKA_SQ_STAGE(1);
-            }
-        }
-        // ---- epilogue: 8 passes of 64 x 128; pass (ph, pc, r2) = rows 64 r2 .. of the quadrant held by the two waves with
-        //      wsub == ph and wq >> 1 == pc
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int ph = pass >> 2, pc = (pass >> 1) & 1, r2 = pass & 1;
-            if (pass) {   // previous staging tile consumed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            if (wsub == ph && (wq >> 1) == pc) {
-#pragma unroll
-                for (int mj = 0; mj < 4; ++mj) {
-                    const int row = 16 * mj + (lane & 15);
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const int ch = (wc >> 2) + 4 * ni + (lane >> 4);
-                        *reinterpret_cast<f32x4*>(ctile + off_c(row, ch)) = acc[4 * r2 + mj][ni] * g.alpha;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            epilogue_rows<32, 16, 0, false, 64, true>(g, ctile, m0c + 128 * ph + 64 * r2, n0c + 128 * pc, tid, bq[pc]);
-        }
-        if (tn >= ntiles) break;
-        if (use_aux) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ICKA_SQ_STAGE(0);
-            if (nk > 1) ICKA_SQ_STAGE(1);
-        }
-        t = tn;
-    }
-#undef ICKA_SQ_INTERLEAVE
-#undef ICKA_SQ_STAGE
-#undef ICKA_SQ_READ
-#undef ICKA_SQ_MMA
-}
-
-int g_w3grid = 0;   // icka_gemm_set_w3_grid: 0 = pick the cut per shape, 8 / 4 / 2 / 1 = force pm (if it divides the tile grid)
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
-static int gemm_w3_grid(int M, int N, int bnw) {
+// (forced: Tune::w3grid, where it divides the tile grid)
+static int gemm_w3_grid(int M, int N, int bnw, int forced) {
     const int nbm = M / 256, nbn = N / bnw;
     int best = 8;
     long cost = -1;
     for (int pm = 8; pm >= 1; pm >>= 1) {
         const int pn = 8 / pm;
         if (nbm % pm || nbn % pn) continue;
-        if (g_w3grid && pm != g_w3grid) continue;
+        if (forced && pm != forced) continue;
         const long c = (long)pn * M + (long)pm * N;
         if (cost < 0 || c < cost) { cost = c; best = pm; }
     }
@@ -1764,22 +1471,11 @@ static int gemm_w3_grid(int M, int N, int bnw) {
     return best;
 }
 
-// CUs of this device rounded down to a multiple of 8 (the persistent 256x256 kernel keeps the b -> XCD map of sq_origin)
-static int sq_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) n = v & ~7;
-        else { n = 256; (void)hipGetLastError(); }
-    }
-    return n;
-}
-
 template <bool A_KM, bool B_KM, bool F16 = false>
-int launch(GemmArgs g, bool aligned, hipStream_t st) {
+int launch(GemmArgs g, bool aligned, hipStream_t st, const Tune& t) {
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if constexpr (!A_KM && !B_KM) {
-        if (!aligned && g.n64ok && g_ws) {   // 64-channel convolutions of the ResNet stem / layer1: 128x64 tiles
+        if (!aligned && g.n64ok && t.ws) {   // 64-channel convolutions of the ResNet stem / layer1: 128x64 tiles
             hipLaunchKernelGGL((gemm_ws_kernel<false, false, 3, 0, 64, F16>), dim3((g.M / BM) * (g.N / 64)), dim3(512), 0, st, g);
             ICKA_CHECK_LAUNCH();
             return 0;
@@ -1787,90 +1483,64 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
     }
     if (aligned) {
 #ifdef ICKA_GEMM_ABLATE
-        if (g_abl == 1 && !g_ws) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(256), 0, st, g);
-        else if (g_abl == 2 && !g_ws) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(256), 0, st, g);
+        if (t.abl == 1 && !t.ws) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(256), 0, st, g);
+        else if (t.abl == 2 && !t.ws) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(256), 0, st, g);
         else
 #endif
         {
             // ring depth: many tiles per CU -> two co-resident blocks (64 KiB ring of 2) overlap one block's
             // epilogue with the other's main loop; few tiles -> one block per CU with a deeper ring (measured,
             // tools/gemm_bench.py)
-            if (g_ws || F16) {   // (fp16 operands exist on the warp-specialised kernels only)
+            if (t.ws || F16) {   // (fp16 operands exist on the warp-specialised kernels only)
 #ifdef ICKA_GEMM_ABLATE
-                if (g_bn == 96 && g.n96ok) {   // the 128x96-tile kernel (icka_gemm_set_tile_n(96))
+                if (t.bn == 96 && g.n96ok) {   // the 128x96-tile kernel (ICKA_TUNE_TILE_N(96))
                     const int nb96 = (g.M / BM) * (g.N / 96);
-                    if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
-                    if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
-                    if (g_abl == 3) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 3, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                    if (t.abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                    if (t.abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                    if (t.abl == 3) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 3, 96>), dim3(nb96), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
                 }
-                if (g_abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
-                if (g_abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                if (t.abl == 1) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 1>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
+                if (t.abl == 2) { hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 2>), dim3(nb), dim3(512), 0, st, g); ICKA_CHECK_LAUNCH(); return 0; }
 #endif
                 // 256x192 tiles (12-wave kernel) where they cover the CUs in ONE round: wide outputs with a short reduction
-                if constexpr (!A_KM) {
-                    // 256x256 tiles (8-wave load+compute kernel) for large outputs in whole rounds of the CUs: N % 256 == 0,
-                    // at least two full rounds' worth of work and at least 7/8 of the last round filled
-                    const int nbq = (g.M / 256) * (g.N / 256);
-                    const int roundsq = (nbq + 255) / 256;
-                    if (g_sq && g.M % 256 == 0 && g.N % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nbq % 8 == 0 && !g.colsum &&
-                        (g_sq == 2 || (nbq >= 448 && 8 * nbq >= 7 * 256 * roundsq))) {   // (2: forced, tests)
-                        { const int pm = gemm_w3_grid(g.M, g.N, 256), pn = 8 / pm;
-                          g.w3_sn = (g.N / 256) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
-                        // one block per tile; ICKA_GEMM_SQ_PERSIST=1 (diagnostic): one block per CU (LDS: the whole 160 KiB),
-                        // block b takes tiles b, b + grid, ... with the next tile's first k-tiles issued under the epilogue --
-                        // measured SLOWER (125.8 vs 96.0 us at 8192 x 4096 x 1024): the epilogue's stores are counted by the
-                        // same vmcnt the next tile's DMA waits use (profiles/NEGATIVE_RESULTS.md)
-                        static const int persist = [] { const char* e = getenv("ICKA_GEMM_SQ_PERSIST"); return e && e[0] == '1'; }();
-                        const int gridq = (persist && nbq > sq_cus()) ? sq_cus() : nbq;
-                        hipLaunchKernelGGL((gemm_sq_kernel<B_KM, F16>), dim3(gridq), dim3(512), 0, st, g, nbq);
-                        ICKA_CHECK_LAUNCH();
-                        return 0;
-                    }
-                }
                 if constexpr (!A_KM) {
                     const int nb3 = (g.M / 256) * (g.N / 192);
                     // ... or in whole rounds: at least 3/4 of the last round of 256 must be filled
                     const int rounds3 = (nb3 + 255) / 256;
-                    if (g_w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
+                    if (t.w3 && g.M % 256 == 0 && g.N % 192 == 0 && g.K <= 1024 && g.K1 == 0 && nb3 % 8 == 0 &&
                         nb3 >= 128 && 4 * nb3 >= 3 * 256 * rounds3 && g.ksplit == 1) {
-                        { const int pm = gemm_w3_grid(g.M, g.N, 192), pn = 8 / pm;
+                        { const int pm = gemm_w3_grid(g.M, g.N, 192, t.w3grid), pn = 8 / pm;
                           g.w3_sn = (g.N / 192) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
-                        if (g_w3p == 2 && nb3 > sq_cus())   // (2 = tests: at 256x192 the persistent form measured SLOWER, 69 vs 65 us)
-                            hipLaunchKernelGGL((gemm_w3p_kernel<B_KM, F16>), dim3(sq_cus()), dim3(768), 0, st, g, nb3);
-                        else
-                            hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
+                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16>), dim3(nb3), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }
                     // 256x128 tiles (the same kernel, 64-column halves) where 128x128 tiles would take exactly two rounds of
                     // the CUs with one block each (N = 1024 at bert-large / M = 8192: 256 tiles), any K
                     const int nb2 = (g.M / 256) * (g.N / 128);
-                    if (g_w3 && g.M % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nb2 % 8 == 0 && nb2 >= 192 && (nb2 <= 256 || (g_w3p && nb2 % 256 == 0 && g.K <= 1024)) &&
-                        !(g.n96ok && g_bn == 96) && !(g.K <= 1024 && g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f)) {
+                    if (t.w3 && g.M % 256 == 0 && g.K1 == 0 && g.ksplit == 1 && nb2 % 8 == 0 && nb2 >= 192 && nb2 <= 256 &&
+                        !(g.n96ok && t.bn == 96) && !(g.K <= 1024 && g.direct && g.c_f32 && g.epi == ICKA_EPI_NONE && g.beta == 0.f)) {
                         // (short reductions with a plain f32 output stay on the 128-wide kernel: its direct epilogue beats
                         //  the two staged passes here, 25.9 vs 28.3 us at 8192 x 1024 x 1024)
-                        { const int pm = gemm_w3_grid(g.M, g.N, 128), pn = 8 / pm;
+                        { const int pm = gemm_w3_grid(g.M, g.N, 128, t.w3grid), pn = 8 / pm;
                           g.w3_sn = (g.N / 128) / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
-                        if (g_w3p && nb2 > sq_cus())
-                            hipLaunchKernelGGL((gemm_w3p_kernel<B_KM, F16, 128>), dim3(sq_cus()), dim3(768), 0, st, g, nb2);
-                        else
-                            hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
+                        hipLaunchKernelGGL((gemm_w3_kernel<B_KM, F16, 128>), dim3(nb2), dim3(768), 0, st, g);
                         ICKA_CHECK_LAUNCH();
                         return 0;
                     }
                 }
                 // Tile width: 128x96 tiles when they quantise better onto the 256 CUs (N = 768: 256 tiles instead of 192).
-                if (g.n96ok && g_bn != 128) {
+                if (g.n96ok && t.bn != 128) {
                     // measured (profiles/README.md): a 128x96 tile costs ~0.9-1.0 of a 128x128 one (the k-loop is bound
                     // by LDS / L1 traffic of the A tile, not by MFMA count), so the narrow tile only pays where it turns
                     // an under-filled single round into a full one
                     const int nb96 = (g.M / BM) * (g.N / 96);
-                    if (g_bn == 96 || (nb < 256 && nb96 <= 256 && nb96 > nb)) {
-                        if ((g_ws == 2 || (g_ws == 1 && nb96 >= 448 && g.K <= 1024)) && !A_KM)
+                    if (t.bn == 96 || (nb < 256 && nb96 <= 256 && nb96 > nb)) {
+                        if ((t.ws == 2 || (t.ws == 1 && nb96 >= 448 && g.K <= 1024)) && !A_KM)
                             hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_nbuf == 4 && !F16)
+                        else if (t.nbuf == 4 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
-                        else if (g_nbuf == 5 && !F16)
+                        else if (t.nbuf == 5 && !F16)
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5, 0, 96>), dim3(nb96), dim3(512), 0, st, g);
                         else
                             hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 96, F16>), dim3(nb96), dim3(512), 0, st, g);
@@ -1880,15 +1550,15 @@ int launch(GemmArgs g, bool aligned, hipStream_t st) {
                 }
                 // measured (tools/gemm_bench.py): two co-resident blocks win only for short reductions on grids of
                 // >= ~2 tiles per CU (qkv, ffn-up, d-ffn-down); long-K shapes prefer the deeper ring of one block
-                if ((g_ws == 2 || (g_ws == 1 && nb >= 448 && g.K <= 1024)) && !A_KM)
+                if ((t.ws == 2 || (t.ws == 1 && nb >= 448 && g.K <= 1024)) && !A_KM)
                     hipLaunchKernelGGL((gemm_ws2_kernel<A_KM, B_KM, 128, F16>), dim3(nb), dim3(512), 0, st, g);
-                else if (g_nbuf == 4 && !F16) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
-                else if (g_nbuf == 5 && !F16) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5>), dim3(nb), dim3(512), 0, st, g);
+                else if (t.nbuf == 4 && !F16) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 4>), dim3(nb), dim3(512), 0, st, g);
+                else if (t.nbuf == 5 && !F16) hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 5>), dim3(nb), dim3(512), 0, st, g);
                 else hipLaunchKernelGGL((gemm_ws_kernel<A_KM, B_KM, 3, 0, 128, F16>), dim3(nb), dim3(512), 0, st, g);
                 ICKA_CHECK_LAUNCH();
                 return 0;
             }
-            const int nbuf = g_nbuf > 0 ? g_nbuf : (nb >= 448 ? 2 : 4);
+            const int nbuf = t.nbuf > 0 ? t.nbuf : (nb >= 448 ? 2 : 4);
             if (nbuf == 2) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 2, 0>), dim3(nb), dim3(256), 0, st, g);
             else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 3, 0>), dim3(nb), dim3(256), 0, st, g);
             else hipLaunchKernelGGL((gemm_dma_kernel<A_KM, B_KM, 4, 0>), dim3(nb), dim3(256), 0, st, g);
@@ -1924,55 +1594,13 @@ inline bool vec_ok(const void* p, int64_t ld) { return (ld % 8 == 0) && ((reinte
 
 }  // namespace
 
-extern "C" int icka_gemm_set_w3_grid(int pm) {
-    if (pm != 0 && pm != 1 && pm != 2 && pm != 4 && pm != 8) return ICKA_E_ARG;
-    g_w3grid = pm;
-    return 0;
-}
-extern "C" int icka_gemm_set_warp_specialized(int on) {
-    g_ws = on;   // 0: single-role kernel, 1: warp-specialised (two blocks per CU for large grids), 2: force two blocks, 3: never
-    return 0;
-}
-
-extern "C" int icka_gemm_set_stamp_buffer(void* p) {
+#ifdef ICKA_GEMM_STAMP
+// diagnostic builds only (tools/gemm_stamp.py): device buffer of [blocks][8] u64 receiving per-segment cycle sums
+extern "C" int icka_diag_gemm_stamp_buffer(void* p) {
     g_stamp = (unsigned long long*)p;
     return 0;
 }
-
-extern "C" int icka_gemm_set_ablation(int mode) {
-    g_abl = mode;
-    return 0;
-}
-
-extern "C" int icka_gemm_set_direct_epilogue(int on) {
-    g_direct = on ? 1 : 0;
-    return 0;
-}
-
-extern "C" int icka_gemm_set_square_tiles(int on) {
-    g_sq = on < 0 || on > 2 ? 0 : on;   // 0 off (default), 1 by shape, 2 wherever the tile divides the output (tests)
-    return 0;
-}
-extern "C" int icka_gemm_set_persistent(int on) {
-    g_w3p = on < 0 || on > 2 ? 0 : on;
-    return 0;
-}
-extern "C" int icka_gemm_set_wide_tiles(int on) {
-    g_w3 = on ? 1 : 0;
-    return 0;
-}
-
-extern "C" int icka_gemm_set_tile_n(int bn) {
-    if (bn != 0 && bn != 96 && bn != 128) return ICKA_E_ARG;
-    g_bn = bn;
-    return 0;
-}
-
-extern "C" int icka_gemm_set_ring(int nbuf) {
-    if (nbuf != 0 && (nbuf < 2 || nbuf > 5)) return ICKA_E_ARG;
-    g_nbuf = nbuf;
-    return 0;
-}
+#endif
 
 // Diagnostic site classes of the per-site store-policy matrix (profiles/r04_store_policy_matrix.txt): which producer of a
 // BERT layer a launch is, from its op / epilogue / shape ratio (N, K in units of H = min(N, K) work for bert-base and -large).
@@ -2005,8 +1633,9 @@ static int plain_mask() {
     return m;
 }
 
-static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
+static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned, Tune& t) {
     if (!d || !d->A || !d->B || !d->C) return ICKA_E_ARG;
+    if (!tune_of(d->tune, t)) return ICKA_E_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return ICKA_E_SHAPE;
     if (d->op < ICKA_GEMM_NT || d->op > ICKA_GEMM_TN) return ICKA_E_ARG;
     if (d->K1 != 0 && (d->K1 < 0 || d->K1 >= d->K || d->K1 % BK != 0 || !d->A2 || !d->B2)) return ICKA_E_ARG;
@@ -2036,9 +1665,10 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     }
     if (g.c3_only && !(g.C3 && g.c_f32 && d->beta == 0.f && d->epilogue == ICKA_EPI_NONE)) return ICKA_E_ARG;
     if (g.c_f16 && d->colsum_out) return ICKA_E_ARG;
-    g.abl = g_abl;
-    g.stamp = g_stamp;
+    g.abl = t.abl;
+    g.stamp = nullptr;
 #ifdef ICKA_GEMM_STAMP
+    g.stamp = g_stamp;
     {   // diagnostic builds: ICKA_GEMM_STAMP_FILTER="op,N,K" stamps only that shape (all GEMMs share one buffer)
         static int f_op = -2, f_n = 0, f_k = 0;
         if (f_op == -2) {
@@ -2053,7 +1683,7 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
     g.ksplit = 1;
     g.n96ok = 0;
     g.n64ok = 0;
-    g.direct = g_direct;
+    g.direct = t.direct;
     g.a_vec = vec_ok(d->A, d->lda) && (d->K1 == 0 || vec_ok(d->A2, d->lda2));
     g.b_vec = vec_ok(d->B, d->ldb) && (d->K1 == 0 || vec_ok(d->B2, d->ldb2));
     auto al = [](const void* p, int64_t ld, int64_t mod) {
@@ -2072,16 +1702,17 @@ static int convert(const icka_gemm_desc* d, GemmArgs& g, bool& aligned) {
 
 extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
     GemmArgs g;
+    Tune t;
     bool aligned = false;
-    const int rc = convert(d, g, aligned);
+    const int rc = convert(d, g, aligned, t);
     if (rc) return rc;
-    if (g.colsum && !(aligned && g_ws)) return ICKA_E_ARG;   // fused column sums exist on the warp-specialised path
+    if (g.colsum && !(aligned && t.ws)) return ICKA_E_ARG;   // fused column sums exist on the warp-specialised path
     hipStream_t st = (hipStream_t)stream;
-    if (g.f16) return launch<false, false, true>(g, aligned, st);
+    if (g.f16) return launch<false, false, true>(g, aligned, st, t);
     switch (d->op) {
-        case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st);
-        case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st);
-        default: return launch<true, true>(g, aligned, st);
+        case ICKA_GEMM_NT: return launch<false, false>(g, aligned, st, t);
+        case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st, t);
+        default: return launch<true, true>(g, aligned, st, t);
     }
 }
 
@@ -2107,7 +1738,7 @@ extern "C" int icka_conv3x3_gemm(const void* x, const void* w, const float* bias
     g.M = (int)rows_padded; g.N = Cout; g.K = 9 * C; g.K1 = 0;
     g.A = (const bf16_t*)x; g.lda = C; g.B = (const bf16_t*)w; g.ldb = 9 * (int64_t)C;
     g.C = y; g.ldc = Cout; g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.bias = bias;
-    g.alpha = 1.f; g.beta = 0.f; g.epi = epilogue; g.c_f32 = 0; g.a_vec = g.b_vec = 1; g.ksplit = 1; g.direct = g_direct;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = epilogue; g.c_f32 = 0; g.a_vec = g.b_vec = 1; g.ksplit = 1; g.direct = kTuneEnv.direct;
     g.cvH = H; g.cvW = W; g.cvC = C; g.cvS = stride; g.cvHo = Ho; g.cvWo = Wo; g.cvRows = (int)rows;
     g.cvZero = (const bf16_t*)zeros;
     hipStream_t st = (hipStream_t)stream;
@@ -2521,30 +2152,23 @@ __global__ __launch_bounds__(W12 ? 768 : 512) void gemm_big_group_kernel(const B
     else gemm_big_tn_body<WIRE>(g, smem, tm * 256, tn * BN);
 }
 
-int g_big = 2;   // icka_gemm_set_big_tiles: 256x128 tiles for eligible grouped TN launches (2: 12-wave form, +0.9 % on the c2 step)
-
 // eligible: fast-path TN, 256-row tiles, plain f32 output (overwrite or accumulate)
 static bool big_ok(const GemmArgs& g, bool aligned) {
     return aligned && g.M % 256 == 0 && g.c_f32 && g.epi == ICKA_EPI_NONE && g.K1 == 0 && !g.bias && !g.bias2 && g.direct;
 }
 
 template <bool A_KM, bool B_KM>
-static int launch_group(const GroupArgs& ga, int total, hipStream_t st) {
-    if (g_ws) {
+static int launch_group(const GroupArgs& ga, int total, hipStream_t st, const Tune& t) {
+    if (t.ws) {
         hipLaunchKernelGGL((gemm_ws_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(512), 0, st, ga);
         ICKA_CHECK_LAUNCH();
         return 0;
     }
-    const int nbuf = g_nbuf > 0 ? g_nbuf : (total >= 448 ? 2 : 4);
+    const int nbuf = t.nbuf > 0 ? t.nbuf : (total >= 448 ? 2 : 4);
     if (nbuf == 2) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 2>), dim3(total), dim3(256), 0, st, ga);
     else if (nbuf == 3) hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 3>), dim3(total), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gemm_dma_group_kernel<A_KM, B_KM, 4>), dim3(total), dim3(256), 0, st, ga);
     ICKA_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int icka_gemm_set_big_tiles(int on) {
-    g_big = on < 0 ? 0 : (on > 2 ? 1 : on);   // 0: 128x128 group kernel, 1: 256x128 tiles / 8 waves, 2: 256x128 tiles / 12 waves
     return 0;
 }
 
@@ -2579,15 +2203,20 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
                         hipStream_t st) {
     bool reds_done = n_red == 0;
     int i = 0;
+    // the group's launch heuristics: the environment default, overridden by the FIRST problem's tune word
+    // (Tune::big: 256x128 tiles for runs of eligible weight-gradient problems -- 2: 12-wave blocks, +0.9 % on the c2 step)
+    Tune t = kTuneEnv;
+    if (n > 0 && !tune_of(descs[0].tune, t)) return ICKA_E_ARG;
+    Tune tk;   // (per-problem decode: convert() validates every problem's word)
     while (i < n) {
-        if (g_big && g_ws && descs[i].op == ICKA_GEMM_TN) {
+        if (t.big && t.ws && descs[i].op == ICKA_GEMM_TN) {
             // 256x128-tile launch for runs of eligible weight-gradient problems (+ their column-sum blocks)
             BigGroupArgs ba;
             int cnt = 0, total = 0, cs_total = 0;
             while (i + cnt < n && cnt < MAX_GROUP && descs[i + cnt].op == ICKA_GEMM_TN) {
                 bool aligned = false;
                 GemmArgs g;
-                const int rc = convert(&descs[i + cnt], g, aligned);
+                const int rc = convert(&descs[i + cnt], g, aligned, tk);
                 if (rc) return rc;
                 if (!big_ok(g, aligned)) break;
                 ba.p[cnt] = g;
@@ -2611,7 +2240,7 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
                 bool wire = false;
                 for (int k = 0; k < cnt; ++k) wire = wire || ba.p[k].C3 != nullptr;
                 const dim3 grid(total + cs_total + red_total);
-                if (g_big == 2) {
+                if (t.big == 2) {
                     if (wire) hipLaunchKernelGGL((gemm_big_group_kernel<true, true>), grid, dim3(768), 0, st, ba);
                     else hipLaunchKernelGGL((gemm_big_group_kernel<true, false>), grid, dim3(768), 0, st, ba);
                 } else {
@@ -2629,9 +2258,9 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
         const int op = descs[i].op;
         while (i + cnt < n && cnt < MAX_GROUP && descs[i + cnt].op == op && !descs[i + cnt].ab_f16) {   // (fp16 problems go alone)
             bool aligned = false;
-            const int rc = convert(&descs[i + cnt], ga.p[cnt], aligned);
+            const int rc = convert(&descs[i + cnt], ga.p[cnt], aligned, tk);
             if (rc) return rc;
-            if (ga.p[cnt].colsum && !(aligned && g_ws)) return ICKA_E_ARG;
+            if (ga.p[cnt].colsum && !(aligned && t.ws)) return ICKA_E_ARG;
             if (!aligned) break;
             ga.start[cnt] = total;
             total += (ga.p[cnt].M / BM) * (ga.p[cnt].N / BN);
@@ -2641,7 +2270,7 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
             for (int k = cnt; k <= MAX_GROUP; ++k) ga.start[k] = total;
             for (int k = cnt; k < MAX_GROUP; ++k) ga.p[k] = ga.p[0];
             int rc;
-            if (op == ICKA_GEMM_TN && !reds_done && g_ws) {
+            if (op == ICKA_GEMM_TN && !reds_done && t.ws) {
                 // the pending slab reductions ride on this launch (extra blocks behind the tiles)
                 GroupArgsRed gr;
                 gr.ga = ga;
@@ -2656,9 +2285,9 @@ static int grouped_impl(const icka_gemm_desc* descs, int32_t n, const icka_slab_
                 ICKA_CHECK_LAUNCH();
                 reds_done = true;
                 rc = 0;
-            } else if (op == ICKA_GEMM_NT) rc = launch_group<false, false>(ga, total, st);
-            else if (op == ICKA_GEMM_NN) rc = launch_group<false, true>(ga, total, st);
-            else rc = launch_group<true, true>(ga, total, st);
+            } else if (op == ICKA_GEMM_NT) rc = launch_group<false, false>(ga, total, st, t);
+            else if (op == ICKA_GEMM_NN) rc = launch_group<false, true>(ga, total, st, t);
+            else rc = launch_group<true, true>(ga, total, st, t);
             if (rc) return rc;
             i += cnt;
         } else {

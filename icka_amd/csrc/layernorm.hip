@@ -65,7 +65,7 @@ __device__ __forceinline__ void store8t(void* base, int is_f16, int64_t off, con
     else store8f(reinterpret_cast<float*>(base) + off, v);
 }
 
-// One wave per row at a time; a wave that owns several rows (grid < M / 4: icka_ln_set_rows_per_wave) issues the loads of its
+// One wave per row at a time; a wave that owns several rows (grid < M / 4) issues the loads of its
 // NEXT row before it reduces and stores the current one, so that a CU's read and write streams overlap instead of the whole
 // chip reading, then reducing, then writing in step.
 template <int NCH>
@@ -668,28 +668,27 @@ __global__ __launch_bounds__(512) void embed_bwd_pos_kernel(const EmbBwdArgs a_)
 }
 
 inline int pick_nch(int H) { return (H / 8 + 63) / 64; }
-// icka_ln_set_rows_per_wave: rows a forward wave owns (> 1: its next row's loads overlap its stores); 0 = automatic: two
-// rows per wave from 4096 rows on (c2: 4.534 -> 4.489 ms per step, same box, twice: profiles/r04_ln_rows_per_wave.txt; three
-// and more rows per wave are slower again, and the backward rows do not gain)
-int g_ln_rows_per_wave = 0;
-inline int row_grid(int M) { int g = (M + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
-inline int fwd_grid(int M) {
-    static const int env_rows = [] { const char* e = getenv("ICKA_LN_ROWS"); return e ? atoi(e) : 0; }();   // diagnostic A/B
-    const int r = env_rows >= 1 && env_rows <= 16 ? env_rows : (g_ln_rows_per_wave < 1 ? (M >= 4096 ? 2 : 1) : g_ln_rows_per_wave);
-    int g = (M + 4 * r - 1) / (4 * r);
-    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
-}
-inline int bwd_grid(int M) { int g = (M + 3) / 4; return g > BWD_BLOCKS ? BWD_BLOCKS : (g < 1 ? 1 : g); }
+// rows a forward wave owns (> 1: its next row's loads overlap its stores): two rows per wave from 4096 rows on (c2: 4.534 ->
+// 4.489 ms per step, same box, twice: profiles/r04_ln_rows_per_wave.txt; three and more rows per wave are slower again, and the
+// backward rows do not gain).  ICKA_TUNE_LN_ROWS_PER_WAVE (1 .. 16; read ONCE at load: same-box A/B runs, tools/ln_bench.py
+// starts one process per setting) replaces the automatic choice -- there is no run-time setter: no mutable process state
 inline int rows_knob(const char* name, int dflt) {
     const char* e = getenv(name);
     const int v = e ? atoi(e) : 0;
     return v >= 1 && v <= 16 ? v : dflt;
 }
-// row blocks of the fused backward launch: rows-per-wave knob ICKA_LN_BWD_ROWS (diagnostic A/B; default g_ln_bwd_rows)
-int g_ln_bwd_rows = 1;
+const int kLnRowsEnv = rows_knob("ICKA_TUNE_LN_ROWS_PER_WAVE", 0);
+const int kLnBwdRowsEnv = rows_knob("ICKA_TUNE_LN_BWD_ROWS_PER_WAVE", 1);
+inline int row_grid(int M) { int g = (M + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+inline int fwd_grid(int M) {
+    const int r = kLnRowsEnv ? kLnRowsEnv : (M >= 4096 ? 2 : 1);
+    int g = (M + 4 * r - 1) / (4 * r);
+    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
+inline int bwd_grid(int M) { int g = (M + 3) / 4; return g > BWD_BLOCKS ? BWD_BLOCKS : (g < 1 ? 1 : g); }
+// row blocks of the fused backward launch (rows per wave: ICKA_TUNE_LN_BWD_ROWS_PER_WAVE, default 1)
 inline int bwd_row_grid(int M) {
-    static const int env_rows = rows_knob("ICKA_LN_BWD_ROWS", 0);
-    const int r = env_rows ? env_rows : g_ln_bwd_rows;
+    const int r = kLnBwdRowsEnv;
     int g = (M + 4 * r - 1) / (4 * r);
     return g > 2048 ? 2048 : (g < 1 ? 1 : g);
 }
@@ -723,12 +722,6 @@ static int ln_fwd_impl(int32_t twin_f16, const void* x, int64_t ldx, int32_t x_i
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_NCH(pick_nch(H), ln_fwd_kernel, fwd_grid(M), 0, st, a);
     ICKA_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int icka_ln_set_rows_per_wave(int32_t rows) {
-    if (rows < 0 || rows > 16) return ICKA_E_ARG;
-    g_ln_rows_per_wave = rows;
     return 0;
 }
 

@@ -779,9 +779,9 @@ static int lstm_cus() {
     const int avail = n - g_lstm_reserved_cus;
     return avail > 0 ? avail : 0;
 }
-int g_lstm_persistent = 1;   // icka_lstm_set_persistent
-int g_lstm_handoff = 1;      // icka_lstm_set_handoff: 1 = flag-in-data words, 0 = tickets
-int g_lstm_bsplit = 1;       // icka_lstm_set_batch_split: batch tiles of 16 rows as separate blocks of the persistent launches
+// Which form a call takes is decided PER CALL by its ``flags`` argument (ICKA_LSTM_*, include/icka_hip.h): the default (0) is
+// the persistent launch with the flag-in-data hand-off and batch tiles of 16 rows as separate blocks; there is no process-wide
+// switch (tests and tools/lstm_bench.py pass the flags of the form they want).
 static unsigned long long* lstm_rs_words(hipStream_t st) {   // [2 parity][2 dir][64 dest][64 src][32 rows][8 words]: 33.5 MB, allocated once
     static unsigned long long* p = nullptr;
     static bool failed = false;
@@ -940,8 +940,11 @@ inline int lstm_check(int B, int S, int H) {
 }  // namespace
 
 extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh, void* y, float* c_all, void* act,
-                             void* hprev, int32_t B, int32_t S, int32_t H, void* stream) {
+                             void* hprev, int32_t B, int32_t S, int32_t H, int32_t flags, void* stream) {
     if (!gates_x || !w_hh || !y || !c_all || !act) return ICKA_E_ARG;
+    if (flags & ~(ICKA_LSTM_PER_STEP | ICKA_LSTM_TICKETS | ICKA_LSTM_NO_BATCH_SPLIT)) return ICKA_E_ARG;
+    const int persistent = !(flags & ICKA_LSTM_PER_STEP), handoff = !(flags & ICKA_LSTM_TICKETS),
+              bsplit = !(flags & ICKA_LSTM_NO_BATCH_SPLIT);
     if (int rc = lstm_check(B, S, H)) return rc;
     if (ldg < 8 * (int64_t)H) return ICKA_E_ARG;
     if ((reinterpret_cast<uintptr_t>(w_hh) | reinterpret_cast<uintptr_t>(y)) & 15) return ICKA_E_ALIGN;
@@ -950,7 +953,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
     a.act = (bf16_t*)act; a.hprev = (bf16_t*)hprev; a.B = B; a.S = S; a.H = H;
     a.test_drop = g_lstm_test_drop;
     const int nrt = (B + 15) / 16;
-    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 128 == 0 && (H / 16) * 2 <= lstm_cus()) {
+    if (persistent && handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 128 == 0 && (H / 16) * 2 <= lstm_cus()) {
         // flag-in-data hand-off: zero the word buffers (tags of an earlier launch), then one launch for all S steps
         hipStream_t st = (hipStream_t)stream;
         unsigned int* errw = lstm_err_word(st);
@@ -961,7 +964,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
         if (hipMemsetAsync(ll, 0, sizeof(unsigned long long) * 2 * 2 * LSTM_LL_ROWS * (LSTM_LL_MAXH / 2), st) != hipSuccess) return ICKA_E_ARG;
         // batch rows are independent recurrences: two tiles of 16 rows run as separate blocks (grid.z) where all of them
         // are co-resident -- half the words to poll and half the MFMAs per block and step
-        const bool split = g_lstm_bsplit && nrt == 2 && (H / 16) * 2 * 2 <= lstm_cus();
+        const bool split = bsplit && nrt == 2 && (H / 16) * 2 * 2 <= lstm_cus();
         const dim3 grid(H / 16, 2, split ? 2 : 1);
         const int nr = split ? 1 : nrt;
 #define ICKA_LL_FWD(NRT_, KQ_) hipLaunchKernelGGL((lstm_fwd_ll_kernel<NRT_, KQ_>), grid, dim3(256), 0, st, a, errw)
@@ -978,7 +981,7 @@ extern "C" int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh
         return 0;
     }
 ticket_form:
-    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
+    if (persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         unsigned int* errw = lstm_err_word((hipStream_t)stream);
@@ -1007,8 +1010,10 @@ ticket_form:
 }
 
 extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const float* c_all, void* dgates,
-                             int64_t ldg, float* dc_carry, int32_t B, int32_t S, int32_t H, void* stream) {
+                             int64_t ldg, float* dc_carry, int32_t B, int32_t S, int32_t H, int32_t flags, void* stream) {
     if (!dy || !w_hh_t || !act || !c_all || !dgates || !dc_carry) return ICKA_E_ARG;
+    if (flags & ~(ICKA_LSTM_PER_STEP | ICKA_LSTM_TICKETS | ICKA_LSTM_NO_BATCH_SPLIT)) return ICKA_E_ARG;
+    const int persistent = !(flags & ICKA_LSTM_PER_STEP), handoff = !(flags & ICKA_LSTM_TICKETS);
     if (int rc = lstm_check(B, S, H)) return rc;
     if (ldg < 8 * (int64_t)H || ldg % 8) return ICKA_E_ARG;
     if ((reinterpret_cast<uintptr_t>(w_hh_t) | reinterpret_cast<uintptr_t>(dgates)) & 15) return ICKA_E_ALIGN;
@@ -1018,7 +1023,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
     a.B = B; a.S = S; a.H = H;
     a.test_drop = g_lstm_test_drop;
     const int nrt = (B + 15) / 16;
-    if (g_lstm_persistent && g_lstm_handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= lstm_cus()) {
+    if (persistent && handoff == 1 && nrt <= 2 && H <= LSTM_LL_MAXH && H % 256 == 0 && (H / 16) * 2 * nrt <= lstm_cus()) {
         // reduce-scatter form with tagged words (lstm_bwd_rs_kernel); the word buffer is allocated once (largest shape)
         unsigned int* errw = lstm_err_word((hipStream_t)stream);
         unsigned long long* llr = lstm_rs_words((hipStream_t)stream);
@@ -1039,7 +1044,7 @@ extern "C" int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act
             return 0;
         }
     }
-    if (g_lstm_persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
+    if (persistent && nrt <= 2 && H <= 1024 && (H / 16) * 2 <= lstm_cus()) {
         LstmPersist ps;
         unsigned int* base = lstm_sync_words();
         unsigned int* errw = lstm_err_word((hipStream_t)stream);
@@ -1092,19 +1097,6 @@ extern "C" int icka_linear_small_m(const void* x, int64_t ldx, const void* W, co
     return 0;
 }
 
-extern "C" int icka_lstm_set_batch_split(int32_t on) {
-    g_lstm_bsplit = on ? 1 : 0;
-    return 0;
-}
-extern "C" int icka_lstm_set_handoff(int32_t mode) {
-    if (mode != 0 && mode != 1) return ICKA_E_ARG;
-    g_lstm_handoff = mode;
-    return 0;
-}
-extern "C" int icka_lstm_set_persistent(int32_t on) {
-    g_lstm_persistent = on ? 1 : 0;
-    return 0;
-}
 /* 1 if a hand-off wait of a persistent recurrence ever gave up (the outputs of that call are NaN-poisoned).  Reads the
    host-mapped error word when there is one (mapped by the first persistent launch issued outside a stream capture) -- a plain
    host read, no runtime call; only launches that had to take the fallback device word cost a blocking copy here. */

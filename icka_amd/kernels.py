@@ -106,11 +106,12 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
               alpha: float = 1.0, beta: float = 0.0, A2: Optional[torch.Tensor] = None,
               B2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
               colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False,
-              out3: Optional[torch.Tensor] = None, out3_only: bool = False) -> GemmDesc:
+              out3: Optional[torch.Tensor] = None, out3_only: bool = False, tune: int = 0) -> GemmDesc:
     """Validate the operands and fill an ``icka_gemm_desc`` (the tensors must stay alive until it is launched).
     Operands are bf16, or -- op NT only, the "mixed16" forward GEMMs -- both fp16; ``out`` may then be fp16 too, with
     ``out3`` an optional bf16 copy of it.  With an f32 ``out``, ``out3`` is the data-parallel wire copy (bf16 of the final,
-    beta-accumulated value) the weight-gradient GEMMs write for dp.GradReducer: op TN only."""
+    beta-accumulated value) the weight-gradient GEMMs write for dp.GradReducer: op TN only.  ``tune``: per-call overrides of
+    the launch heuristics (``gemm_tune(...)``; 0 = the library's choice) -- results do not depend on it."""
     odt = A.dtype if A.dtype == F16 else BF16     # operand dtype of this launch
     if odt == F16 and op != GEMM_NT:
         raise ValueError("fp16 operands: NT (forward) GEMMs only")
@@ -177,6 +178,8 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
             raise ValueError("bias2 must be contiguous device f32 [N]")
         d.bias2 = bias2.data_ptr()
     d.alpha, d.beta, d.epilogue = alpha, beta, epilogue
+    if tune:
+        d.tune = int(tune)
     if colsum_out is not None:
         if op != GEMM_TN or colsum_out.dtype != F32 or colsum_out.numel() != M or not colsum_out.is_contiguous():
             raise ValueError("colsum_out: contiguous f32 [M] with op TN")
@@ -186,6 +189,44 @@ def gemm_desc(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, b
     if _PROF is not None:   # the recorded launch is re-issued later: its operands must outlive the step
         d._keep = (A, B, out, bias, aux, out2, A2, B2, bias2, colsum_out, out3)
     return d
+
+
+def gemm_tune(*, ring: Optional[int] = None, tile_n: Optional[int] = None, wide_tiles: Optional[bool] = None,
+              direct_epilogue: Optional[bool] = None, warp_specialized: Optional[int] = None, w3_grid: Optional[int] = None,
+              big_tiles: Optional[int] = None, ablation: Optional[int] = None) -> int:
+    """The ``icka_gemm_desc.tune`` word (include/icka_hip.h, ICKA_TUNE_*): per-call overrides of single launch heuristics, for
+    tests of the alternative kernels and for probes.  There is no process-wide setter; the same fields can be given to a whole
+    process through the ICKA_TUNE_GEMM_* environment (read once when the library loads)."""
+    t = 0
+    if ring is not None:
+        if ring not in (2, 3, 4, 5):
+            raise ValueError("ring: 2 .. 5")
+        t |= ring
+    if tile_n is not None:
+        if tile_n not in (96, 128):
+            raise ValueError("tile_n: 96 or 128")
+        t |= (1 if tile_n == 96 else 2) << 4
+    if wide_tiles is not None:
+        t |= (2 if wide_tiles else 1) << 8
+    if direct_epilogue is not None:
+        t |= (2 if direct_epilogue else 1) << 12
+    if warp_specialized is not None:
+        if warp_specialized not in (0, 1, 2, 3):
+            raise ValueError("warp_specialized: 0 .. 3")
+        t |= (warp_specialized + 1) << 16
+    if w3_grid is not None:
+        if w3_grid not in (1, 2, 4, 8):
+            raise ValueError("w3_grid: 1, 2, 4 or 8")
+        t |= w3_grid << 20
+    if big_tiles is not None:
+        if big_tiles not in (0, 1, 2):
+            raise ValueError("big_tiles: 0 .. 2")
+        t |= (big_tiles + 1) << 24
+    if ablation is not None:
+        if ablation not in (1, 2, 3):
+            raise ValueError("ablation: 1 .. 3 (diagnostic builds)")
+        t |= ablation << 28
+    return t
 
 
 def gemm(op: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, **kw) -> torch.Tensor:
@@ -455,16 +496,17 @@ def attn_keepbits(B, heads, Sq, Skv, device) -> torch.Tensor:
 
 
 def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed=0, scale=None, fp8=False, out16=None,
-             keepbits=None):
+             keepbits=None, tiled=False):
     """q/k/v/out: 2-D row-major bf16 views [B*S, >=heads*64] (may be column slices of a fused projection).
     fp8=True: QK^T and PV on the fp8 matrix cores (Sq, Skv <= 128 only).  out16: optional fp16 copy of the context with
-    the strides of ``out`` (the "mixed16" operand of the out-proj GEMM)."""
+    the strides of ``out`` (the "mixed16" operand of the out-proj GEMM).  tiled=True takes the tiled flash-style kernels
+    also where the head would fit the whole-head kernels (per call: tests exercise both paths)."""
     lib = _lib.load()
     for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         _mat(t, n)
     if scale is None:
         scale = 1.0 / math.sqrt(64.0)
-    if out16 is not None or keepbits is not None:
+    if out16 is not None or keepbits is not None or tiled:
         if out16 is not None:
             _mat(out16, "out16", F16)
             if tuple(out16.shape) != tuple(out.shape) or out16.stride(0) != out.stride(0):
@@ -474,7 +516,8 @@ def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed
             raise ValueError("keepbits: contiguous 32-bit device buffer of icka_attn_keepbits_words words (attn_keepbits)")
         check(lib.icka_attn_fwd_ex(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                    add_mask.data_ptr(), out.data_ptr(), _ptr(out16), out.stride(0), _ptr(lse), B, heads,
-                                   Sq, Skv, scale, p_drop, seed, int(bool(fp8)), _ptr(keepbits), _stream()), "icka_attn_fwd_ex")
+                                   Sq, Skv, scale, p_drop, seed, (_lib.ATTN_FP8 if fp8 else 0) | (_lib.ATTN_TILED if tiled else 0),
+                                   _ptr(keepbits), _stream()), "icka_attn_fwd_ex")
         return out
     fn = lib.icka_attn_fwd_fp8 if fp8 else lib.icka_attn_fwd
     check(fn(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), add_mask.data_ptr(),
@@ -484,7 +527,7 @@ def attn_fwd(q, k, v, add_mask, out, lse, B, heads, Sq, Skv, *, p_drop=0.0, seed
 
 
 def attn_bwd(q, k, v, add_mask, out, dout, lse, delta, dq, dk, dv, B, heads, Sq, Skv, *, p_drop=0.0, seed=0,
-             scale=None, keepbits=None):
+             scale=None, keepbits=None, tiled=False):
     lib = _lib.load()
     for n, t in (("q", q), ("k", k), ("v", v), ("out", out), ("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
         _mat(t, n)
@@ -494,16 +537,11 @@ def attn_bwd(q, k, v, add_mask, out, dout, lse, delta, dq, dk, dv, B, heads, Sq,
                             add_mask.data_ptr(), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0),
                             lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
                             dk.stride(0), dv.data_ptr(), dv.stride(0), B, heads, Sq, Skv, scale, p_drop, seed,
-                            _ptr(keepbits), _stream()), "icka_attn_bwd")
-
-
-def attn_set_whole_head(on: bool) -> None:
-    """False forces the tiled attention kernels for every shape (tests exercise both paths)."""
-    _lib.load().icka_attn_set_whole_head(int(bool(on)))
+                            _ptr(keepbits), _lib.ATTN_TILED if tiled else 0, _stream()), "icka_attn_bwd")
 
 
 # ------------------------------------------------------------------------------------------------- LSTM
-def lstm_fwd(gates_x, w_hh, y, c_all, act, hprev, B, S, H):
+def lstm_fwd(gates_x, w_hh, y, c_all, act, hprev, B, S, H, flags=0):
     """gates_x f32 [B*S, 8H]; w_hh bf16 [8H, H] (= [2][4H][H]); y bf16 [B*S, 2H]; c_all f32 [B*S, 2H];
     act bf16 [B*S, 8H]; hprev bf16 [B*S, 2H] or None."""
     _dev(gates_x, "gates_x")
@@ -515,10 +553,10 @@ def lstm_fwd(gates_x, w_hh, y, c_all, act, hprev, B, S, H):
         if t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous():
             raise ValueError("%s must be contiguous %s %s" % (n, dt, shp))
     check(_lib.load().icka_lstm_fwd(gates_x.data_ptr(), gates_x.stride(0), w_hh.data_ptr(), y.data_ptr(),
-                                    c_all.data_ptr(), act.data_ptr(), _ptr(hprev), B, S, H, _stream()), "icka_lstm_fwd")
+                                    c_all.data_ptr(), act.data_ptr(), _ptr(hprev), B, S, H, int(flags), _stream()), "icka_lstm_fwd")
 
 
-def lstm_bwd(dy, w_hh_t, act, c_all, dgates, dc_carry, B, S, H):
+def lstm_bwd(dy, w_hh_t, act, c_all, dgates, dc_carry, B, S, H, flags=0):
     for n, t, shp, dt in (("dy", dy, (B * S, 2 * H), BF16), ("w_hh_t", w_hh_t, (2 * H, 4 * H), BF16),
                           ("act", act, (B * S, 8 * H), BF16), ("c_all", c_all, (B * S, 2 * H), F32),
                           ("dgates", dgates, (B * S, 8 * H), BF16), ("dc_carry", dc_carry, (2 * B, H), F32)):
@@ -526,7 +564,7 @@ def lstm_bwd(dy, w_hh_t, act, c_all, dgates, dc_carry, B, S, H):
         if t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous():
             raise ValueError("%s must be contiguous %s %s" % (n, dt, shp))
     check(_lib.load().icka_lstm_bwd(dy.data_ptr(), w_hh_t.data_ptr(), act.data_ptr(), c_all.data_ptr(),
-                                    dgates.data_ptr(), dgates.stride(0), dc_carry.data_ptr(), B, S, H, _stream()),
+                                    dgates.data_ptr(), dgates.stride(0), dc_carry.data_ptr(), B, S, H, int(flags), _stream()),
           "icka_lstm_bwd")
 
 
@@ -546,7 +584,7 @@ def lstm_check_error(where: str = "") -> None:
             "icka_amd BiLSTM%s: a block of a persistent LSTM launch gave up waiting for another block's words (status %d): "
             "the grid was not co-resident (another kernel held its CUs, e.g. a collective on the communication stream, or "
             "the GPU is partitioned / shared).  The outputs and gradients of that call are NaN.  Reserve CUs "
-            "(icka_lstm_set_reserved_cus) or take the per-step launches (icka_lstm_set_persistent(0))."
+            "(icka_lstm_set_reserved_cus) or take the per-step launches (BiLSTM.recurrence_flags = LSTM_PER_STEP)."
             % ((" (" + where + ")") if where else "", rc))
 
 

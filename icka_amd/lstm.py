@@ -34,7 +34,8 @@ class _LstmFn(torch.autograd.Function):
         act = torch.empty(M, 8 * H, dtype=BF16, device=dev)
         save = any(ctx.needs_input_grad)
         hprev = torch.empty(M, 2 * H, dtype=BF16, device=dev) if save else None
-        K.lstm_fwd(gx, A.w_cat((mod.weight_hh_l0, mod.weight_hh_l0_reverse)), y, c_all, act, hprev, B, S, H)
+        K.lstm_fwd(gx, A.w_cat((mod.weight_hh_l0, mod.weight_hh_l0_reverse)), y, c_all, act, hprev, B, S, H,
+                   flags=mod.recurrence_flags)
         ctx.mod, ctx.A, ctx.dims = mod, A, (B, S, H)
         ctx.need_dx = x.requires_grad
         if save:
@@ -56,7 +57,7 @@ class _LstmFn(torch.autograd.Function):
         whh_t = K.transpose_bf16(whh, torch.empty(2 * H, 4 * H, dtype=BF16, device=dev), 2, 4 * H, H)
         dgates = torch.empty(M, 8 * H, dtype=BF16, device=dev)
         carry = torch.empty(2 * B, H, dtype=F32, device=dev)
-        K.lstm_bwd(dy, whh_t, act, c_all, dgates, carry, B, S, H)
+        K.lstm_bwd(dy, whh_t, act, c_all, dgates, carry, B, S, H, flags=mod.recurrence_flags)
         # parameter gradients: GEMMs / column sums over all steps
         wih = (mod.weight_ih_l0, mod.weight_ih_l0_reverse)
         K.gemm(K.GEMM_TN, dgates, x, A.g_cat(wih), beta=A.grad_beta(wih))
@@ -87,6 +88,9 @@ class BiLSTM(ArenaModule):
             raise ValueError("hidden_size must be a multiple of 32 and input_size of 8 (MFMA / 16-byte tiles)")
         self.config = None
         self.input_size, self.hidden_size, self.batch_first = input_size, hidden_size, batch_first
+        # which form of the recurrence this module's calls take (icka_hip.h: ICKA_LSTM_*; 0 = one persistent launch with the
+        # tagged-word hand-off).  A per-module, per-call argument: the library keeps no process-wide switch.
+        self.recurrence_flags = 0
         H = hidden_size
         for sfx in ("", "_reverse"):
             self.register_parameter("weight_ih_l0" + sfx, nn.Parameter(torch.empty(4 * H, input_size)))

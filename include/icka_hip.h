@@ -8,6 +8,14 @@
  *
  * Return value: 0 on success, a positive hipError_t from the launch, or a negative ICKA_E_* argument error.
  * Nothing here allocates, frees or synchronises: every call is stream-ordered and hipGraph-capturable.
+ *
+ * Re-entrancy: the compute entry points read NO mutable process state.  What varies between launches of
+ * one shape -- the alternative kernels the tests exercise, A/B runs of a heuristic -- is an explicit per-call argument
+ * (icka_gemm_desc.tune, the `flags` of icka_attn_* / icka_lstm_*) or an ICKA_TUNE_* environment variable read ONCE when the
+ * library is loaded; there are no tuning setters.  The only process-wide controls left are documented where they are declared:
+ * the dropout nonce registration (icka_set_dropout_nonce), the error words of the persistent kernels
+ * (icka_lstm_clear_error, icka_dp_clear_error), the CU reservation beside RCCL (icka_lstm_set_reserved_cus) and the test hooks
+ * of the give-up paths (icka_lstm_test_hooks).
  */
 #ifndef ICKA_HIP_H
 #define ICKA_HIP_H
@@ -31,8 +39,12 @@ extern "C" {
  *    (the data-parallel wire copy, c3_only); icka_dp_*; icka_regions_to_tokens_h, icka_sample_gate_fwd_h, icka_optim_* (additive).
  * 5: round 4 -- icka_dp_flag_wait's third argument is the bucket's BAD WORD (it no longer writes the NaN itself);
  *    icka_dp_poison_if, icka_dp_poison_final, icka_copy_many, icka_embed_bwd_rows, icka_embed_scatter_rows,
- *    icka_ln_set_rows_per_wave, icka_gemm_set_square_tiles, icka_gemm_set_persistent (additive); icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN. */
-#define ICKA_ABI_VERSION 5
+ *    icka_ln_set_rows_per_wave, icka_gemm_set_square_tiles, icka_gemm_set_persistent (additive); icka_gemm refuses an f32 output with a wire copy (C3) unless op == TN.
+ * 6: round 5 -- every tuning setter is GONE (icka_gemm_set_*, icka_ln_set_rows_per_wave, icka_attn_set_whole_head,
+ *    icka_lstm_set_persistent / _handoff / _batch_split): icka_gemm_desc grew `tune`; icka_attn_fwd_ex's `fp8` argument became
+ *    `flags`; icka_attn_bwd, icka_lstm_fwd and icka_lstm_bwd take `flags`; the 256x256-tile and persistent 12-wave GEMM kernels
+ *    those setters switched on left the library (profiles/NEGATIVE_RESULTS.md). */
+#define ICKA_ABI_VERSION 6
 int icka_abi_version(void);
 const char* icka_build_arch(void);
 
@@ -92,7 +104,38 @@ typedef struct icka_gemm_desc {
     int32_t c3_only;       /* f32 C with a wire copy C3, beta == 0, no epilogue: store ONLY C3 (2 bytes per element instead of
                               4 + 2); C is left untouched -- icka_amd/dp.py writes it from the reduced wire buffer
                               (icka_dp_cast_back_scaled), which is the only consumer of such a gradient before that point */
+    uint64_t tune;         /* 0 = the library's per-shape heuristics (the ICKA_TUNE_GEMM_* environment read at load, if set);
+                              else an OR of ICKA_TUNE_* words that force single choices for THIS call (tests of the alternative
+                              kernels, probes).  Results never depend on it; a code outside a field's range is ICKA_E_ARG.
+                              A grouped launch takes the word of its first problem. */
 } icka_gemm_desc;
+/* icka_gemm_desc.tune fields (4 bits each; environment equivalents in parentheses):
+ *   RING(n)        LDS-DMA ring depth of the fast path, n = 2 .. 5 (ICKA_TUNE_GEMM_RING): 2 = 64 KiB, two blocks per CU; 3 / 4 =
+ *                  96 / 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier.  Default: ring 2
+ *                  with two co-resident blocks for short-K grids of >= ~2 tiles per CU, ring 3 otherwise.
+ *   TILE_N(n)      output-tile width of the warp-specialised path, n = 96 | 128 (ICKA_TUNE_GEMM_TILE_N).  Default: the narrower
+ *                  tile when it quantises better onto the 256 CUs (N = 768: 256 tiles instead of 192); 96 needs N % 96 == 0.
+ *   WIDE_TILES(b)  256x192 / 256x128 tiles of the 12-wave kernel for wide outputs with a short reduction whose tile grid
+ *                  covers the CUs in one round (ICKA_TUNE_GEMM_WIDE_TILES; default on).
+ *   DIRECT_EPILOGUE(b)  f32 outputs without activation / fan-in operand / accumulate stored straight from the MFMA
+ *                  accumulators (default on); off: every epilogue goes through the LDS C tile (ICKA_TUNE_GEMM_DIRECT_EPILOGUE).
+ *   WARP_SPECIALIZED(v)  1 (default): 512-thread fast path (4 loader + 4 compute waves; two blocks per CU for large grids),
+ *                  0: 256-thread single-role path, 2: force two blocks, 3: never two (ICKA_TUNE_GEMM_WARP_SPECIALIZED).
+ *   W3_GRID(pm)    XCD cut of the 12-wave kernel's tile grid, pm = 1 | 2 | 4 | 8 where it divides the grid: the 8 XCDs (private
+ *                  L2s) take a pm x pn patch grid of the tiles, the chip then fetches pn * |A| + pm * |B|
+ *                  (ICKA_TUNE_GEMM_W3_GRID).  Default: the dividing cut with the smallest pn * M + pm * N.
+ *   BIG_TILES(v)   grouped TN launches of plain f32 outputs with M % 256 == 0 (the weight gradients of a layer): 2 (default)
+ *                  = 256x128 tiles in 12-wave blocks with the fused column sums in extra blocks of the grid, 1 = 8-wave
+ *                  blocks, 0 = 128x128 tiles (ICKA_TUNE_GEMM_BIG_TILES).
+ *   ABLATION(m)    diagnostic builds only, WRONG results: 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging. */
+#define ICKA_TUNE_RING(n) ((uint64_t)(n) << 0)
+#define ICKA_TUNE_TILE_N(n) ((uint64_t)((n) == 96 ? 1 : ((n) == 128 ? 2 : 15)) << 4)
+#define ICKA_TUNE_WIDE_TILES(b) ((uint64_t)((b) ? 2 : 1) << 8)
+#define ICKA_TUNE_DIRECT_EPILOGUE(b) ((uint64_t)((b) ? 2 : 1) << 12)
+#define ICKA_TUNE_WARP_SPECIALIZED(v) ((uint64_t)((v) + 1) << 16)
+#define ICKA_TUNE_W3_GRID(pm) ((uint64_t)(pm) << 20)
+#define ICKA_TUNE_BIG_TILES(v) ((uint64_t)((v) + 1) << 24)
+#define ICKA_TUNE_ABLATION(m) ((uint64_t)(m) << 28)
 int icka_gemm(const icka_gemm_desc* d, void* stream);
 /* n independent GEMMs; consecutive fast-path problems of one layout are packed (up to 4) into ONE launch so that
  * several partially-filling grids (the weight-gradient GEMMs of a layer) fill the chip together. */
@@ -107,42 +150,6 @@ typedef struct icka_slab_reduction {
 } icka_slab_reduction;
 int icka_gemm_grouped_ex(const icka_gemm_desc* descs, int32_t n, const icka_slab_reduction* reds, int32_t n_red,
                          void* stream);
-/* Tuning knob of the aligned fast path: depth of the LDS-DMA ring (2: 64 KiB LDS, two blocks per CU; 3 / 4: 96 /
- * 128 KiB, one block per CU, one / two k-tiles of DMA kept in flight across the barrier).  0 (default) = per-shape
- * choice: ring 2 with two co-resident blocks for short-K grids of >= ~2 tiles per CU, ring 3 otherwise. */
-int icka_gemm_set_ring(int nbuf);
-/* Output-tile width of the warp-specialised fast path: 0 (default) = per-shape choice between 128x128 and 128x96
- * tiles (the narrower tile when it quantises better onto the 256 CUs: N = 768 gives 256 tiles instead of 192),
- * 128 / 96 = forced where applicable (96 needs N % 96 == 0 on top of the fast-path alignment). */
-int icka_gemm_set_tile_n(int bn);
-/* 256x192 output tiles (12-wave kernel) for wide outputs with a short reduction whose tile grid covers the 256 CUs in one
- * round (M % 256 == 0, N % 192 == 0, K <= 1024, 128..256 tiles): on by default; 0 switches back to 128x128 tiles. */
-int icka_gemm_set_wide_tiles(int on);
-int icka_gemm_set_persistent(int on);     /* persistent form of the 12-wave kernel: 0 off (default), 1 = 256x128 tiles in whole
-                                             multiples of 256 tiles with K <= 1024, 2 = also 256x192 tiles (tests) */
-int icka_gemm_set_square_tiles(int on);   /* 256x256 tiles of the 8-wave load+compute kernel: 0 off (default), 1 by shape,
-                                             2 wherever the tile divides the output (tests) */
-/* 1 (default): f32 outputs without activation / fan-in operand / accumulate are stored straight from the MFMA
- * accumulators; 0: every epilogue goes through the LDS C tile (16-byte row-contiguous stores). */
-int icka_gemm_set_direct_epilogue(int on);
-/* Grouped TN launches whose problems are plain f32 outputs with M % 256 == 0 (the weight gradients of a layer,
- * overwrite or beta-accumulate) use 256x128 output tiles and compute their fused column sums in extra blocks of the
- * same grid.  2 (default): 12-wave blocks (8 compute waves of 64x64 + 4 loader waves); 1: 8-wave blocks (4 compute
- * waves of 128x64); 0: 128x128 tiles. */
-int icka_gemm_set_big_tiles(int on);
-/* Diagnostic only (wrong results): 1 = skip MFMA + LDS reads, 2 = skip the LDS-DMA staging; 0 = normal. */
-int icka_gemm_set_ablation(int mode);
-/* 1 (default): 512-thread warp-specialised fast path (4 loader + 4 compute waves); 0: 256-thread single-role path. */
-int icka_gemm_set_warp_specialized(int on);
-/* XCD cut of the 12-wave kernel's tile grid (256 x 192 / 256 x 128 tiles): the 8 XCDs (private L2s) take a pm x pn patch grid of
- * the tiles, the chip then fetches pn * |A| + pm * |B|.  0 (default): per shape, the dividing cut with the smallest
- * pn * M + pm * N; 8 / 4 / 2 / 1: force pm where it divides the tile grid (8 = the row-major runs of rounds 1-2).  Results
- * do not depend on it. */
-int icka_gemm_set_w3_grid(int pm);
-/* Diagnostic builds (-DICKA_GEMM_STAMP) only: device buffer of [blocks][8] u64 receiving per-segment cycle sums of
- * the fast-path k-loop (vmcnt wait, barrier, DMA issue, LDS reads+MFMA, total cycles, 100 MHz real-time ticks, nk). */
-int icka_gemm_set_stamp_buffer(void* p);
-
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused  y = LayerNorm(dropout(x + bias) + residual)   (BertSelfOutput.forward :561-565, BertOutput.forward
  * :532-536, BertLayerNorm.forward :518-522: biased variance, eps inside the sqrt).  One wave per row.
@@ -151,10 +158,9 @@ int icka_gemm_set_stamp_buffer(void* p);
  *   optional second bf16 copy (ldy2); y_f32 optional contiguous f32 copy (the residual stream is carried in f32
  *   so bf16 rounding does not accumulate over layers); xhat [M,H] bf16 contiguous and rstd f32[M] are the saved
  *   statistics for backward (may be NULL in inference).
- * icka_ln_set_rows_per_wave(rows): rows a forward wave owns (1 .. 16, 0 = automatic: two from 4096 rows on; process-global
- *   tuning knob).  With more than one, the loads of a wave's next row are issued before the current row is reduced and stored.
+ * A forward wave owns two rows from 4096 rows on (the loads of its next row are issued before the current row is reduced and
+ *   stored), else one; ICKA_TUNE_LN_ROWS_PER_WAVE = 1 .. 16 (read once at load) replaces that choice for A/B runs.
  */
-int icka_ln_set_rows_per_wave(int32_t rows);
 int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias, const void* residual, int64_t ldr,
                 int32_t res_is_f32, const float* gamma, const float* beta, void* y, int64_t ldy, void* y2,
                 int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop,
@@ -257,6 +263,8 @@ int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int64_t ldk, co
 /* icka_attn_fwd / icka_attn_fwd_fp8 (fp8 != 0) with an additional fp16 copy O_f16 (may be NULL; same leading dimension
  * ldo) of the context: the "mixed16" mode feeds it to the out-proj GEMM as fp16 operand, O (bf16) stays the operand of
  * the bf16 weight-gradient GEMM and of icka_attn_bwd.
+ * flags: ICKA_ATTN_FP8 = the fp8 QK^T / PV form (icka_attn_fwd_fp8); ICKA_ATTN_TILED = take the tiled flash-style kernels
+ * also where the head would fit the whole-head kernels below (per call; the tests exercise both paths).
  * keep_bits (may be NULL; used when p_drop > 0): icka_attn_keepbits_words(B, heads, Sq, Skv) 32-bit words that receive the
  * keep decisions of the attention-probability dropout (nn.Dropout on the probabilities, :500 / :616) -- the same decisions
  * icka_attn_dropout_mask materialises -- so that icka_attn_bwd, given the same buffer, reads bits instead of hashing every
@@ -264,20 +272,22 @@ int icka_attn_fwd_fp8(const void* Q, int64_t ldq, const void* K, int64_t ldk, co
  * ceil(Skv / 128) words, bit (key / 16) * 4 + key % 4.  Round 3: ABI version 4 added this parameter. */
 int icka_attn_fwd_ex(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                      const float* add_mask, void* O, void* O_f16, int64_t ldo, float* lse, int32_t B, int32_t heads,
-                     int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, int32_t fp8, void* keep_bits,
+                     int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, int32_t flags, void* keep_bits,
                      void* stream);
+#define ICKA_ATTN_FP8 1
+#define ICKA_ATTN_TILED 2
 int64_t icka_attn_keepbits_words(int32_t B, int32_t heads, int32_t Sq, int32_t Skv);
 /* Heads with Sq <= 128 and Skv <= 128 (the reference's max_seq_length 128 and 36/49 regions) take the whole-head
  * kernels: one block per (batch, head), forward without online-softmax rescaling, backward (dQ, dK, dV, delta) in
- * one launch.  icka_attn_set_whole_head(0) forces the tiled flash-style kernels for every shape (default 1). */
-void icka_attn_set_whole_head(int32_t on);
+ * one launch (ICKA_ATTN_TILED in a call's flags takes the tiled kernels instead). */
 /* delta f32 [B,heads,Sq] is workspace (rowsum(dO*O) = rowsum(P.dP)); it is written by the call.  keep_bits: NULL, or the
  * buffer the forward (icka_attn_fwd_ex) filled for the same shape, seed and replay nonce (whole-head kernels read it, the tiled
  * ones hash). */
 int icka_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const float* add_mask, const void* O, int64_t ldo, const void* dO, int64_t lddo, const float* lse,
                   float* delta, void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int32_t B,
-                  int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, const void* keep_bits, void* stream);
+                  int32_t heads, int32_t Sq, int32_t Skv, float scale, float p_drop, uint64_t seed, const void* keep_bits,
+                  int32_t flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Element-wise / layout helpers.
@@ -414,21 +424,24 @@ int icka_crf_decode(const float* emissions, int64_t ld, const int64_t* mask, con
  *                  pre-activation gradients dgates bf16 [B*S, ldg >= 8H]; dW_ih, dW_hh, db and dx are GEMMs / column
  *                  sums over dgates afterwards.  dc_carry f32 [2,B,H] is workspace. */
 int icka_lstm_fwd(const float* gates_x, int64_t ldg, const void* w_hh, void* y, float* c_all, void* act, void* hprev,
-                  int32_t B, int32_t S, int32_t H, void* stream);
+                  int32_t B, int32_t S, int32_t H, int32_t flags, void* stream);
 int icka_lstm_bwd(const void* dy, const void* w_hh_t, const void* act, const float* c_all, void* dgates, int64_t ldg,
-                  float* dc_carry, int32_t B, int32_t S, int32_t H, void* stream);
-/* 1 (default): for B <= 32 and H <= 768 the recurrence is ONE persistent launch per direction pair -- W_hh slices and
- * cell state resident in registers, a per-direction grid barrier (device-scope release/acquire + atomic ticket) between
- * steps; 0: one launch per time step.  icka_lstm_barrier_error() returns 1 if a barrier wait ever gave up (bounded
- * spin: the kernel then finishes with invalid data instead of hanging), -1 if the query itself failed. */
-int icka_lstm_set_persistent(int32_t on);
-/* hand-off between the blocks of a persistent launch: 1 (default) = flag-in-data 8-byte words polled by the consumers (H % 256
- * == 0 shapes; others use the ticket form) -- forward broadcasts h_t, backward reduce-scatters bf16 partial products of
- * dgates_t . W_hh --, 0 = step tickets + L1 invalidate.  Same forward results; backward gradients agree to bf16 rounding. */
-int icka_lstm_set_handoff(int32_t mode);
-/* 1 (default): in the forward launch with the tagged-word hand-off a batch of 17..32 rows runs as two independent tiles of
- * 16 rows (separate blocks); 0: one block per 16 hidden units holds all rows.  Same results. */
-int icka_lstm_set_batch_split(int32_t on);
+                  float* dc_carry, int32_t B, int32_t S, int32_t H, int32_t flags, void* stream);
+/* flags of icka_lstm_fwd / icka_lstm_bwd (0 = the defaults; per call, no process-wide switch):
+ *   default            for B <= 32 and H <= 768 the recurrence is ONE persistent launch per direction pair -- W_hh slices and cell
+ *                      state resident in registers; the blocks hand h_t over as flag-in-data 8-byte words polled by the consumers
+ *                      (H % 256 == 0 shapes; others use the ticket form): forward broadcasts h_t, backward reduce-scatters bf16
+ *                      partial products of dgates_t . W_hh; in the forward a batch of 17..32 rows runs as two independent tiles
+ *                      of 16 rows (separate blocks).
+ *   ICKA_LSTM_PER_STEP        one launch per time step instead of the persistent launch.
+ *   ICKA_LSTM_TICKETS         persistent launch with step tickets + L1 invalidate instead of tagged words (same forward
+ *                             results; backward gradients agree to bf16 rounding).
+ *   ICKA_LSTM_NO_BATCH_SPLIT  one block per 16 hidden units holds all rows (same results).
+ * icka_lstm_barrier_error() returns 1 if a hand-off wait ever gave up (bounded spin: the kernel then finishes with NaN-poisoned
+ * data instead of hanging), -1 if the query itself failed. */
+#define ICKA_LSTM_PER_STEP 1
+#define ICKA_LSTM_TICKETS 2
+#define ICKA_LSTM_NO_BATCH_SPLIT 4
 /* The persistent launches wait on words written by other blocks of the same grid, with a bounded spin.  A wait that gives
  * up (a peer block that never became resident, a lost word) raises a sticky error word AND poisons the recurrence: the
  * waiting block continues with NaN operands, so every later step of every block -- y, the loss, every gradient of the

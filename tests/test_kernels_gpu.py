@@ -185,151 +185,54 @@ def test_gemm_epilogues_and_dual_k():
 @pytest.mark.parametrize("op", ["NT", "NN"])
 @pytest.mark.parametrize("M,N,K", [(4096, 2304, 768), (4096, 3072, 768), (2048, 3072, 64), (4096, 1536, 1024), (4096, 3072, 192),
                                    (8192, 1024, 1024), (8192, 1024, 3072), (8192, 768, 768), (6144, 1024, 192)])
-def test_gemm_wide_tiles(M, N, K, op, wide, request):
+def test_gemm_wide_tiles(M, N, K, op, wide):
     """256x192-tile kernel (qkv / ffn-up / d-ffn-down shapes: 128..256 tiles of one round) and its 256x128-tile form (192..256
     tiles: N = 1024 / 768 at M = 8192, long and short reductions) against fp32 matmul, with
     every epilogue those GEMMs use: bias, GELU (two outputs), GELU' (aux), fan-in add, f32 and bf16 outputs, odd and even
     k-tile counts; wide=0 runs the same calls on the 128x128 path."""
     k = _k()
-    lib = k._lib.load()
-    assert lib.icka_gemm_set_wide_tiles(wide) == 0
-    request.addfinalizer(lambda: lib.icka_gemm_set_wide_tiles(1))
+    T = k.gemm_tune(wide_tiles=bool(wide))      # a per-call word of the descriptor: no process-wide switch
     A = rnd(M, K, seed=1, scale=0.5)
     B = rnd(N, K, seed=2, scale=0.5) if op == "NT" else rnd(K, N, seed=2, scale=0.5)
     kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
     bias = rnd(N, seed=3, dtype=F32)
     ref = A.float() @ (B.float().t() if op == "NT" else B.float())
     o = torch.empty(M, N, dtype=BF16, device="cuda")
-    k.gemm(kop, A, B, o)
+    k.gemm(kop, A, B, o, tune=T)
     assert rel_err(o, ref) < 1e-2
     of = torch.empty(M, N, dtype=F32, device="cuda")
-    k.gemm(kop, A, B, of, bias=bias)
+    k.gemm(kop, A, B, of, bias=bias, tune=T)
     assert rel_err(of, ref + bias) < 1e-4
     z = torch.empty_like(o)
-    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z, tune=T)
     assert rel_err(z, ref + bias) < 1e-2 and rel_err(o, torch.nn.functional.gelu(ref + bias)) < 1e-2
     aux = rnd(M, N, seed=4)
-    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
+    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux, tune=T)
     x = aux.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     assert rel_err(o, ref * x.grad) < 1e-2
-    k.gemm(kop, A, B, o, epilogue=k.EPI_ADD, aux=aux)
+    k.gemm(kop, A, B, o, epilogue=k.EPI_ADD, aux=aux, tune=T)
     assert rel_err(o, ref + aux.float()) < 1e-2
     ov = torch.empty(M, N + 64, dtype=BF16, device="cuda")[:, :N]      # strided output view
-    k.gemm(kop, A, B, ov, alpha=0.5)
+    k.gemm(kop, A, B, ov, alpha=0.5, tune=T)
     assert rel_err(ov, 0.5 * ref) < 1e-2
-
-
-@pytest.mark.parametrize("op", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (8192, 4096, 1024), (8192, 3072, 64), (16384, 1536, 192), (8192, 2048, 128)])
-def test_gemm_persistent_wide_tiles(M, N, K, op, request):
-    """Persistent form of the 12-wave kernel (gemm_w3p_kernel: one block per CU walks 2 - 4 tiles of 256 x 192 / 256 x 128, the
-    loader waves issue the next tile's first k-tiles under the epilogue, ring slots numbered across tiles) == the one-tile-per-
-    block kernels bitwise for the plain bf16 output, and against fp32 matmul with the epilogues these GEMMs use; one, two, three
-    and many k-tiles per tile (ring hand-over across tiles at every phase of the 3-slot / 2-slot rings)."""
-    k = _k()
-    lib = k._lib.load()
-    request.addfinalizer(lambda: lib.icka_gemm_set_persistent(0))
-    A = rnd(M, K, seed=31, scale=0.5)
-    B = rnd(N, K, seed=32, scale=0.5) if op == "NT" else rnd(K, N, seed=32, scale=0.5)
-    kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
-    bias = rnd(N, seed=33, dtype=F32)
-    ref = A.float() @ (B.float().t() if op == "NT" else B.float())
-    lib.icka_gemm_set_persistent(0)
-    o0 = torch.empty(M, N, dtype=BF16, device="cuda")
-    k.gemm(kop, A, B, o0)
-    assert lib.icka_gemm_set_persistent(2) == 0
-    o = torch.full((M, N), float("nan"), dtype=BF16, device="cuda")
-    k.gemm(kop, A, B, o)
-    assert torch.isfinite(o.float()).all()                   # no tile left out
-    assert rel_err(o, ref) < 1e-2
-    assert torch.equal(o, o0)
-    of = torch.empty(M, N, dtype=F32, device="cuda")
-    k.gemm(kop, A, B, of, bias=bias)
-    assert rel_err(of, ref + bias) < 1e-4
-    z = torch.empty_like(o)
-    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z)
-    assert rel_err(z, ref + bias) < 1e-2 and rel_err(o, torch.nn.functional.gelu(ref + bias)) < 1e-2
-    aux = rnd(M, N, seed=34)
-    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
-    x = aux.float().requires_grad_(True)
-    torch.nn.functional.gelu(x).sum().backward()
-    assert rel_err(o, ref * x.grad) < 1e-2
-    ov = torch.empty(M, N + 64, dtype=BF16, device="cuda")[:, :N]      # strided output view
-    k.gemm(kop, A, B, ov, alpha=0.5)
-    assert rel_err(ov, 0.5 * ref) < 1e-2
-    if op == "NT":
-        oh = torch.empty(M, N, dtype=torch.float16, device="cuda")
-        k.gemm(kop, A.to(torch.float16), B.to(torch.float16), oh, bias=bias)
-        assert rel_err(oh, A.to(torch.float16).float() @ B.to(torch.float16).float().t() + bias) < 2e-3
-
-
-@pytest.mark.parametrize("op", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K,forced", [(8192, 4096, 1024, 1), (2048, 1024, 64, 2), (2048, 2048, 192, 2), (4096, 1024, 3072, 2),
-                                          (2048, 512, 128, 2)])
-def test_gemm_square_tiles(M, N, K, forced, op, request):
-    """256x256-tile kernel (8 waves, all loading and computing; off by default -- profiles/NEGATIVE_RESULTS.md; bert-large's ffn-up /
-    d(ffn-down) shape 8192 x 4096 x 1024 takes it by shape when enabled, the small cases force it) against fp32 matmul with every epilogue those GEMMs use, one / two / three / many k-tiles
-    (the two-stage ring's prologue, steady state and drain), fp16 operands, strided outputs; and bitwise against the 128x128
-    path's result for the plain bf16 output (same MFMA k-order per output element)."""
-    k = _k()
-    lib = k._lib.load()
-    assert lib.icka_gemm_set_square_tiles(forced) == 0
-    request.addfinalizer(lambda: lib.icka_gemm_set_square_tiles(0))
-    A = rnd(M, K, seed=21, scale=0.5)
-    B = rnd(N, K, seed=22, scale=0.5) if op == "NT" else rnd(K, N, seed=22, scale=0.5)
-    kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
-    bias = rnd(N, seed=23, dtype=F32)
-    ref = A.float() @ (B.float().t() if op == "NT" else B.float())
-    o = torch.full((M, N), float("nan"), dtype=BF16, device="cuda")
-    k.gemm(kop, A, B, o)
-    assert torch.isfinite(o.float()).all()                   # no tile left out
-    assert rel_err(o, ref) < 1e-2
-    lib.icka_gemm_set_square_tiles(0)
-    o128 = torch.empty_like(o)
-    k.gemm(kop, A, B, o128)
-    lib.icka_gemm_set_square_tiles(forced)
-    assert torch.equal(o, o128)
-    of = torch.empty(M, N, dtype=F32, device="cuda")
-    k.gemm(kop, A, B, of, bias=bias)
-    assert rel_err(of, ref + bias) < 1e-4
-    z = torch.empty_like(o)
-    k.gemm(kop, A, B, o, bias=bias, epilogue=k.EPI_GELU, out2=z)
-    assert rel_err(z, ref + bias) < 1e-2 and rel_err(o, torch.nn.functional.gelu(ref + bias)) < 1e-2
-    aux = rnd(M, N, seed=24)
-    k.gemm(kop, A, B, o, epilogue=k.EPI_DGELU, aux=aux)
-    x = aux.float().requires_grad_(True)
-    torch.nn.functional.gelu(x).sum().backward()
-    assert rel_err(o, ref * x.grad) < 1e-2
-    k.gemm(kop, A, B, o, epilogue=k.EPI_ADD, aux=aux)
-    assert rel_err(o, ref + aux.float()) < 1e-2
-    ov = torch.empty(M, N + 64, dtype=BF16, device="cuda")[:, :N]      # strided output view
-    k.gemm(kop, A, B, ov, alpha=0.5)
-    assert rel_err(ov, 0.5 * ref) < 1e-2
-    if op == "NT":                                                     # the "mixed16" forward form: fp16 operands and output
-        oh = torch.empty(M, N, dtype=torch.float16, device="cuda")
-        k.gemm(kop, A.to(torch.float16), B.to(torch.float16), oh, bias=bias)
-        assert rel_err(oh, A.to(torch.float16).float() @ B.to(torch.float16).float().t() + bias) < 2e-3
 
 
 @pytest.mark.parametrize("M,N,K,op", [(4096, 3072, 768, "NT"), (4096, 2304, 768, "NT"), (4096, 3072, 768, "NN"), (2048, 3072, 192, "NT"),
                                       (8192, 1024, 1024, "NN"), (6144, 1024, 192, "NT")])
-def test_gemm_wide_tiles_xcd_cut_does_not_change_results(M, N, K, op, request):
-    """The 12-wave kernel cuts its tile grid over the 8 XCDs per shape (icka_gemm_set_w3_grid: 0 = pick the cut, 8 / 4 / 2 / 1 =
+def test_gemm_wide_tiles_xcd_cut_does_not_change_results(M, N, K, op):
+    """The 12-wave kernel cuts its tile grid over the 8 XCDs per shape (ICKA_TUNE_W3_GRID: default = pick the cut, 8 / 4 / 2 / 1 =
     force the number of patch rows where it divides the grid): every forced cut covers every tile exactly once -- bitwise the
     result of the default."""
     k = _k()
-    lib = k._lib.load()
-    request.addfinalizer(lambda: lib.icka_gemm_set_w3_grid(0))
     A = rnd(M, K, seed=11, scale=0.5)
     B = rnd(N, K, seed=12, scale=0.5) if op == "NT" else rnd(K, N, seed=12, scale=0.5)
     kop = k.GEMM_NT if op == "NT" else k.GEMM_NN
     ref = A.float() @ (B.float().t() if op == "NT" else B.float())
     outs = []
     for pm in (0, 8, 4, 2, 1):
-        assert lib.icka_gemm_set_w3_grid(pm) == 0
         o = torch.full((M, N), float("nan"), dtype=BF16, device="cuda")
-        k.gemm(kop, A, B, o)
+        k.gemm(kop, A, B, o, tune=k.gemm_tune(w3_grid=pm) if pm else 0)
         assert torch.isfinite(o.float()).all(), pm          # no tile left out
         outs.append(o)
     assert rel_err(outs[0], ref) < 1e-2
@@ -339,39 +242,36 @@ def test_gemm_wide_tiles_xcd_cut_does_not_change_results(M, N, K, op, request):
 
 @pytest.mark.parametrize("tile_n", [96, 128])
 @pytest.mark.parametrize("M,N,K", [(128, 384, 64), (4096, 768, 768), (512, 2304, 768), (256, 768, 3072)])
-def test_gemm_tile_widths(M, N, K, tile_n, request):
+def test_gemm_tile_widths(M, N, K, tile_n):
     """128x96 and 128x128 output tiles of the warp-specialised path, all three layouts, fused epilogues."""
     k = _k()
-    from icka_amd import _lib
-    lib = _lib.load()
-    assert lib.icka_gemm_set_tile_n(tile_n) == 0
-    request.addfinalizer(lambda: lib.icka_gemm_set_tile_n(0))
+    T = k.gemm_tune(tile_n=tile_n)
     A, Bt, Bn = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5), rnd(K, N, seed=3, scale=0.5)
     bias, aux = rnd(N, seed=4, dtype=F32), rnd(M, N, seed=5)
     acc = A.float() @ Bt.float().t() + bias
     g = torch.empty(M, N, dtype=BF16, device="cuda"); z = torch.empty_like(g)
-    k.gemm(k.GEMM_NT, A, Bt, g, bias=bias, epilogue=k.EPI_GELU, out2=z)
+    k.gemm(k.GEMM_NT, A, Bt, g, bias=bias, epilogue=k.EPI_GELU, out2=z, tune=T)
     assert rel_err(z, acc) < 1e-2 and rel_err(g, torch.nn.functional.gelu(acc)) < 1e-2
     of = torch.full((M, N), 1.0, dtype=F32, device="cuda")
-    k.gemm(k.GEMM_NT, A, Bt, of, beta=1.0)
+    k.gemm(k.GEMM_NT, A, Bt, of, beta=1.0, tune=T)
     assert rel_err(of, A.float() @ Bt.float().t() + 1.0) < 1e-4
     o = torch.empty(M, N, dtype=BF16, device="cuda")
     for direct in (1, 0):   # plain outputs: straight from the accumulators, or through the LDS C tile
-        assert lib.icka_gemm_set_direct_epilogue(direct) == 0
-        k.gemm(k.GEMM_NT, A, Bt, o, bias=bias, alpha=0.5)
+        T = k.gemm_tune(tile_n=tile_n, direct_epilogue=bool(direct))
+        k.gemm(k.GEMM_NT, A, Bt, o, bias=bias, alpha=0.5, tune=T)
         assert rel_err(o, 0.5 * (A.float() @ Bt.float().t()) + bias) < 1e-2
-        k.gemm(k.GEMM_NT, A, Bt, of, bias=bias)
+        k.gemm(k.GEMM_NT, A, Bt, of, bias=bias, tune=T)
         assert rel_err(of, acc) < 1e-4
-    lib.icka_gemm_set_direct_epilogue(1)
-    k.gemm(k.GEMM_NN, A, Bn, o, epilogue=k.EPI_ADD, aux=aux)
+    T = k.gemm_tune(tile_n=tile_n)
+    k.gemm(k.GEMM_NN, A, Bn, o, epilogue=k.EPI_ADD, aux=aux, tune=T)
     assert rel_err(o, A.float() @ Bn.float() + aux.float()) < 1e-2
-    k.gemm(k.GEMM_NN, A, Bn, of)
+    k.gemm(k.GEMM_NN, A, Bn, of, tune=T)
     assert rel_err(of, A.float() @ Bn.float()) < 1e-4
     # TN: dW[M2, N] = At^T . X  with the fused column sums (bias gradient) of At
     At, X = rnd(K, 256, seed=6), rnd(K, N, seed=7)
     dw = torch.full((256, N), 0.5, dtype=F32, device="cuda")
     cs = torch.zeros(256, dtype=F32, device="cuda")
-    k.gemm(k.GEMM_TN, At, X, dw, beta=1.0, colsum_out=cs)
+    k.gemm(k.GEMM_TN, At, X, dw, beta=1.0, colsum_out=cs, tune=T)
     assert rel_err(dw, At.float().t() @ X.float() + 0.5) < 1e-4
     assert rel_err(cs, At.float().sum(0)) < 1e-4
 
@@ -405,14 +305,13 @@ def test_gemm_grouped_matches_individual_launches():
 
 
 @pytest.mark.parametrize("big", [1, 2, 0])
-def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
+def test_gemm_grouped_weight_gradient_layer_shapes(big):
     """The four weight-gradient GEMMs of a BERT layer as one grouped launch, overwrite mode (beta = 0) with fused bias
     gradients: 256x128-tile kernel with column-sum blocks in the same grid (big=1) vs the 128x128 group kernel."""
     k = _k()
     from icka_amd import _lib
     lib = _lib.load()
-    assert lib.icka_gemm_set_big_tiles(big) == 0
-    request.addfinalizer(lambda: lib.icka_gemm_set_big_tiles(2))
+    T = k.gemm_tune(big_tiles=big)       # a grouped launch takes the tune word of its first problem
     T, H, I = 1024, 768, 3072
     shapes = [(3 * H, H), (H, H), (I, H), (H, I)]
     descs, outs, refs, css, keep = [], [], [], [], []
@@ -421,7 +320,7 @@ def test_gemm_grouped_weight_gradient_layer_shapes(big, request):
         out = torch.full((m, n), 7.0, dtype=F32, device="cuda")          # overwritten, or accumulated into (i == 3)
         cs = torch.full((m,), 3.0, dtype=F32, device="cuda") if i != 1 else None
         descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=1.0 if i == 3 else 0.0, colsum_out=cs,
-                                 colsum_accumulate=(i == 2)))
+                                 colsum_accumulate=(i == 2), tune=T))
         keep.append((A, B)); outs.append(out); css.append(cs)
         refs.append(A.float().t() @ B.float() + (7.0 if i == 3 else 0.0))
     # two LayerNorm slab reductions ride on the launch (dgamma / dbeta of the layer's two LayerNorms)
@@ -557,12 +456,11 @@ def test_attn_dropout_mask_matches_the_numpy_restatement():
                                           (2, 2, 200, 130, 0.1), (1, 2, 256, 64, 0.1), (1, 2, 320, 50, 0.0),
                                           (2, 3, 180, 180, 0.1), (1, 2, 192, 150, 0.0), (1, 2, 150, 192, 0.1)])
 @pytest.mark.parametrize("whole_head", [True, False])
-def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
+def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head):
     k = _k()
     # whole_head=True: Sq, Skv <= 128 run the whole-head forward AND backward; up to 256 keys the forward keeps every score
     # of a 64-query block in registers (the backward then takes the tiled kernels); beyond that both are tiled
-    k.attn_set_whole_head(whole_head)
-    request.addfinalizer(lambda: k.attn_set_whole_head(True))
+    tiled = not whole_head              # a per-call flag (ICKA_ATTN_TILED): no process-wide switch
     H = h * 64
     fused = rnd(B * Sq, 3 * H, seed=1)          # q lives inside a fused [M,3H] buffer (strided view)
     q = fused[:, H:2 * H]
@@ -576,7 +474,7 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
     dmask = k.attn_dropout_mask(B * h * Sq, Skv, p, seed, "cuda").view(B, h, Sq, Skv)
     out = torch.empty(B * Sq, H, dtype=BF16, device="cuda")
     lse = torch.empty(B, h, Sq, dtype=F32, device="cuda")
-    k.attn_fwd(q, kk, v, add_mask, out, lse, B, h, Sq, Skv, p_drop=p, seed=seed)
+    k.attn_fwd(q, kk, v, add_mask, out, lse, B, h, Sq, Skv, p_drop=p, seed=seed, tiled=tiled)
     qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, kk, v))
     oref, lref = _attn_ref(qf, kf, vf, add_mask, dmask, B, h, Sq, Skv)
     assert rel_err(out, oref) < 1.5e-2
@@ -586,7 +484,7 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
     dq = torch.empty(B * Sq, H, dtype=BF16, device="cuda")
     dkv = torch.empty(B * Skv, 2 * H, dtype=BF16, device="cuda")
     delta = torch.empty(B, h, Sq, dtype=F32, device="cuda")
-    k.attn_bwd(q, kk, v, add_mask, out, dout, lse, delta, dq, dkv[:, :H], dkv[:, H:], B, h, Sq, Skv, p_drop=p, seed=seed)
+    k.attn_bwd(q, kk, v, add_mask, out, dout, lse, delta, dq, dkv[:, :H], dkv[:, H:], B, h, Sq, Skv, p_drop=p, seed=seed, tiled=tiled)
     assert rel_err(dq, qf.grad) < 3e-2
     assert rel_err(dkv[:, :H], kf.grad) < 3e-2
     assert rel_err(dkv[:, H:], vf.grad) < 3e-2
@@ -598,7 +496,7 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
         kb = k.attn_keepbits(B, h, Sq, Skv, "cuda")
         kb.fill_(-1)
         out2, lse2 = torch.empty_like(out), torch.empty_like(lse)
-        k.attn_fwd(q, kk, v, add_mask, out2, lse2, B, h, Sq, Skv, p_drop=p, seed=seed, keepbits=kb)
+        k.attn_fwd(q, kk, v, add_mask, out2, lse2, B, h, Sq, Skv, p_drop=p, seed=seed, keepbits=kb, tiled=tiled)
         assert torch.equal(out2, out) and torch.equal(lse2, lse)
         wpl = (Skv + 127) // 128
         words = kb.view(B * h * Sq, 4, wpl).cpu().numpy().astype("uint32")
@@ -609,7 +507,7 @@ def test_attention_fwd_bwd(B, h, Sq, Skv, p, whole_head, request):
         assert np.array_equal(bits.astype(bool), dmask.view(B * h * Sq, Skv).cpu().numpy() > 0)
         dq2, dkv2, delta2 = torch.empty_like(dq), torch.empty_like(dkv), torch.empty_like(delta)
         k.attn_bwd(q, kk, v, add_mask, out, dout, lse, delta2, dq2, dkv2[:, :H], dkv2[:, H:], B, h, Sq, Skv, p_drop=p, seed=seed,
-                   keepbits=kb)
+                   keepbits=kb, tiled=tiled)
         assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv) and torch.equal(delta2, delta)
 
 

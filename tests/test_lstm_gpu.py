@@ -11,18 +11,15 @@ TAGGER_GRAD_BAR = 1.6e-2   # 2x the 7.8e-3 measured on MI355X (printed by the te
 @pytest.mark.parametrize("persistent", [1, 2, 0])
 @pytest.mark.parametrize("B,S,H", [(2, 5, 32), (4, 16, 64), (32, 128, 768), (3, 40, 256), (40, 9, 64), (32, 24, 1024), (7, 12, 1024),
                                    (20, 33, 512)])
-def test_bilstm_forward_backward_against_aten(B, S, H, persistent, request):
+def test_bilstm_forward_backward_against_aten(B, S, H, persistent):
     from icka_amd import _lib
     from icka_amd.lstm import BiLSTM
-    lib = _lib.load()
-    # 1: one persistent launch, forward hand-off by tagged data words (H % 256 == 0) / 2: the same with step tickets in
-    # both directions / 0: one launch per step
-    lib.icka_lstm_set_persistent(int(persistent > 0))
-    lib.icka_lstm_set_handoff(int(persistent == 1))
-    request.addfinalizer(lambda: (lib.icka_lstm_set_persistent(1), lib.icka_lstm_set_handoff(1)))
     torch.manual_seed(B * 100 + S)
     ref = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
     mine = BiLSTM(H, H)
+    # 1: one persistent launch, forward hand-off by tagged data words (H % 256 == 0) / 2: the same with step tickets in
+    # both directions / 0: one launch per step -- a per-call argument of icka_lstm_fwd / _bwd (no process-wide switch)
+    mine.recurrence_flags = {1: 0, 2: _lib.LSTM_TICKETS, 0: _lib.LSTM_PER_STEP}[persistent]
     mine.load_state_dict(ref.state_dict())          # same parameter names as nn.LSTM
     mine = mine.cuda()
     x = torch.randn(B, S, H) * 0.5
@@ -133,17 +130,16 @@ def test_a_failed_handoff_is_never_silent(handoff, phase, request):
     from icka_amd import kernels as K
     from icka_amd.lstm import BiLSTM
     lib = _lib.load()
-    lib.icka_lstm_set_persistent(1)
-    lib.icka_lstm_set_handoff(handoff)
+    form = 0 if handoff == 1 else _lib.LSTM_TICKETS
 
     def restore():
         lib.icka_lstm_test_hooks(0, -1)
-        lib.icka_lstm_set_handoff(1)
         lib.icka_lstm_clear_error()
     request.addfinalizer(restore)
     B, S, H = 8, 12, 256
     torch.manual_seed(5)
     m = BiLSTM(H, H).cuda()
+    m.recurrence_flags = form
     x = (torch.randn(B, S, H) * 0.5).cuda().requires_grad_(True)
     out, _ = m(x)                      # healthy call first (also maps the host-visible error word)
     out.float().sum().backward()

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--keepbits", type=int, default=0, help="1: the forward leaves its keep bits, the backward reads them")
     args = ap.parse_args()
-    K.attn_set_whole_head(bool(args.whole))
+    tiled = not bool(args.whole)      # a per-call flag of icka_attn_fwd_ex / icka_attn_bwd (no process-wide switch)
     B, h, H = (args.batch, 16, 1024) if args.c4 else (args.batch, 12, 768)
     torch.manual_seed(0)
     shapes = ((256, 256), (256, 50)) if args.c4 else ((128, 128), (128, 36))
@@ -48,11 +48,11 @@ def main():
         for it in range(args.iters + 3):
             if it == 3:
                 ev[0].record()
-            K.attn_fwd(q, k, v, mask, out, lse, B, h, Sq, Skv, p_drop=args.p, seed=1234, keepbits=kb)
+            K.attn_fwd(q, k, v, mask, out, lse, B, h, Sq, Skv, p_drop=args.p, seed=1234, keepbits=kb, tiled=tiled)
         ev[1].record()
         for it in range(args.iters):
             K.attn_bwd(q, k, v, mask, out, dout, lse, delta, dqkv[:, :H], dkv[:, :H], dkv[:, H:2 * H], B, h, Sq, Skv,
-                       p_drop=args.p, seed=1234, keepbits=kb)
+                       p_drop=args.p, seed=1234, keepbits=kb, tiled=tiled)
         ev[2].record()
         torch.cuda.synchronize()
         print("B %d heads %d Sq %d Skv %d p %.2f whole %d keepbits %d: fwd %.1f us, bwd %.1f us (HIP events, back-to-back launches)"

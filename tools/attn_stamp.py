@@ -14,7 +14,7 @@ from icka_amd import _lib, kernels as K  # noqa: E402
 
 BF16, F32 = torch.bfloat16, torch.float32
 lib = _lib.load()
-setbuf = lib.icka_attn_set_stamp_buffer
+setbuf = lib.icka_diag_attn_stamp_buffer
 setbuf.argtypes = [C.c_void_p]
 setbuf.restype = None
 CASES = [(32, 12, 128, 128, 0.1), (32, 12, 128, 128, 0.0), (32, 12, 128, 36, 0.1),

@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""A/B helper: run bench.py's main() in this process after setting library knobs.
+"""A/B helper: run bench.py's main() in this process with launch-heuristic overrides -- given to the library the only way a
+whole process can: the ICKA_TUNE_GEMM_* environment, read once when libicka_hip.so loads (there are no setters).
 usage: python tools/bench_knob.py ring=4 tile_n=96 -- --steps 20 --warmup 5"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from icka_amd import _lib  # noqa: E402
-
 args = sys.argv[1:]
 cut = args.index("--") if "--" in args else len(args)
+ENV = {"ring": "ICKA_TUNE_GEMM_RING", "tile_n": "ICKA_TUNE_GEMM_TILE_N", "ws": "ICKA_TUNE_GEMM_WARP_SPECIALIZED",
+       "direct": "ICKA_TUNE_GEMM_DIRECT_EPILOGUE", "big": "ICKA_TUNE_GEMM_BIG_TILES", "w3grid": "ICKA_TUNE_GEMM_W3_GRID",
+       "wide": "ICKA_TUNE_GEMM_WIDE_TILES", "ln_rows": "ICKA_TUNE_LN_ROWS_PER_WAVE"}
+for kv in args[:cut]:
+    k, v = kv.split("=")
+    if k != "stamp":
+        os.environ[ENV[k]] = str(int(v))
+from icka_amd import _lib  # noqa: E402
+
 lib = _lib.load()
 stamp = None
 for kv in args[:cut]:
@@ -16,12 +24,8 @@ for kv in args[:cut]:
     if k == "stamp":   # build with EXTRA=-DICKA_GEMM_STAMP: every GEMM stamps into one buffer (last writer wins per block)
         import torch
         stamp = torch.zeros(8192, 16, dtype=torch.int64, device="cuda")
-        lib.icka_gemm_set_stamp_buffer(stamp.data_ptr())
-        continue
-    rc = getattr(lib, {"ring": "icka_gemm_set_ring", "tile_n": "icka_gemm_set_tile_n", "ws": "icka_gemm_set_warp_specialized",
-                       "direct": "icka_gemm_set_direct_epilogue", "big": "icka_gemm_set_big_tiles",
-                       "w3grid": "icka_gemm_set_w3_grid"}[k])(int(v))
-    assert rc == 0, (k, v, rc)
+        lib.icka_diag_gemm_stamp_buffer.argtypes = [__import__("ctypes").c_void_p]
+        lib.icka_diag_gemm_stamp_buffer(stamp.data_ptr())
 sys.argv = ["bench.py"] + args[cut + 1:]
 import bench  # noqa: E402
 

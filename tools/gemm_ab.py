@@ -14,8 +14,11 @@ BF16 = torch.bfloat16
 lib = _lib.load()
 knob = sys.argv[1]
 vals = [int(v) for v in sys.argv[2:]]
-setter = {"wide": lib.icka_gemm_set_wide_tiles, "ring": lib.icka_gemm_set_ring,
-          "tile_n": lib.icka_gemm_set_tile_n, "direct": lib.icka_gemm_set_direct_epilogue}[knob]
+field = {"wide": "wide_tiles", "ring": "ring", "tile_n": "tile_n", "direct": "direct_epilogue"}[knob]
+
+
+def tune_of(v):      # the per-call tune word of a variant (0 = the library's own choice)
+    return K.gemm_tune(**{field: v}) if (v or knob in ("wide", "direct")) else 0
 
 
 def timed(fn, sets, reps=3):
@@ -49,8 +52,8 @@ for name, op, M, N, Kd, f32 in SHAPES:
     res = {v: [] for v in vals}
     for rnd in range(7):
         for v in vals:
-            assert setter(v) == 0
-            t = timed(lambda A, B, o: K.gemm(kop, A, B, o), sets)
+            T = tune_of(v)
+            t = timed(lambda A, B, o: K.gemm(kop, A, B, o, tune=T), sets)
             if rnd:
                 res[v].append(t)
             out = sets[0][2].float().clone()
@@ -58,7 +61,6 @@ for name, op, M, N, Kd, f32 in SHAPES:
                 ref = (sets[0][0].float() @ (sets[0][1].float().t() if op == "NT" else sets[0][1].float()))
             err = ((out - ref).norm() / ref.norm()).item()
             assert err < 1e-2, (name, v, err)
-    setter(0)
     fl = 2.0 * M * N * Kd
     line = "%-15s %4dx%4dx%4d " % (name, M, N, Kd)
     for v in vals:

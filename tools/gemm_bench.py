@@ -38,9 +38,8 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--ws", type=int, default=1)
     args = ap.parse_args()
-    from icka_amd import _lib
-    assert _lib.load().icka_gemm_set_ring(args.ring) == 0
-    _lib.load().icka_gemm_set_warp_specialized(args.ws)
+    T0 = K.gemm_tune(ring=args.ring, warp_specialized=args.ws)      # per-call words of the descriptor (no setters)
+    T = K.gemm_tune(ring=args.ring, warp_specialized=args.ws, **({"ablation": args.ablate} if args.ablate else {}))
     print("ring depth", args.ring, "ablation", args.ablate, "warp-specialised", args.ws)
     torch.manual_seed(0)
     cases = []
@@ -58,17 +57,16 @@ def main():
         aux = torch.randn(m, n, device="cuda").to(BF16) if epi in (K.EPI_DGELU, K.EPI_ADD) else None
         out2 = torch.empty(m, n, dtype=BF16, device="cuda") if epi == K.EPI_GELU else None
         bias = torch.randn(n, device="cuda") if epi == K.EPI_GELU else None
-        K.gemm(op, A, B, out, epilogue=K.EPI_NONE)
+        K.gemm(op, A, B, out, epilogue=K.EPI_NONE, tune=T0)
         err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
         cases.append((name, op, m, n, k, epi, A, B, out, aux, out2, bias, err))
-    _lib.load().icka_gemm_set_ablation(args.ablate)
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in cases]
           for _ in range(args.iters)]
     for it in range(args.iters + 3):
         for ci, (name, op, m, n, k, epi, A, B, out, aux, out2, bias, err) in enumerate(cases):
             if it >= 3:
                 ev[it - 3][ci][0].record()
-            K.gemm(op, A, B, out, epilogue=epi, aux=aux, out2=out2, bias=bias)
+            K.gemm(op, A, B, out, epilogue=epi, aux=aux, out2=out2, bias=bias, tune=T)
             if it >= 3:
                 ev[it - 3][ci][1].record()
     torch.cuda.synchronize()

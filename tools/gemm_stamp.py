@@ -12,7 +12,8 @@ from icka_amd import _lib, kernels as K  # noqa: E402
 BF16, F32 = torch.bfloat16, torch.float32
 lib = _lib.load()
 ring = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-lib.icka_gemm_set_ring(ring)
+T = K.gemm_tune(ring=ring)          # per-call word of the descriptor (no setters)
+lib.icka_diag_gemm_stamp_buffer.argtypes = [__import__("ctypes").c_void_p]   # exported by -DICKA_GEMM_STAMP builds only
 for name, op, M, N, Kd in (("Wo TN", K.GEMM_TN, 768, 768, 4096), ("ffndn NT", K.GEMM_NT, 4096, 768, 3072),
                            ("qkv NT", K.GEMM_NT, 4096, 2304, 768), ("outproj NT", K.GEMM_NT, 4096, 768, 768),
                            ("ffnup NT", K.GEMM_NT, 4096, 3072, 768), ("dffnup NN", K.GEMM_NN, 4096, 768, 3072)):
@@ -25,11 +26,11 @@ for name, op, M, N, Kd in (("Wo TN", K.GEMM_TN, 768, 768, 4096), ("ffndn NT", K.
     out = torch.empty(M, N, dtype=BF16, device="cuda")
     buf = torch.zeros(4096, 16, dtype=torch.int64, device="cuda")   # >= any grid here (96-wide tiles: more blocks)
     for _ in range(20):   # warm the clocks
-        K.gemm(op, A, B, out)
-    lib.icka_gemm_set_stamp_buffer(buf.data_ptr())
-    K.gemm(op, A, B, out)
+        K.gemm(op, A, B, out, tune=T)
+    lib.icka_diag_gemm_stamp_buffer(buf.data_ptr())
+    K.gemm(op, A, B, out, tune=T)
     torch.cuda.synchronize()
-    lib.icka_gemm_set_stamp_buffer(None)
+    lib.icka_diag_gemm_stamp_buffer(None)
     b = buf.double().cpu()
     b = b[b[:, 6] > 0]
     nb = b.shape[0]
@@ -66,10 +67,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "chain":
             for i, (name, a, w, o) in enumerate(seq):
                 hit = it == 11 and i == target
                 if hit:
-                    lib.icka_gemm_set_stamp_buffer(buf.data_ptr())
-                K.gemm(K.GEMM_NT, a, w, o)
+                    lib.icka_diag_gemm_stamp_buffer(buf.data_ptr())
+                K.gemm(K.GEMM_NT, a, w, o, tune=T)
                 if hit:
-                    lib.icka_gemm_set_stamp_buffer(None)
+                    lib.icka_diag_gemm_stamp_buffer(None)
         torch.cuda.synchronize()
         b = buf.double().cpu()
         b = b[b[:, 6] > 0]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-tile error map of the fast-path GEMM for a forced tile width (icka_gemm_set_tile_n)."""
+"""Diagnostic: per-tile error map of the fast-path GEMM for a forced tile width (the ICKA_TUNE_TILE_N word of the call's descriptor)."""
 import os
 import sys
 
@@ -11,9 +11,7 @@ from icka_amd import _lib, kernels as K  # noqa: E402
 BF16, F32 = torch.bfloat16, torch.float32
 lib = _lib.load()
 bn = int(sys.argv[1]) if len(sys.argv) > 1 else 96
-lib.icka_gemm_set_tile_n(bn)
-if len(sys.argv) > 2:   # LDS ring depth (14: ring 4 with paired staging)
-    assert lib.icka_gemm_set_ring(int(sys.argv[2])) == 0
+T = K.gemm_tune(tile_n=bn, **({"ring": int(sys.argv[2])} if len(sys.argv) > 2 else {}))   # optional LDS ring depth
 torch.manual_seed(0)
 for op, name in ((K.GEMM_TN, "TN"), (K.GEMM_NN, "NN"), (K.GEMM_NT, "NT")):
     for Kd in (64, 128, 192, 256, 320, 384, 448, 768):
@@ -30,7 +28,7 @@ for op, name in ((K.GEMM_TN, "TN"), (K.GEMM_NN, "NN"), (K.GEMM_NT, "NT")):
                     ref = A.float() @ B.float().t()
                 out = torch.zeros(M, N, dtype=F32, device="cuda")
                 cs = torch.zeros(M, dtype=F32, device="cuda") if cs_on else None
-                K.gemm(op, A, B, out, colsum_out=cs)
+                K.gemm(op, A, B, out, colsum_out=cs, tune=T)
                 err = (out - ref).abs()
                 tiles = err.view(M // 128, 128, N // bn, bn).amax((1, 3)) / ref.abs().max()
                 bad = (tiles > 1e-3).nonzero().tolist()

@@ -54,10 +54,10 @@ def timed(fn, p, reps=30):
     return 1e3 * e0.elapsed_time(e1) / reps / N
 
 
-for rows in (1, 2, 4, 8, 1):      # rows a forward wave owns (icka_ln_set_rows_per_wave): > 1 overlaps next-row loads with stores
-    lib.icka_ln_set_rows_per_wave(rows)
-    print("ln_fwd, %d row(s) per wave: p = 0 %6.2f us | p = 0.1 %6.2f us" % (rows, timed(fwd, 0.0), timed(fwd, 0.1)), flush=True)
-lib.icka_ln_set_rows_per_wave(0)
+# rows a forward wave owns (> 1 overlaps next-row loads with stores): ICKA_TUNE_LN_ROWS_PER_WAVE, read once when the library loads
+# -- one process per setting:  for r in 1 2 4 8; do ICKA_TUNE_LN_ROWS_PER_WAVE=$r python3 tools/ln_bench.py; done
+print("ln_fwd, rows per wave %s: p = 0 %6.2f us | p = 0.1 %6.2f us"
+      % (os.environ.get("ICKA_TUNE_LN_ROWS_PER_WAVE", "automatic"), timed(fwd, 0.0), timed(fwd, 0.1)), flush=True)
 for name, fn in (("ln_fwd", fwd), ("ln_bwd (rows + column slabs)", bwd)):
     for rnd in range(2):
         a, b = timed(fn, 0.0), timed(fn, 0.1)

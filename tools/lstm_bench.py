@@ -45,11 +45,10 @@ def timed(fn):
 
 
 for mode, split in ((1, 1), (1, 0), (0, 1), (0, 0)):
-    lib.icka_lstm_set_handoff(mode)
-    lib.icka_lstm_set_batch_split(split)
-    tf = timed(lambda: K.lstm_fwd(gx, whh, y, c_all, act, hprev, B, S, H))
+    flags = (0 if mode else _lib.LSTM_TICKETS) | (0 if split else _lib.LSTM_NO_BATCH_SPLIT)     # per-call flags (no setters)
+    tf = timed(lambda: K.lstm_fwd(gx, whh, y, c_all, act, hprev, B, S, H, flags=flags))
     ysum = y.float().abs().sum().item()
-    tb = timed(lambda: K.lstm_bwd(dy, whh_t, act, c_all, dgates, dcc, B, S, H))
+    tb = timed(lambda: K.lstm_bwd(dy, whh_t, act, c_all, dgates, dcc, B, S, H, flags=flags))
     gsum = dgates.float().abs().sum().item()
     print("B %d S %d H %d handoff %s split %d | fwd %.1f us (%.2f us/step) | bwd %.1f us (%.2f us/step) | checksums %.6e %.6e"
           % (B, S, H, mode, split, tf, tf / S, tb, tb / S, ysum, gsum), flush=True)
