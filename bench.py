@@ -591,6 +591,44 @@ def main():
         log("eager / refresh side report failed (%s: %s): reported as null" % (type(e).__name__, e))
         torch.cuda.synchronize()
 
+    # ---- BASELINE config 4 says bf16; the step above runs c4 in "mixed16" (fp16 forward operands), because pure bf16 measures
+    #      2.2e-2 .. 2.5e-2 max abs logit error at 24 layers, above north_star's 2e-2 (tests/test_fullsize_gpu.py).  The
+    #      configuration AS STATED goes on the record beside it: the same step captured again in pure bf16, same batches.
+    stated = None
+    if workload_name(args) == "c4" and args.precision != "bf16" and world == 1 and not args.no_graph and not args.no_eager_leg:
+        gs2 = None
+        try:
+            import icka_amd
+            from icka_amd.graph import GraphedStep
+            icka_amd.set_precision(model, "bf16")
+            gs2 = GraphedStep(model, step, inputs=pool[0])
+            for i in range(3):
+                model.zero_grad()
+                gs2(*pool[i % POOL])
+            sync()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                model.zero_grad()
+                gs2(*pool[i % POOL])
+            sync()
+            ms2 = 1e3 * (time.perf_counter() - t1) / args.steps
+            stated = {"precision": "bf16 (the configuration as BASELINE.json states it)", "ms_per_step": round(ms2, 3),
+                      "samples_per_s": round(args.batch / (ms2 * 1e-3), 2), "steps": args.steps,
+                      "max_abs_logit_err_vs_oracle": "2.2e-2 .. 2.5e-2 at 24 layers (tests/test_fullsize_gpu.py, documented 3e-2 "
+                                                     "leg): above north_star's 2e-2 bar, which is why the headline of this line "
+                                                     "runs mixed16 (3.9e-3)"}
+            log("c4 in pure bf16 (configuration as stated): %.3f ms/step" % ms2)
+        except Exception as e:  # noqa: BLE001
+            log("pure-bf16 side leg failed (%s: %s): reported as null" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+        finally:
+            import icka_amd
+            icka_amd.set_precision(model, args.precision)
+            if gs2 is not None:
+                gs2.close()
+            if getattr(run_step, "nonce", None) is not None:
+                K.set_dropout_nonce(run_step.nonce)
+
     # what the default ("always") shadow policy adds to a step: one f32 -> bf16 cast of the GEMM weights
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     arena.sync(force=True)
@@ -754,6 +792,8 @@ def main():
             "loss": round(final_loss, 5),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if stated is not None:
+            out["config_as_stated"] = stated
         if opt_ms is not None:
             out["with_optimizer_ms_per_step"] = round(opt_ms, 3)
             out["with_optimizer"] = {"update": "icka_amd.optim.ArenaAdamW: global-norm clip at 1.0 + AdamW (two weight-decay groups, "

@@ -311,7 +311,7 @@ def test_gemm_grouped_weight_gradient_layer_shapes(big):
     k = _k()
     from icka_amd import _lib
     lib = _lib.load()
-    T = k.gemm_tune(big_tiles=big)       # a grouped launch takes the tune word of its first problem
+    TUNE = k.gemm_tune(big_tiles=big)    # a grouped launch takes the tune word of its first problem
     T, H, I = 1024, 768, 3072
     shapes = [(3 * H, H), (H, H), (I, H), (H, I)]
     descs, outs, refs, css, keep = [], [], [], [], []
@@ -320,7 +320,7 @@ def test_gemm_grouped_weight_gradient_layer_shapes(big):
         out = torch.full((m, n), 7.0, dtype=F32, device="cuda")          # overwritten, or accumulated into (i == 3)
         cs = torch.full((m,), 3.0, dtype=F32, device="cuda") if i != 1 else None
         descs.append(k.gemm_desc(k.GEMM_TN, A, B, out, beta=1.0 if i == 3 else 0.0, colsum_out=cs,
-                                 colsum_accumulate=(i == 2), tune=T))
+                                 colsum_accumulate=(i == 2), tune=TUNE))
         keep.append((A, B)); outs.append(out); css.append(cs)
         refs.append(A.float().t() @ B.float() + (7.0 if i == 3 else 0.0))
     # two LayerNorm slab reductions ride on the launch (dgamma / dbeta of the layer's two LayerNorms)

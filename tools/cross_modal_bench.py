@@ -78,6 +78,8 @@ def main():
                       "launch": mode, "loss": round(loss, 5), "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
                       "parameters_M": round(nparam / 1e6, 1),
                       "algorithmic_tflops": round(3 * fwd * args.batch / ms * 1e-9, 1),
+                      "algorithmic_gflop_per_step": round(3 * fwd * args.batch * 1e-9, 1),
+                      "frac_of_bf16_mfma_peak": round(3 * fwd * args.batch / ms * 1e-9 / 2500.0, 4),
                       "config": {"workload": "H1024 x %d layers text encoder (seq 128, 49 regions) + H1024 x %d layers "
                                  "prompt encoder (170 ids -> 178 positions), batch %d, train mode" % (L, L, args.batch)}}))
 

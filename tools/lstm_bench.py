@@ -50,5 +50,10 @@ for mode, split in ((1, 1), (1, 0), (0, 1), (0, 0)):
     ysum = y.float().abs().sum().item()
     tb = timed(lambda: K.lstm_bwd(dy, whh_t, act, c_all, dgates, dcc, B, S, H, flags=flags))
     gsum = dgates.float().abs().sum().item()
-    print("B %d S %d H %d handoff %s split %d | fwd %.1f us (%.2f us/step) | bwd %.1f us (%.2f us/step) | checksums %.6e %.6e"
-          % (B, S, H, mode, split, tf, tf / S, tb, tb / S, ysum, gsum), flush=True)
+    # arithmetic of the recurrence alone: per step and direction h_{t-1} [B, H] x W_hh^T [H, 4H] = 2 B H 4H FLOP (backward: the
+    # transposed product, the same count); the floor of a step is the hand-off of h_t between the blocks of the persistent launch
+    # (one flag-in-data word round trip through L2, ~1 us idle by the microarch guide's handoff table), not this arithmetic
+    fl = 2.0 * 2 * B * H * 4 * H * S
+    print("B %d S %d H %d handoff %s split %d | fwd %.1f us (%.2f us/step, %.1f TFLOP/s = %.4f of the bf16 peak) | bwd %.1f us (%.2f "
+          "us/step, %.1f TFLOP/s) | checksums %.6e %.6e"
+          % (B, S, H, mode, split, tf, tf / S, fl / tf * 1e-6, fl / tf * 1e-6 / 2500.0, tb, tb / S, fl / tb * 1e-6, ysum, gsum), flush=True)

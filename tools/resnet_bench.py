@@ -53,7 +53,8 @@ def main():
     flops = 2 * 11.56e9 * args.batch     # 11.56 G multiply-adds per 224x224 image (ResNet-152)
     print(json.dumps({"metric": "ResNet-152 image encoder, forward (frozen), images/s", "value": round(1e3 * args.batch / ms, 1),
                       "unit": "images/s", "ms_per_batch": round(ms, 3), "batch": args.batch, "launch": mode,
-                      "algorithmic_tflops": round(flops / ms / 1e9, 1), "dtype": "bf16", "n_gpus": 1}))
+                      "algorithmic_tflops": round(flops / ms / 1e9, 1), "algorithmic_gflop_per_batch": round(flops * 1e-9, 1),
+                      "frac_of_bf16_mfma_peak": round(flops / ms / 1e9 / 2500.0, 4), "dtype": "bf16", "n_gpus": 1}))
 
 
 if __name__ == "__main__":

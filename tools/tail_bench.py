@@ -95,7 +95,20 @@ def main():
         (-model.crf(em, g["labels"], mask=g["input_mask"].byte(), reduction="token_mean")).backward()
     lstm_ms = timed(lstm_only, args.steps, args.warmup)
     crf_ms = timed(crf_only, args.steps, args.warmup)
+    # algorithmic GEMM FLOPs per sample, forward (x 3 = forward + backward): the trunk of bench.py's formula (BERT layers, one
+    # cross layer, region projection) + the BiLSTM (input projection 2 S H 8H + recurrence 2 S H 8H over both directions) +
+    # the [2H -> C] classifier; the CRF's O(S C^2) is negligible
+    H, I, S, R, C = 768, 3072, args.seq, (49 if args.with_encoder else args.regions), 13
+    fwd = 12 * (S * (8 * H * H + 4 * H * I) + 4 * S * S * H) + (S * (4 * H * H + 4 * H * I) + 4 * R * H * H + 4 * S * R * H) \
+        + 2 * R * 2048 * H + 32 * S * H * H + 4 * S * H * C
+    if args.with_encoder:
+        fwd += 2 * 11.56e9
+    tfl = 3 * fwd * args.batch / ms * 1e-9
+    # the recurrence's floor is NOT arithmetic: S dependent steps per direction, each a hand-off of h_t between the blocks of
+    # the persistent launch (measured ~3.7 us forward / ~5.3 us backward per step: tools/lstm_bench.py)
     print(json.dumps({"metric": "MNER samples/sec (fwd+bwd), _gate_1 tagger: trunk + BiLSTM + classifier + CRF",
+                      "algorithmic_gflop_per_step": round(3 * fwd * args.batch * 1e-9, 1), "algorithmic_tflops": round(tfl, 1),
+                      "frac_of_bf16_mfma_peak": round(tfl / 2500.0, 4),
                       "value": round(1e3 * args.batch / ms, 2), "unit": "samples/s", "ms_per_step": round(ms, 3),
                       "launch": mode, "loss": round(loss, 5), "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
                       "config": {"workload": "bert-base + %d regions, seq %d, batch %d, train mode"
