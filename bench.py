@@ -702,7 +702,7 @@ def main():
         flops, ms, launches, abytes = K.profile_gemm(False, reps=nprof)
         traffic, traffic_src = None, None
         tpath = None
-        for tag in ("r04", "r03", "r02", "r01"):      # the newest committed PMC passes
+        for tag in ("r05", "r04", "r03", "r02", "r01"):      # the newest committed PMC passes
             cand = os.path.join(ROOT, "profiles", "%s_gemm_traffic.json" % tag)
             if os.path.exists(cand):
                 tpath = cand
@@ -714,7 +714,7 @@ def main():
         # MFMA-busy counters of the same GEMM launches (SQ_VALU_MFMA_BUSY_CYCLES, separate rocprofv3 --pmc pass over the eager
         # step: tools/profile_mfma.sh -> profiles/r0N_mfma_busy_<config>.json); like `traffic`, not collectable in-process
         mfma_busy = None
-        for tag in ("r04",):
+        for tag in ("r05", "r04"):
             cand = os.path.join(ROOT, "profiles", "%s_mfma_busy_%s.json" % (tag, workload_name(args)))
             if os.path.exists(cand):
                 mj = json.load(open(cand))

@@ -14,6 +14,7 @@ TAGGER_GRAD_BAR = 1.6e-2   # 2x the 7.8e-3 measured on MI355X (printed by the te
 def test_bilstm_forward_backward_against_aten(B, S, H, persistent):
     from icka_amd import _lib
     from icka_amd.lstm import BiLSTM
+    lib = _lib.load()
     torch.manual_seed(B * 100 + S)
     ref = torch.nn.LSTM(H, H, batch_first=True, bidirectional=True)
     mine = BiLSTM(H, H)
