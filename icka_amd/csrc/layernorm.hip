@@ -5,80 +5,13 @@
 // rows a wave visits, combined per block through LDS and written as per-block partial slabs that a tiny finalize
 // kernel sums: no global float atomics on hot addresses, bitwise reproducible.
 #include "common.h"
+#include "ln_row.h"
 #include <cstdlib>
 
 namespace {
 
-constexpr int MAX_CH = 4;           // chunks of 8 per lane -> H <= 2048
 constexpr int BWD_BLOCKS = 1024;    // partial slabs per backward launch (one row per wave at M = 4096: 16 waves/CU)
 constexpr int SLOTS = 4;            // column-sum slots per slab
-
-struct LnFwdArgs {
-    const void* x; int64_t ldx; int x_f32; const float* bias; const void* res; int64_t ldr; int r_f32;
-    const float* gamma; const float* beta;
-    bf16_t* y; int64_t ldy; bf16_t* y2; int64_t ldy2; void* yf; bf16_t* xhat; float* rstd;
-    int M, H; float eps; DropCfg drop;
-    int yf_f16;   // the twin output ``yf`` is fp16 (the "mixed16" forward operand + residual) instead of f32
-};
-
-__device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
-    const bf16x8 v = as_bf16x8(*reinterpret_cast<const u32x4*>(p));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = bf2f(v[e]);
-}
-__device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-}
-__device__ __forceinline__ void load8h(const _Float16* p, float (&o)[8]) {
-    const f16x8 v = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
-}
-// row element loads in either precision: kind 0 = bf16, 1 = f32 (GEMM outputs, the f32 residual twin), 2 = fp16 (the
-// residual stream of the "mixed16" mode)
-__device__ __forceinline__ void load8x(const void* base, int kind, int64_t off, float (&o)[8]) {
-    if (kind == 1) load8f(reinterpret_cast<const float*>(base) + off, o);
-    else if (kind == 2) load8h(reinterpret_cast<const _Float16*>(base) + off, o);
-    else load8(reinterpret_cast<const bf16_t*>(base) + off, o);
-}
-__device__ __forceinline__ void store8f(float* p, const float (&v)[8]) {
-    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-}
-__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-    *reinterpret_cast<u32x4*>(p) = as_u32x4(o);
-}
-
-__device__ __forceinline__ void store8h(_Float16* p, const float (&v)[8]) {
-    f16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
-    *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, o);
-}
-// the twin copy of a LayerNorm output: f32, or fp16 in the "mixed16" mode
-__device__ __forceinline__ void store8t(void* base, int is_f16, int64_t off, const float (&v)[8]) {
-    if (is_f16) store8h(reinterpret_cast<_Float16*>(base) + off, v);
-    else store8f(reinterpret_cast<float*>(base) + off, v);
-}
-
-// One wave per row at a time; a wave that owns several rows (grid < M / 4) issues the loads of its
-// NEXT row before it reduces and stores the current one, so that a CU's read and write streams overlap instead of the whole
-// chip reading, then reducing, then writing in step.
-template <int NCH>
-__device__ __forceinline__ void ln_load_raw(const LnFwdArgs& a, int row, int lane, int nchunk, float (&x)[NCH][8], float (&r)[NCH][8]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-            load8x(a.x, a.x_f32, (int64_t)row * a.ldx + c * 8, x[i]);
-            if (a.res) load8x(a.res, a.r_f32, (int64_t)row * a.ldr + c * 8, r[i]);
-        }
-    }
-}
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
@@ -86,74 +19,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_) {
     a.drop = drop_resolve(a.drop);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    const int nchunk = a.H >> 3;
-    const float inv_h = 1.f / (float)a.H;
-    float s[NCH][8], rr[NCH][8];
-    if (wid < a.M) ln_load_raw<NCH>(a, wid, lane, nchunk, s, rr);
-    for (int row = wid; row < a.M; row += nw) {
-        float nx[NCH][8], nr[NCH][8];
-        const int nrow = row + nw;
-        if (nrow < a.M) ln_load_raw<NCH>(a, nrow, lane, nchunk, nx, nr);   // in flight while this row is reduced and stored
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk) {
-                if (a.bias) {
-                    float b[8];
-                    load8f(a.bias + c * 8, b);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] += b[e];
-                }
-                if (a.drop.thr) {
-                    const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] *= drop_mul(a.drop, base + e);
-                }
-                if (a.res) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] += rr[i][e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum += s[i][e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s[i][e] = 0.f;
-            }
-        }
-        const float mean = wave_sum(sum) * inv_h;
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (lane + 64 * i < nchunk) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = s[i][e] - mean; sq += d * d; }
-            }
-        const float var = wave_sum(sq) * inv_h;
-        const float rstd = 1.f / sqrtf(var + a.eps);
-        if (lane == 0 && a.rstd) a.rstd[row] = rstd;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk) {
-                float g[8], b[8], xh[8], o[8];
-                load8f(a.gamma + c * 8, g);
-                load8f(a.beta + c * 8, b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[e] = (s[i][e] - mean) * rstd; o[e] = g[e] * xh[e] + b[e]; }
-                store8(a.y + (int64_t)row * a.ldy + c * 8, o);
-                if (a.y2) store8(a.y2 + (int64_t)row * a.ldy2 + c * 8, o);
-                if (a.yf) store8t(a.yf, a.yf_f16, (int64_t)row * a.H + c * 8, o);
-                if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
-            }
-        }
-        if (nrow < a.M) {
-#pragma unroll
-            for (int i = 0; i < NCH; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s[i][e] = nx[i][e]; rr[i][e] = nr[i][e]; }
-        }
-    }
+    ln_fwd_rows<NCH>(a, wid, nw, a.M, lane);      // (ln_row.h: the row body shared with gemm.hip's gemm_ln_kernel)
 }
 
 struct LnBwdArgs {
