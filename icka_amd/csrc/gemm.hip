@@ -18,6 +18,7 @@
 // forward GEMMs) and CONV (gemm_ws_kernel only: the A tile is gathered from an NHWC activation = implicit 3x3 convolution).
 // LDS images are XOR-swizzled per layout (off_kc / off_km), the swizzle applied to the DMA source address.
 #include "common.h"
+#include "ln_row.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -867,7 +868,9 @@ __device__ __forceinline__ bool g_direct_epilogue(const GemmArgs& g) {
 // MFMA; a loader wave co-resident on the same SIMD hides that issue time under the compute wave's matrix work.
 // One s_barrier per k-tile joins both roles: loaders arrive after their counted vmcnt (tile kt landed), compute waves
 // after finishing tile kt-1, so the barrier both publishes tile kt and frees the buffer of tile kt-1 for re-staging.
-template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false>
+// LNF (gemm_ln_kernel): the tile's plain f32 output is stored WRITE-THROUGH (sc1) and the body returns instead of retiring its
+// waves -- the kernel then hands the stripe's rows over to its LayerNorm phase inside the same launch.
+template <bool A_KM, bool B_KM, int NBUF, int ABL = 0, int DIST = 2, int BNT = 128, bool F16 = false, bool CONV = false, bool LNF = false>
 __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, const int bid, const int nb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1163,7 +1166,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                 for (int mi = 0; mi < 4; ++mi) {
                     const int m = m0 + wr + 16 * mi + (lane & 15);
                     const f32x4 v = acc[mi][ni] * g.alpha + b4;
-                    if (g.c_f32) {
+                    if constexpr (LNF) {   // write-through: the rows are read by OTHER CUs of this launch (sc1 loads, ln_row.h)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), "v"(v) : "memory");
+                    } else if (g.c_f32) {
                         if (!A_KM || !g.c3_only) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
                         if constexpr (A_KM) {   // weight-gradient instances only: the data-parallel wire copy
                             if (g.C3) st_out(reinterpret_cast<u32x2*>(g.C3 + (int64_t)m * g.ldc3 + n), pack4(v[0], v[1], v[2], v[3]));
@@ -1213,6 +1218,69 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
     const GemmArgs g = gp;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_BYTES];
     gemm_ws_body<A_KM, B_KM, NBUF, ABL, 2, BNT, F16, CONV>(g, smem, blockIdx.x, gridDim.x);
+}
+
+// =====================================================================================================================
+// dense -> bias + dropout + residual -> LayerNorm in ONE launch (BertSelfOutput.forward Cross_Modal_Interaction_Module.py:
+// 561-565, BertOutput.forward :532-536): the 128 x BNT NT kernel above for shapes whose tile grid is one block per CU with
+// EIGHT column tiles per 128-row stripe (N = 768 with 96-wide tiles, N = 1024 with 128-wide ones; M / 128 stripes, a multiple
+// of 8, at most one block per CU).  tile_origin puts the 8 blocks of a stripe on one XCD (blocks b, b + 8, ... share an XCD
+// under the observed round-robin dispatch -- a speed property only, nothing below depends on it).
+//   phase 1  the tile's f32 output is stored write-through (sc1) into the usual GEMM -> LayerNorm intermediate;
+//   seam     every wave waits for its stores (s_waitcnt vmcnt(0)), the block barrier joins them, ONE lane adds 1 to the stripe's
+//            arrival counter (agent scope) and polls it (sc1 load, bounded) until all 8 blocks of the stripe have arrived;
+//            measured 0.6 us (max 0.8) on an idle chip against 4.8 us first-block-start -> last-block-end for the same two
+//            phases as two launches (tools/probe/xcd_seam_probe.hip, profiles/r05_xcd_seam_probe.txt);
+//   phase 2  block j of the stripe finishes rows 16 j .. 16 j + 15 of it -- all 8 waves, two rows each, through the SAME row body
+//            as the stand-alone kernel (ln_row.h: bitwise the same y / twin / xhat / rstd), reading the intermediate with
+//            L1-bypassing (sc1) loads.
+// Why the round-2 attempt at this fusion lost (profiles/r02_gemm_ln_fusion.txt: +6 - 8 us per site) and this form differs: there
+// a thread kept 24 columns of a row and the 8 blocks exchanged partial (sum, M2) statistics through four dependent agent-scope
+// round trips, then wrote y / twin / xhat as 48 - 96-byte pieces; here the seam is ONE counter and the LayerNorm phase moves whole
+// rows, 16 bytes per lane, like the row kernel.  The counters reset themselves: the last of the 8 blocks to LEAVE the wait
+// zeroes both words (by then every block of the stripe has seen the count), so a launch leaves the workspace as it found it
+// and the same words serve every fused launch of a stream (launches of one stream do not overlap).
+// A wait that gives up (a block of the stripe never became resident: more blocks than CUs are refused on the host) stores 1
+// into the error word and the block goes on with whatever the intermediate holds: never a hang; the host polls the word.
+struct GemmLnArgs {
+    GemmArgs g;
+    LnFwdArgs ln;
+    unsigned int* sync;      // [stripes][32] words: [0] arrivals, [16] departures (one 64-byte line each); then 1 error word
+    unsigned int* err;
+    int polls;
+};
+template <int BNT, bool F16 = false>
+__global__ __launch_bounds__(512) void gemm_ln_kernel(const GemmLnArgs p) {
+    const GemmArgs g = p.g;
+    __shared__ __attribute__((aligned(16))) char smem[3 * 2 * TILE_BYTES];
+    gemm_ws_body<false, false, 3, 0, 2, BNT, F16, false, true>(g, smem, blockIdx.x, gridDim.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left the CU
+    __syncthreads();
+    int m0, n0;
+    tile_origin(blockIdx.x, gridDim.x, g.M / BM, g.N / BNT, m0, n0, BNT);
+    const int nbn = g.N / BNT;                             // = 8 (host)
+    if (threadIdx.x == 0) {
+        unsigned int* arrive = p.sync + (size_t)(m0 / BM) * 32;
+        unsigned int* depart = arrive + 16;
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = false;
+        for (int i = 0; i < p.polls; ++i) {
+            if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nbn) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nbn - 1)) {
+            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block of the stripe has seen 8
+            __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    LnFwdArgs a = p.ln;
+    a.drop = drop_resolve(a.drop);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int ROWS_PER_BLOCK = BM / 8, ROWS_PER_WAVE = ROWS_PER_BLOCK / 8;
+    const int r0 = m0 + (n0 / BNT) * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
+    ln_fwd_rows<2, true>(a, r0, 1, r0 + ROWS_PER_WAVE, lane);
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1714,6 +1782,57 @@ extern "C" int icka_gemm(const icka_gemm_desc* d, void* stream) {
         case ICKA_GEMM_NN: return launch<false, true>(g, aligned, st, t);
         default: return launch<true, true>(g, aligned, st, t);
     }
+}
+
+static int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else { n = 1; (void)hipGetLastError(); }
+    }
+    return n;
+}
+constexpr int GEMM_LN_MAX_STRIPES = 64;
+extern "C" int64_t icka_gemm_ln_sync_words(void) { return (int64_t)GEMM_LN_MAX_STRIPES * 32 + 16; }
+// 1 if a stripe wait of an icka_gemm_ln launch ever gave up (sync_words[last 16 words][0]); the caller reads / clears the word
+// itself (it is ordinary device memory it owns) -- see icka_amd/kernels.py gemm_ln_error.
+extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const void* residual, int64_t ldr, int32_t res_kind,
+                            const float* gamma, const float* beta, void* y, int64_t ldy, void* y_twin, int32_t twin_f16,
+                            void* xhat, float* rstd, float eps, float p_drop, uint64_t seed, uint32_t* sync_words, void* stream) {
+    if (!d || !gamma || !beta || !y || !sync_words) return ICKA_E_ARG;
+    if (res_kind < 0 || res_kind > 2) return ICKA_E_ARG;
+    GemmArgs g;
+    Tune t;
+    bool aligned = false;
+    const int rc = convert(d, g, aligned, t);
+    if (rc) return rc;
+    // eligibility (else ICKA_E_SHAPE: the caller takes icka_gemm + icka_ln_fwd): NT, bf16 operands, plain f32 output that the
+    // direct epilogue stores, one reduction segment, EIGHT column tiles per stripe, whole groups of 8 stripes, and at most one
+    // block per CU -- the blocks of a stripe wait for each other, so all of them must be resident at once
+    if (d->op != ICKA_GEMM_NT || g.f16 || !aligned || !g.c_f32 || g.epi != ICKA_EPI_NONE || g.beta != 0.f || g.alpha != 1.f || g.bias ||
+        g.bias2 || g.K1 != 0 || g.colsum || g.C3 || !t.direct || !t.ws || d->tune)
+        return ICKA_E_SHAPE;
+    const int bnt = (g.N % 96 == 0 && g.N / 96 == 8) ? 96 : ((g.N % 128 == 0 && g.N / 128 == 8) ? 128 : 0);
+    const int stripes = g.M / BM;
+    if (!bnt || stripes % 8 != 0 || stripes > GEMM_LN_MAX_STRIPES || stripes * 8 > device_cus()) return ICKA_E_SHAPE;
+    if (g.N % 8 || ldy % 8 || (residual && ldr % 8) || g.ldc % 4) return ICKA_E_ALIGN;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(y) || (residual && !al16(residual)) || (xhat && !al16(xhat)) || (bias && !al16(bias)) || !al16(gamma) || !al16(beta) ||
+        (y_twin && !al16(y_twin)))
+        return ICKA_E_ALIGN;
+    GemmLnArgs p;
+    p.g = g;
+    p.ln = LnFwdArgs{g.C, g.ldc, 1, bias, residual, ldr, res_kind, gamma, beta, (bf16_t*)y, ldy, nullptr, 0, y_twin, (bf16_t*)xhat, rstd,
+                     g.M, g.N, eps, make_drop(p_drop, seed), twin_f16};
+    p.sync = sync_words;
+    p.err = sync_words + (size_t)GEMM_LN_MAX_STRIPES * 32;
+    p.polls = 1 << 18;
+    hipStream_t st = (hipStream_t)stream;
+    if (bnt == 96) hipLaunchKernelGGL((gemm_ln_kernel<96>), dim3(stripes * 8), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_ln_kernel<128>), dim3(stripes * 8), dim3(512), 0, st, p);
+    ICKA_CHECK_LAUNCH();
+    return 0;
 }
 
 // 3x3 / pad 1 convolution (stride 1 or 2) of an NHWC bf16 activation as an implicit GEMM on the warp-specialised kernel:

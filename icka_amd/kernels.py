@@ -340,6 +340,39 @@ def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, y_f32=None, y_f16=None
     return y
 
 
+def gemm_ln_sync(device) -> torch.Tensor:
+    """Zeroed counter words for ``gemm_ln`` (icka_gemm_ln_sync_words; the launches leave them zero: one buffer per stream)."""
+    return torch.zeros(_lib.load().icka_gemm_ln_sync_words(), dtype=torch.int32, device=device)
+
+
+def gemm_ln(h, w, o, bias, residual, gamma, beta, y, sync, *, y_f32=None, y_f16=None, xhat=None, rstd=None, eps=1e-12,
+            p_drop=0.0, seed=0) -> bool:
+    """dense (h @ w^T -> o, f32) + bias + dropout + residual + LayerNorm -> y (and twin / xhat / rstd) as ONE launch
+    (icka_gemm_ln) -- bitwise ``gemm(NT, h, w, o)`` followed by ``ln_fwd(o, bias, residual, gamma, beta, y, ...)``.  Returns False
+    (nothing launched) when the shape is not eligible: the caller then makes the two calls."""
+    lib = _lib.load()
+    d = gemm_desc(GEMM_NT, h, w, o)
+    _mat(y, "y")
+    if residual is not None:
+        _mat(residual, "residual", residual.dtype if residual.dtype in (BF16, F32, F16) else BF16)
+    twin = y_f16 if y_f16 is not None else y_f32
+    M, N = o.shape
+    if twin is not None and (twin.dtype != (F16 if y_f16 is not None else F32) or not twin.is_contiguous() or tuple(twin.shape) != (M, N)):
+        raise ValueError("twin output must be contiguous [M,N] f32 (y_f32) / fp16 (y_f16)")
+    rc = lib.icka_gemm_ln(d, _ptr(bias), _ptr(residual), _ld(residual), 0 if residual is None else _kind(residual), gamma.data_ptr(),
+                          beta.data_ptr(), y.data_ptr(), y.stride(0), _ptr(twin), int(y_f16 is not None), _ptr(xhat), _ptr(rstd), eps,
+                          p_drop, seed, sync.data_ptr(), _stream())
+    if rc == -1:        # ICKA_E_SHAPE: not a shape of the fused kernel
+        return False
+    check(rc, "icka_gemm_ln")
+    return True
+
+
+def gemm_ln_error(sync: torch.Tensor) -> int:
+    """The error word of a ``gemm_ln`` counter buffer (1: a stripe wait gave up; a device read, tests / diagnostics only)."""
+    return int(sync[-16].item())
+
+
 def ln_bwd_slabs(dy, xhat, rstd, gamma, partials, *, dy2=None, dres=None, dx=None, p_drop=0.0, seed=0) -> int:
     """LayerNorm backward without the parameter-gradient finalize; returns the number of slabs left in ``partials``
     (slot 0 -> dgamma, slot 1 -> dbeta) for a slab_reduction."""

@@ -26,6 +26,9 @@ import os as _os
 # 98.1 -> 87.2 us, forward 43.5 -> 45.4 us, c4 step 23.26 -> 23.17 ms (profiles/r04_attn_keepbits_256.txt).
 # "auto" (default): on for self-attention sites with more than 128 keys; "1" / "0": always / never.
 ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "auto")
+# dense -> bias + dropout + residual -> LayerNorm as ONE launch where the shape allows it (icka_gemm_ln: one 128-row block per CU;
+# bitwise the two launches).  "0" keeps the two launches everywhere (same-box A/B: tools/ab_env.sh).
+FUSE_DENSE_LN = _os.environ.get("ICKA_FUSE_DENSE_LN", "1") != "0"
 
 
 def _keepbits_on(Sq: int, Skv: int) -> bool:
@@ -281,17 +284,27 @@ def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool, h16=None):
     M = h.shape[0]
     H = mod.dense.weight.shape[0]
     o = _empty(h, M, H, dtype=F32)      # GEMM -> LayerNorm intermediates stay f32 (no extra 16-bit rounding)
-    if h16 is not None:
-        K.gemm(K.GEMM_NT, h16, A.w16(mod.dense.weight), o)
-    else:
-        K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
     y = _empty(h, M, H)
     yf = _empty(h, M, H, dtype=F16 if d.h16 else F32)
     xhat = _empty(h, M, H) if save else None
     rstd = _empty(h, M, dtype=F32) if save else None
     seed_h = A.next_seed() if d.p_hidden > 0 else 0
+    twin = {"y_f16": yf} if d.h16 else {"y_f32": yf}
+    if FUSE_DENSE_LN and h16 is None:
+        # one launch: the GEMM's blocks finish the rows of their own stripe (icka_gemm_ln; bitwise the two launches below);
+        # shapes the fused kernel does not take (anything but one 128-row block per CU: M = 4096 on MI355X) return False
+        sync = A._ws.get("gemm_ln_sync")
+        if sync is None:
+            sync = A._ws["gemm_ln_sync"] = K.gemm_ln_sync(h.device)
+        if K.gemm_ln(h, A.w(mod.dense.weight), o, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, sync,
+                     xhat=xhat, rstd=rstd, eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **twin):
+            return y, yf, ((xhat, rstd, seed_h) if save else None)
+    if h16 is not None:
+        K.gemm(K.GEMM_NT, h16, A.w16(mod.dense.weight), o)
+    else:
+        K.gemm(K.GEMM_NT, h, A.w(mod.dense.weight), o)
     K.ln_fwd(o, mod.dense.bias, res, mod.LayerNorm.weight, mod.LayerNorm.bias, y, xhat=xhat, rstd=rstd,
-             eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **({"y_f16": yf} if d.h16 else {"y_f32": yf}))
+             eps=d.eps, p_drop=d.p_hidden, seed=seed_h, **twin)
     return y, yf, ((xhat, rstd, seed_h) if save else None)
 
 

@@ -43,7 +43,7 @@ extern "C" {
  * 6: round 5 -- every tuning setter is GONE (icka_gemm_set_*, icka_ln_set_rows_per_wave, icka_attn_set_whole_head,
  *    icka_lstm_set_persistent / _handoff / _batch_split): icka_gemm_desc grew `tune`; icka_attn_fwd_ex's `fp8` argument became
  *    `flags`; icka_attn_bwd, icka_lstm_fwd and icka_lstm_bwd take `flags`; the 256x256-tile and persistent 12-wave GEMM kernels
- *    those setters switched on left the library (profiles/NEGATIVE_RESULTS.md). */
+ *    those setters switched on left the library (profiles/NEGATIVE_RESULTS.md); icka_gemm_ln, icka_gemm_ln_sync_words (additive). */
 #define ICKA_ABI_VERSION 6
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -165,6 +165,23 @@ int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias,
                 int32_t res_is_f32, const float* gamma, const float* beta, void* y, int64_t ldy, void* y2,
                 int64_t ldy2, float* y_f32, void* xhat, float* rstd, int32_t M, int32_t H, float eps, float p_drop,
                 uint64_t seed, void* stream);
+/* dense -> bias + dropout + residual -> LayerNorm as ONE launch (BertSelfOutput.forward :561-565, BertOutput.forward :532-536 =
+ * icka_gemm + icka_ln_fwd with the launch boundary replaced by a per-stripe arrival counter inside the kernel).  `d` describes the
+ * dense GEMM exactly as icka_gemm would take it for this site: op NT, bf16 operands, C = the f32 intermediate [M, N] (written,
+ * then read back by the LayerNorm phase), no bias / epilogue / accumulate in `d` (bias is the LayerNorm phase's, as in
+ * icka_ln_fwd).  The remaining arguments are icka_ln_fwd's (x = d->C): residual [M, N] of kind res_kind (0 bf16, 1 f32,
+ * 2 fp16; ldr), gamma / beta f32 [N], y bf16 [M, N] (ldy), y_twin contiguous f32 (twin_f16 = 0) or fp16 (1) or NULL, xhat
+ * bf16 contiguous and rstd f32 [M] or NULL.  Results are BITWISE those of the two calls.
+ * Eligible shapes: the aligned fast path with eight column tiles per 128-row stripe (N = 768 or 1024), M / 128 a multiple of 8
+ * and M / 128 * 8 blocks <= the device's CUs (the 8 blocks of a stripe wait for each other: all must be resident; M = 4096 on a
+ * whole MI355X).  Anything else returns ICKA_E_SHAPE and launches nothing: the caller takes the two calls.
+ * sync_words: icka_gemm_ln_sync_words() 32-bit words of device memory, zero before the first use; every launch leaves them
+ * zero again (the counters reset themselves), so one buffer serves all fused launches of a stream.  Its LAST 16 words are the
+ * error word: a stripe wait that gave up (bounded spin: never a hang) stores 1 there and the launch's outputs are invalid. */
+int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const void* residual, int64_t ldr, int32_t res_kind,
+                 const float* gamma, const float* beta, void* y, int64_t ldy, void* y_twin, int32_t twin_f16, void* xhat,
+                 float* rstd, float eps, float p_drop, uint64_t seed, uint32_t* sync_words, void* stream);
+int64_t icka_gemm_ln_sync_words(void);
 /* "mixed16" form of the same call: x_kind / res_kind are 0 = bf16, 1 = f32, 2 = fp16, and the twin copy of the output is
  * fp16 (y_f16, contiguous, saturating at +-65504): it is both the fp16 MFMA operand of the next forward GEMM and the
  * residual input of the next block, while y (bf16) stays the operand of the bf16 weight-gradient GEMM in backward. */

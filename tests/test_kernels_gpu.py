@@ -707,3 +707,48 @@ def test_embed_bwd_rows_plus_scatter_equals_embed_bwd():
     ref = torch.zeros(V, H, device="cuda").index_add_(0, ids2, two.float() * 0.5)
     ref[0] = 0.0
     assert torch.allclose(acc, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,p,res_dtype,twin", [(4096, 768, 768, 0.1, F32, "f32"), (4096, 768, 3072, 0.0, F32, "f32"),
+                                                    (1024, 768, 768, 0.1, BF16, None), (4096, 1024, 1024, 0.1, F32, "f32"),
+                                                    (2048, 1024, 4096, 0.0, torch.float16, "f16")])
+def test_gemm_ln_one_launch_equals_the_two_launches_bitwise(M, N, K, p, res_dtype, twin):
+    """icka_gemm_ln (dense -> bias + dropout + residual -> LayerNorm in ONE launch: the 8 blocks of a 128-row stripe meet at an
+    arrival counter, then finish 16 rows each through the row body shared with ln_fwd_kernel) == icka_gemm + icka_ln_fwd, BITWISE:
+    y, twin, xhat, rstd and the f32 intermediate; repeated launches on ONE counter buffer (the counters reset themselves); the
+    error word stays 0.  Shapes outside the fused kernel's domain return False and launch nothing.
+    (reference: BertSelfOutput.forward Cross_Modal_Interaction_Module.py:561-565, BertOutput.forward :532-536)"""
+    k = _k()
+    h, w = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5)
+    bias, gamma, beta = rnd(N, seed=3, dtype=F32), rnd(N, seed=4, dtype=F32) + 1.0, rnd(N, seed=5, dtype=F32)
+    res = rnd(M, N, seed=6, dtype=F32).to(res_dtype)
+    seed = 0x1234567890
+
+    def outs():
+        o = torch.full((M, N), float("nan"), dtype=F32, device="cuda")
+        y = torch.empty(M, N, dtype=BF16, device="cuda")
+        tw = None if twin is None else torch.empty(M, N, dtype=F32 if twin == "f32" else torch.float16, device="cuda")
+        return o, y, tw, torch.empty(M, N, dtype=BF16, device="cuda"), torch.empty(M, dtype=F32, device="cuda")
+
+    tw_kw = lambda t: {} if twin is None else ({"y_f32": t} if twin == "f32" else {"y_f16": t})
+    o0, y0, t0, xh0, rs0 = outs()
+    k.gemm(k.GEMM_NT, h, w, o0)
+    k.ln_fwd(o0, bias, res, gamma, beta, y0, xhat=xh0, rstd=rs0, eps=1e-12, p_drop=p, seed=seed, **tw_kw(t0))
+    ref = torch.nn.functional.layer_norm((h.float() @ w.float().t() + bias) * k.dropout_mask(M * N, p, seed, "cuda").view(M, N)
+                                         + res.float(), (N,), gamma, beta, 1e-12)
+    assert rel_err(y0, ref) < 1e-2
+    sync = k.gemm_ln_sync("cuda")
+    for rep in range(3):        # one counter buffer, launch after launch
+        o1, y1, t1, xh1, rs1 = outs()
+        assert k.gemm_ln(h, w, o1, bias, res, gamma, beta, y1, sync, xhat=xh1, rstd=rs1, eps=1e-12, p_drop=p, seed=seed, **tw_kw(t1))
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o0) and torch.equal(y1, y0) and torch.equal(xh1, xh0) and torch.equal(rs1, rs0), rep
+        if twin is not None:
+            assert torch.equal(t1, t0)
+        assert k.gemm_ln_error(sync) == 0 and int(sync[:-16].abs().sum().item()) == 0      # counters back at zero
+    # outside the domain: not 8 column tiles / stripes not in groups of 8 / more blocks than CUs -> False, nothing launched
+    for (m2, n2) in ((4096, 2304), (512, 768), (8192, 768)):
+        o = torch.zeros(m2, n2, dtype=F32, device="cuda")
+        assert not k.gemm_ln(rnd(m2, K, seed=7), rnd(n2, K, seed=8), o, None, None, rnd(n2, seed=9, dtype=F32), rnd(n2, seed=10, dtype=F32),
+                             torch.empty(m2, n2, dtype=BF16, device="cuda"), sync)
+        assert o.abs().sum().item() == 0.0
