@@ -1149,6 +1149,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
         }
 #endif
         if (wave < 4) {
+            __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, 0x7ffffff0, 0x00020000);   // (LNF stores)
+            (void)crsrc;
             if (do_cs && lane < 16) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
@@ -1166,8 +1168,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmArgs& g, char* smem, cons
                 for (int mi = 0; mi < 4; ++mi) {
                     const int m = m0 + wr + 16 * mi + (lane & 15);
                     const f32x4 v = acc[mi][ni] * g.alpha + b4;
-                    if constexpr (LNF) {   // write-through: the rows are read by OTHER CUs of this launch (sc1 loads, ln_row.h)
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), "v"(v) : "memory");
+                    if constexpr (LNF) {
+                        // write-through (sc1 raw buffer store): the rows are read by OTHER CUs of this launch (ln_row.h).  (A first
+                        // version used an inline-asm global_store ... sc1: hipcc's hazard recognizer cannot see into it, and the
+                        // next tile's v_pk_fma overwrote the data registers of the store in flight -- 10 % wrong elements.)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crsrc, (int)(((int64_t)m * g.ldc + n) * 4), 0, 16);
                     } else if (g.c_f32) {
                         if (!A_KM || !g.c3_only) st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n), v);
                         if constexpr (A_KM) {   // weight-gradient instances only: the data-parallel wire copy
@@ -1817,6 +1822,7 @@ extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const vo
     const int stripes = g.M / BM;
     if (!bnt || stripes % 8 != 0 || stripes > GEMM_LN_MAX_STRIPES || stripes * 8 > device_cus()) return ICKA_E_SHAPE;
     if (g.N % 8 || ldy % 8 || (residual && ldr % 8) || g.ldc % 4) return ICKA_E_ALIGN;
+    if ((int64_t)g.M * g.ldc * 4 >= (1ll << 31) - 64) return ICKA_E_SHAPE;      // 32-bit byte offsets of the raw buffer accesses
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (!al16(y) || (residual && !al16(residual)) || (xhat && !al16(xhat)) || (bias && !al16(bias)) || !al16(gamma) || !al16(beta) ||
         (y_twin && !al16(y_twin)))

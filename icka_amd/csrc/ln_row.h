@@ -77,34 +77,29 @@ __device__ __forceinline__ void ln_load_raw(const LnFwdArgs& a, int row, int lan
 }
 
 // x loads that bypass this CU's L1 (sc1): the row was written by OTHER CUs of the same launch (gemm_ln_kernel: write-through
-// sc1 stores, s_waitcnt vmcnt(0), then the stripe's arrival counter) -- L2 / memory serve it, whatever this CU's L1 still
-// holds of the buffer from an earlier launch.  The loads are issued without a wait; ln_wait_sc1 makes their registers
-// depend on ONE s_waitcnt vmcnt(0) (hipcc does not count inline-asm loads).
-__device__ __forceinline__ void load8f_sc1(const float* p, f32x4& a, f32x4& b) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1"
-                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+// sc1 stores, s_waitcnt vmcnt(0), then the stripe's arrival counter) -- L2 / memory serve it, whatever this CU's L1 still holds of
+// the buffer from an earlier launch.  Raw buffer loads with the sc1 cache-policy bit (aux 16): 16-byte loads the compiler
+// tracks itself (waits, hazards) -- inline-asm loads were tried first: hipcc copies their result registers before the wait.
+constexpr int ICKA_CPOL_SC1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_x_rsrc(const LnFwdArgs& a) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ void load8f_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float (&o)[8]) {
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, ICKA_CPOL_SC1);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, ICKA_CPOL_SC1);
+    o[0] = __uint_as_float(lo[0]); o[1] = __uint_as_float(lo[1]); o[2] = __uint_as_float(lo[2]); o[3] = __uint_as_float(lo[3]);
+    o[4] = __uint_as_float(hi[0]); o[5] = __uint_as_float(hi[1]); o[6] = __uint_as_float(hi[2]); o[7] = __uint_as_float(hi[3]);
 }
 template <int NCH>
-__device__ __forceinline__ void ln_load_raw_sc1(const LnFwdArgs& a, int row, int lane, int nchunk, f32x4 (&xa)[NCH], f32x4 (&xb)[NCH],
-                                                float (&r)[NCH][8]) {
+__device__ __forceinline__ void ln_load_raw_sc1(const LnFwdArgs& a, __amdgpu_buffer_rsrc_t xr, int row, int lane, int nchunk,
+                                                float (&x)[NCH][8], float (&r)[NCH][8]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            load8f_sc1(reinterpret_cast<const float*>(a.x) + (int64_t)row * a.ldx + c * 8, xa[i], xb[i]);
+            load8f_sc1(xr, (int)(((int64_t)row * a.ldx + c * 8) * 4), x[i]);      // (host: M * ldx * 4 < 2^31)
             if (a.res) load8x(a.res, a.r_f32, (int64_t)row * a.ldr + c * 8, r[i]);
         }
-    }
-}
-template <int NCH>
-__device__ __forceinline__ void ln_wait_sc1(f32x4 (&xa)[NCH], f32x4 (&xb)[NCH], float (&x)[NCH][8]) {
-    static_assert(NCH <= 2, "operand list of the wait below");
-    if constexpr (NCH == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa[0]), "+v"(xb[0]) :: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa[0]), "+v"(xb[0]), "+v"(xa[1]), "+v"(xb[1]) :: "memory");
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        x[i][0] = xa[i][0]; x[i][1] = xa[i][1]; x[i][2] = xa[i][2]; x[i][3] = xa[i][3];
-        x[i][4] = xb[i][0]; x[i][5] = xb[i][1]; x[i][6] = xb[i][2]; x[i][7] = xb[i][3];
     }
 }
 
@@ -115,20 +110,17 @@ __device__ __forceinline__ void ln_fwd_rows(const LnFwdArgs& a, int row0, int st
     const int nchunk = a.H >> 3;
     const float inv_h = 1.f / (float)a.H;
     float s[NCH][8], rr[NCH][8];
-    f32x4 sa[XSC1 ? NCH : 1], sb[XSC1 ? NCH : 1];
+    __amdgpu_buffer_rsrc_t xr = ln_x_rsrc(a);
     if (row0 < row_end) {
-        if constexpr (XSC1) ln_load_raw_sc1<NCH>(a, row0, lane, nchunk, sa, sb, rr);
+        if constexpr (XSC1) ln_load_raw_sc1<NCH>(a, xr, row0, lane, nchunk, s, rr);
         else ln_load_raw<NCH>(a, row0, lane, nchunk, s, rr);
     }
     for (int row = row0; row < row_end; row += step) {
         float nx[NCH][8], nr[NCH][8];
-        f32x4 na[XSC1 ? NCH : 1], nb[XSC1 ? NCH : 1];
         const int nrow = row + step;
-        if constexpr (XSC1) {
-            ln_wait_sc1<NCH>(sa, sb, s);            // this row's x has arrived (and nothing else of this wave is in flight)
-            if (nrow < row_end) ln_load_raw_sc1<NCH>(a, nrow, lane, nchunk, na, nb, nr);
-        } else {
-            if (nrow < row_end) ln_load_raw<NCH>(a, nrow, lane, nchunk, nx, nr);   // in flight while this row is reduced and stored
+        if (nrow < row_end) {                                  // in flight while this row is reduced and stored
+            if constexpr (XSC1) ln_load_raw_sc1<NCH>(a, xr, nrow, lane, nchunk, nx, nr);
+            else ln_load_raw<NCH>(a, nrow, lane, nchunk, nx, nr);
         }
         float sum = 0.f;
 #pragma unroll
@@ -185,14 +177,9 @@ __device__ __forceinline__ void ln_fwd_rows(const LnFwdArgs& a, int row0, int st
         }
         if (nrow < row_end) {
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                if constexpr (XSC1) { sa[i] = na[i]; sb[i] = nb[i]; }
+            for (int i = 0; i < NCH; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if constexpr (!XSC1) s[i][e] = nx[i][e];
-                    rr[i][e] = nr[i][e];
-                }
-            }
+                for (int e = 0; e < 8; ++e) { s[i][e] = nx[i][e]; rr[i][e] = nr[i][e]; }
         }
     }
 }

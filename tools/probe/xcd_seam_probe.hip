@@ -26,7 +26,7 @@ constexpr int MAX_POLLS = 1 << 18;
 __device__ __forceinline__ unsigned pattern(int row, int col8, int iter) {   // value of the 8-element group (row, col8): 16 bytes
     return (unsigned)(row * 131 + col8 * 7 + iter * 1000003);
 }
-__device__ __forceinline__ void store16_sc1(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store16_sc1(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }   // (s_nop: store-data hazard)
 __device__ __forceinline__ u32x4 load16_sc1(const void* p) {
     u32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
