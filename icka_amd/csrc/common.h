@@ -81,6 +81,10 @@ struct DropCfg {
                             // fresh masks while forward and backward of one step still agree
 };
 extern const uint32_t* g_icka_nonce;   // set by icka_set_dropout_nonce (elementwise.hip)
+// CUs the caller has reserved for OTHER kernels that may run beside ours (icka_lstm_set_reserved_cus: dp.GradReducer reserves
+// the CUs RCCL's workgroups may hold): every launch whose blocks wait for each other (the persistent BiLSTM, icka_gemm_ln)
+// is used only when its grid fits into the device's CUs minus this reserve.  Defined in elementwise.hip.
+extern int g_icka_reserved_cus;
 __host__ __device__ __forceinline__ DropCfg make_drop(float p, uint64_t seed) {
     DropCfg d;
     d.s0 = (uint32_t)seed;

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(256) void copy_many_kernel(const CopyMany t) {
 }  // namespace
 
 const uint32_t* g_icka_nonce = nullptr;
+int g_icka_reserved_cus = 0;
 
 extern "C" int icka_abi_version(void) { return ICKA_ABI_VERSION; }
 extern "C" int icka_set_dropout_nonce(const uint32_t* device_words) {

@@ -1245,47 +1245,66 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
 // rows, 16 bytes per lane, like the row kernel.  The counters reset themselves: the last of the 8 blocks to LEAVE the wait
 // zeroes both words (by then every block of the stripe has seen the count), so a launch leaves the workspace as it found it
 // and the same words serve every fused launch of a stream (launches of one stream do not overlap).
-// A wait that gives up (a block of the stripe never became resident: more blocks than CUs are refused on the host) stores 1
-// into the error word and the block goes on with whatever the intermediate holds: never a hang; the host polls the word.
+// A wait that gives up (a block of the stripe never became resident: grids of more blocks than the device's CUs minus the
+// caller's reserve, icka_lstm_set_reserved_cus, are refused on the host) stores 1 into the error word -- host-mapped memory the
+// host polls without a device synchronisation -- and the block turns the rows it finished into NaN: never a hang, never a
+// silent wrong result.
 struct GemmLnArgs {
     GemmArgs g;
     LnFwdArgs ln;
-    unsigned int* sync;      // [stripes][32] words: [0] arrivals, [16] departures (one 64-byte line each); then 1 error word
-    unsigned int* err;
+    unsigned int* sync;      // [stripes][32] words: [0] arrivals, [16] departures (one 64-byte line each)
+    unsigned int* err;       // error word (host-mapped memory when the caller wants to poll it without a device sync)
     int polls;
+    int test_drop;           // test hook: this block never arrives (its stripe's waits give up); -1 = off
 };
 template <int BNT, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_ln_kernel(const GemmLnArgs p) {
     const GemmArgs g = p.g;
     __shared__ __attribute__((aligned(16))) char smem[3 * 2 * TILE_BYTES];
-    gemm_ws_body<false, false, 3, 0, 2, BNT, F16, false, true>(g, smem, blockIdx.x, gridDim.x);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left the CU
-    __syncthreads();
+    __shared__ int s_gave_up;
     int m0, n0;
     tile_origin(blockIdx.x, gridDim.x, g.M / BM, g.N / BNT, m0, n0, BNT);
     const int nbn = g.N / BNT;                             // = 8 (host)
-    if (threadIdx.x == 0) {
-        unsigned int* arrive = p.sync + (size_t)(m0 / BM) * 32;
-        unsigned int* depart = arrive + 16;
-        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = false;
-        for (int i = 0; i < p.polls; ++i) {
-            if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nbn) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nbn - 1)) {
-            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block of the stripe has seen 8
-            __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
     LnFwdArgs a = p.ln;
     a.drop = drop_resolve(a.drop);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int ROWS_PER_BLOCK = BM / 8, ROWS_PER_WAVE = ROWS_PER_BLOCK / 8;
     const int r0 = m0 + (n0 / BNT) * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
-    ln_fwd_rows<2, true>(a, r0, 1, r0 + ROWS_PER_WAVE, lane);
+    // the residual rows this wave will finish do not depend on the GEMM: requested now, they arrive under the k-loop instead of
+    // in the tail, where all 256 blocks would ask HBM for them at the same moment (32 registers per lane, held across the loop)
+    float rr[ROWS_PER_WAVE][2][8];
+    ln_prefetch_res<2, ROWS_PER_WAVE>(a, r0, lane, rr);
+    gemm_ws_body<false, false, 3, 0, 2, BNT, F16, false, true>(g, smem, blockIdx.x, gridDim.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int* arrive = p.sync + (size_t)(m0 / BM) * 32;
+        unsigned int* depart = arrive + 16;
+        if ((int)blockIdx.x != p.test_drop) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = false;
+        for (int i = 0; i < p.polls; ++i) {
+            if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nbn) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        s_gave_up = ok ? 0 : 1;
+        if (!ok) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the last block to LEAVE the wait zeroes the stripe's words (every block of the stripe has stopped polling by then --
+        // it saw the full count or gave up): the workspace is left as it was found, also after a failed launch
+        if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nbn - 1)) {
+            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    ln_fwd_rows_handoff<2, ROWS_PER_WAVE>(a, r0, lane, rr);
+    if (s_gave_up) {
+        // a failed launch never passes for a result: the rows this block finished from an incomplete stripe become NaN (y is the
+        // operand of everything downstream: the loss and every gradient of the step are NaN), and the host raises at its next
+        // touch-point (kernels.gemm_ln_check_error)
+        const bf16_t qnan = f2bf(__builtin_nanf(""));
+        for (int r = 0; r < ROWS_PER_WAVE; ++r)
+            for (int c = lane; c < a.H; c += 64) a.y[(int64_t)(r0 + r) * a.ldy + c] = qnan;
+    }
 }
 
 // Two co-resident blocks per CU (64 KiB ring of 2 each, 4 waves per SIMD -> <= 128 VGPRs): for grids of several
@@ -1799,13 +1818,19 @@ static int device_cus() {
     return n;
 }
 constexpr int GEMM_LN_MAX_STRIPES = 64;
-extern "C" int64_t icka_gemm_ln_sync_words(void) { return (int64_t)GEMM_LN_MAX_STRIPES * 32 + 16; }
-// 1 if a stripe wait of an icka_gemm_ln launch ever gave up (sync_words[last 16 words][0]); the caller reads / clears the word
-// itself (it is ordinary device memory it owns) -- see icka_amd/kernels.py gemm_ln_error.
+static int g_gemm_ln_polls = 0;      // icka_gemm_ln_test_hooks: 0 = the default budget (~7 ms of s_sleep polls)
+static int g_gemm_ln_drop = -1;      // icka_gemm_ln_test_hooks: block that never arrives (-1: off)
+extern "C" int64_t icka_gemm_ln_sync_words(void) { return (int64_t)GEMM_LN_MAX_STRIPES * 32; }
+extern "C" int icka_gemm_ln_test_hooks(int32_t polls, int32_t drop_block) {
+    g_gemm_ln_polls = polls > 0 ? polls : 0;
+    g_gemm_ln_drop = drop_block >= 0 ? drop_block : -1;
+    return 0;
+}
 extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const void* residual, int64_t ldr, int32_t res_kind,
                             const float* gamma, const float* beta, void* y, int64_t ldy, void* y_twin, int32_t twin_f16,
-                            void* xhat, float* rstd, float eps, float p_drop, uint64_t seed, uint32_t* sync_words, void* stream) {
-    if (!d || !gamma || !beta || !y || !sync_words) return ICKA_E_ARG;
+                            void* xhat, float* rstd, float eps, float p_drop, uint64_t seed, uint32_t* sync_words,
+                            uint32_t* error_word, void* stream) {
+    if (!d || !gamma || !beta || !y || !sync_words || !error_word) return ICKA_E_ARG;
     if (res_kind < 0 || res_kind > 2) return ICKA_E_ARG;
     GemmArgs g;
     Tune t;
@@ -1820,7 +1845,7 @@ extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const vo
         return ICKA_E_SHAPE;
     const int bnt = (g.N % 96 == 0 && g.N / 96 == 8) ? 96 : ((g.N % 128 == 0 && g.N / 128 == 8) ? 128 : 0);
     const int stripes = g.M / BM;
-    if (!bnt || stripes % 8 != 0 || stripes > GEMM_LN_MAX_STRIPES || stripes * 8 > device_cus()) return ICKA_E_SHAPE;
+    if (!bnt || stripes % 8 != 0 || stripes > GEMM_LN_MAX_STRIPES || stripes * 8 > device_cus() - g_icka_reserved_cus) return ICKA_E_SHAPE;
     if (g.N % 8 || ldy % 8 || (residual && ldr % 8) || g.ldc % 4) return ICKA_E_ALIGN;
     if ((int64_t)g.M * g.ldc * 4 >= (1ll << 31) - 64) return ICKA_E_SHAPE;      // 32-bit byte offsets of the raw buffer accesses
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1832,8 +1857,9 @@ extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const vo
     p.ln = LnFwdArgs{g.C, g.ldc, 1, bias, residual, ldr, res_kind, gamma, beta, (bf16_t*)y, ldy, nullptr, 0, y_twin, (bf16_t*)xhat, rstd,
                      g.M, g.N, eps, make_drop(p_drop, seed), twin_f16};
     p.sync = sync_words;
-    p.err = sync_words + (size_t)GEMM_LN_MAX_STRIPES * 32;
-    p.polls = 1 << 18;
+    p.err = error_word;
+    p.polls = g_gemm_ln_polls > 0 ? g_gemm_ln_polls : (1 << 18);
+    p.test_drop = g_gemm_ln_drop;
     hipStream_t st = (hipStream_t)stream;
     if (bnt == 96) hipLaunchKernelGGL((gemm_ln_kernel<96>), dim3(stripes * 8), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_ln_kernel<128>), dim3(stripes * 8), dim3(512), 0, st, p);

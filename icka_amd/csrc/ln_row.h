@@ -90,91 +90,78 @@ __device__ __forceinline__ void load8f_sc1(__amdgpu_buffer_rsrc_t r, int byte_of
     o[0] = __uint_as_float(lo[0]); o[1] = __uint_as_float(lo[1]); o[2] = __uint_as_float(lo[2]); o[3] = __uint_as_float(lo[3]);
     o[4] = __uint_as_float(hi[0]); o[5] = __uint_as_float(hi[1]); o[6] = __uint_as_float(hi[2]); o[7] = __uint_as_float(hi[3]);
 }
+// ONE row from its raw operands to its stores: s = the dense output (x), rr = the residual (ignored without a.res); on return s holds
+// the pre-normalisation row.  The single definition of the arithmetic of every forward path.
 template <int NCH>
-__device__ __forceinline__ void ln_load_raw_sc1(const LnFwdArgs& a, __amdgpu_buffer_rsrc_t xr, int row, int lane, int nchunk,
-                                                float (&x)[NCH][8], float (&r)[NCH][8]) {
+__device__ __forceinline__ void ln_row_finish(const LnFwdArgs& a, int row, int lane, float (&s)[NCH][8], const float (&rr)[NCH][8]) {
+    const int nchunk = a.H >> 3;
+    const float inv_h = 1.f / (float)a.H;
+    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            load8f_sc1(xr, (int)(((int64_t)row * a.ldx + c * 8) * 4), x[i]);      // (host: M * ldx * 4 < 2^31)
-            if (a.res) load8x(a.res, a.r_f32, (int64_t)row * a.ldr + c * 8, r[i]);
+            if (a.bias) {
+                float b[8];
+                load8f(a.bias + c * 8, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[i][e] += b[e];
+            }
+            if (a.drop.thr) {
+                const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[i][e] *= drop_mul(a.drop, base + e);
+            }
+            if (a.res) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[i][e] += rr[i][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += s[i][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) * inv_h;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = s[i][e] - mean; sq += d * d; }
+        }
+    const float var = wave_sum(sq) * inv_h;
+    const float rstd = 1.f / sqrtf(var + a.eps);
+    if (lane == 0 && a.rstd) a.rstd[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float g[8], b[8], xh[8], o[8];
+            load8f(a.gamma + c * 8, g);
+            load8f(a.beta + c * 8, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xh[e] = (s[i][e] - mean) * rstd; o[e] = g[e] * xh[e] + b[e]; }
+            store8(a.y + (int64_t)row * a.ldy + c * 8, o);
+            if (a.y2) store8(a.y2 + (int64_t)row * a.ldy2 + c * 8, o);
+            if (a.yf) store8t(a.yf, a.yf_f16, (int64_t)row * a.H + c * 8, o);
+            if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
         }
     }
 }
 
-// Rows row0, row0 + step, ... < row_end of ONE wave.  ``a.drop`` is already resolved (drop_resolve).  XSC1: x is f32 and read
-// with L1-bypassing loads (see above); the arithmetic is the same in both forms.
-template <int NCH, bool XSC1 = false>
+// Rows row0, row0 + step, ... < row_end of ONE wave (the stand-alone row kernel).  ``a.drop`` is already resolved (drop_resolve).
+template <int NCH>
 __device__ __forceinline__ void ln_fwd_rows(const LnFwdArgs& a, int row0, int step, int row_end, int lane) {
     const int nchunk = a.H >> 3;
-    const float inv_h = 1.f / (float)a.H;
     float s[NCH][8], rr[NCH][8];
-    __amdgpu_buffer_rsrc_t xr = ln_x_rsrc(a);
-    if (row0 < row_end) {
-        if constexpr (XSC1) ln_load_raw_sc1<NCH>(a, xr, row0, lane, nchunk, s, rr);
-        else ln_load_raw<NCH>(a, row0, lane, nchunk, s, rr);
-    }
+    if (row0 < row_end) ln_load_raw<NCH>(a, row0, lane, nchunk, s, rr);
     for (int row = row0; row < row_end; row += step) {
         float nx[NCH][8], nr[NCH][8];
         const int nrow = row + step;
-        if (nrow < row_end) {                                  // in flight while this row is reduced and stored
-            if constexpr (XSC1) ln_load_raw_sc1<NCH>(a, xr, nrow, lane, nchunk, nx, nr);
-            else ln_load_raw<NCH>(a, nrow, lane, nchunk, nx, nr);
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk) {
-                if (a.bias) {
-                    float b[8];
-                    load8f(a.bias + c * 8, b);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] += b[e];
-                }
-                if (a.drop.thr) {
-                    const uint32_t base = (uint32_t)row * (uint32_t)a.H + c * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] *= drop_mul(a.drop, base + e);
-                }
-                if (a.res) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[i][e] += rr[i][e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum += s[i][e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s[i][e] = 0.f;
-            }
-        }
-        const float mean = wave_sum(sum) * inv_h;
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (lane + 64 * i < nchunk) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = s[i][e] - mean; sq += d * d; }
-            }
-        const float var = wave_sum(sq) * inv_h;
-        const float rstd = 1.f / sqrtf(var + a.eps);
-        if (lane == 0 && a.rstd) a.rstd[row] = rstd;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk) {
-                float g[8], b[8], xh[8], o[8];
-                load8f(a.gamma + c * 8, g);
-                load8f(a.beta + c * 8, b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[e] = (s[i][e] - mean) * rstd; o[e] = g[e] * xh[e] + b[e]; }
-                store8(a.y + (int64_t)row * a.ldy + c * 8, o);
-                if (a.y2) store8(a.y2 + (int64_t)row * a.ldy2 + c * 8, o);
-                if (a.yf) store8t(a.yf, a.yf_f16, (int64_t)row * a.H + c * 8, o);
-                if (a.xhat) store8(a.xhat + (int64_t)row * a.H + c * 8, xh);
-            }
-        }
+        if (nrow < row_end) ln_load_raw<NCH>(a, nrow, lane, nchunk, nx, nr);   // in flight while this row is reduced and stored
+        ln_row_finish<NCH>(a, row, lane, s, rr);
         if (nrow < row_end) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
@@ -182,6 +169,37 @@ __device__ __forceinline__ void ln_fwd_rows(const LnFwdArgs& a, int row0, int st
                 for (int e = 0; e < 8; ++e) { s[i][e] = nx[i][e]; rr[i][e] = nr[i][e]; }
         }
     }
+}
+
+// The LayerNorm phase of gemm_ln_kernel, per wave: NR consecutive rows whose RESIDUAL operands were loaded before the GEMM
+// started (ln_prefetch_res: they do not depend on it, and after the seam the whole chip would ask HBM for them at once) and
+// whose x arrives from the other blocks of the stripe: all NR rows' x loads (sc1: L2 / memory, not this CU's L1) are issued
+// at once, then the rows are finished one after the other.
+template <int NCH, int NR>
+__device__ __forceinline__ void ln_prefetch_res(const LnFwdArgs& a, int row0, int lane, float (&rr)[NR][NCH][8]) {
+    const int nchunk = a.H >> 3;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (a.res && c < nchunk) load8x(a.res, a.r_f32, (int64_t)(row0 + r) * a.ldr + c * 8, rr[r][i]);
+        }
+}
+template <int NCH, int NR>
+__device__ __forceinline__ void ln_fwd_rows_handoff(const LnFwdArgs& a, int row0, int lane, const float (&rr)[NR][NCH][8]) {
+    const int nchunk = a.H >> 3;
+    __amdgpu_buffer_rsrc_t xr = ln_x_rsrc(a);
+    float s[NR][NCH][8];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) load8f_sc1(xr, (int)(((int64_t)(row0 + r) * a.ldx + c * 8) * 4), s[r][i]);      // (host: M * ldx * 4 < 2^31)
+        }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) ln_row_finish<NCH>(a, row0 + r, lane, s[r], rr[r]);
 }
 
 }  // namespace

@@ -768,7 +768,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmArgs a, unsi
 // registers per lane of some SIMD -- an RCCL all-reduce workgroup on the communication stream of a data-parallel step
 // (dp.GradReducer) -- cannot take one until that workgroup exits: the grid is no longer co-resident by construction and
 // its blocks would spin on a peer that has not started.  The reducer reserves as many CUs as RCCL runs channels.
-int g_lstm_reserved_cus = 0;
 static int lstm_cus() {
     static int n = 0;
     if (n == 0) {
@@ -776,7 +775,7 @@ static int lstm_cus() {
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
         else { n = 1; (void)hipGetLastError(); }
     }
-    const int avail = n - g_lstm_reserved_cus;
+    const int avail = n - g_icka_reserved_cus;
     return avail > 0 ? avail : 0;
 }
 // Which form a call takes is decided PER CALL by its ``flags`` argument (ICKA_LSTM_*, include/icka_hip.h): the default (0) is
@@ -1117,7 +1116,7 @@ extern "C" int icka_lstm_clear_error(void) {
 }
 extern "C" int icka_lstm_set_reserved_cus(int32_t n) {
     if (n < 0) return ICKA_E_ARG;
-    g_lstm_reserved_cus = n;
+    g_icka_reserved_cus = n;
     return 0;
 }
 /* Test hooks of the give-up path: poll_limit > 0 replaces the per-form poll budgets (0 restores them); drop_step >= 0 makes

@@ -381,6 +381,7 @@ class _StepCapture(_StepBase):
         # a persistent LSTM launch of an EARLIER replay that gave up a hand-off (NaN-poisoned outputs): raise at this host
         # touch-point (a host read of a mapped word, no synchronisation)
         K.lstm_check_error("detected before a GraphedStep replay")
+        K.gemm_ln_check_error("detected before a GraphedStep replay")
         accumulate, stale = self._cycle_state()
         if accumulate and True not in self._graphs:
             self._capture(True)                 # (a capture executes nothing: the gradients held so far are untouched)
@@ -723,6 +724,7 @@ class _ModuleCapture(_StepBase):
         if self.arena.shadow_policy != "always":
             self.arena.sync()
         K.lstm_check_error("detected before a GraphedModule replay")
+        K.gemm_ln_check_error("detected before a GraphedModule replay")
         if self.reducer is not None:
             K.dp_check_error("detected before a GraphedModule replay")
         if torch.is_grad_enabled() and self._bwd:
@@ -1055,6 +1057,7 @@ class SegmentedStep(_StepBase):
         if self.arena.shadow_policy != "always":
             self.arena.sync()
         K.lstm_check_error("detected before a SegmentedStep replay")
+        K.gemm_ln_check_error("detected before a SegmentedStep replay")
         for graph, buckets in self.segments:
             graph.replay()
             for bi in buckets:
@@ -1266,6 +1269,7 @@ class FlaggedStep(_StepBase):
         if self.arena.shadow_policy != "always":
             self.arena.sync()
         K.lstm_check_error("detected before a FlaggedStep replay")
+        K.gemm_ln_check_error("detected before a FlaggedStep replay")
         K.dp_check_error("detected before a FlaggedStep replay")
         accumulate, stale = self._cycle_state()
         if not accumulate:

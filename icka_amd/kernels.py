@@ -340,6 +340,20 @@ def ln_fwd(x, bias, residual, gamma, beta, y, *, y2=None, y_f32=None, y_f16=None
     return y
 
 
+class GemmLnHandoffError(RuntimeError):
+    """A stripe wait of a fused dense + LayerNorm launch gave up: the rows it finished are NaN."""
+
+
+_GEMM_LN_ERR = None      # one pinned (host-mapped) error word for the process: polled by the host without a device sync
+
+
+def _gemm_ln_err_word() -> torch.Tensor:
+    global _GEMM_LN_ERR
+    if _GEMM_LN_ERR is None:
+        _GEMM_LN_ERR = torch.zeros(16, dtype=torch.int32).pin_memory()
+    return _GEMM_LN_ERR
+
+
 def gemm_ln_sync(device) -> torch.Tensor:
     """Zeroed counter words for ``gemm_ln`` (icka_gemm_ln_sync_words; the launches leave them zero: one buffer per stream)."""
     return torch.zeros(_lib.load().icka_gemm_ln_sync_words(), dtype=torch.int32, device=device)
@@ -349,7 +363,9 @@ def gemm_ln(h, w, o, bias, residual, gamma, beta, y, sync, *, y_f32=None, y_f16=
             p_drop=0.0, seed=0) -> bool:
     """dense (h @ w^T -> o, f32) + bias + dropout + residual + LayerNorm -> y (and twin / xhat / rstd) as ONE launch
     (icka_gemm_ln) -- bitwise ``gemm(NT, h, w, o)`` followed by ``ln_fwd(o, bias, residual, gamma, beta, y, ...)``.  Returns False
-    (nothing launched) when the shape is not eligible: the caller then makes the two calls."""
+    (nothing launched) when the shape is not eligible: the caller then makes the two calls.  A stripe wait of an EARLIER fused
+    launch that gave up is raised here (gemm_ln_check_error: a host read of a pinned word)."""
+    gemm_ln_check_error("detected before the next fused launch")
     lib = _lib.load()
     d = gemm_desc(GEMM_NT, h, w, o)
     _mat(y, "y")
@@ -361,16 +377,24 @@ def gemm_ln(h, w, o, bias, residual, gamma, beta, y, sync, *, y_f32=None, y_f16=
         raise ValueError("twin output must be contiguous [M,N] f32 (y_f32) / fp16 (y_f16)")
     rc = lib.icka_gemm_ln(d, _ptr(bias), _ptr(residual), _ld(residual), 0 if residual is None else _kind(residual), gamma.data_ptr(),
                           beta.data_ptr(), y.data_ptr(), y.stride(0), _ptr(twin), int(y_f16 is not None), _ptr(xhat), _ptr(rstd), eps,
-                          p_drop, seed, sync.data_ptr(), _stream())
+                          p_drop, seed, sync.data_ptr(), _gemm_ln_err_word().data_ptr(), _stream())
     if rc == -1:        # ICKA_E_SHAPE: not a shape of the fused kernel
         return False
     check(rc, "icka_gemm_ln")
     return True
 
 
-def gemm_ln_error(sync: torch.Tensor) -> int:
-    """The error word of a ``gemm_ln`` counter buffer (1: a stripe wait gave up; a device read, tests / diagnostics only)."""
-    return int(sync[-16].item())
+def gemm_ln_check_error(where: str = "") -> None:
+    """Raise if a fused dense + LayerNorm launch ever reported a stripe wait that gave up.  The word is pinned host memory the
+    kernel writes with a system-scope store: the check is a plain host read, no device synchronisation, so it runs at every host
+    touch-point (the next fused launch, GraphedStep / GraphedModule replays).  The word is cleared when the error is raised."""
+    if _GEMM_LN_ERR is not None and int(_GEMM_LN_ERR[0]) != 0:
+        _GEMM_LN_ERR[0] = 0
+        raise GemmLnHandoffError(
+            "icka_amd fused dense + LayerNorm%s: a block gave up waiting for the other blocks of its 128-row stripe -- the grid "
+            "was not co-resident (another kernel held CUs: a collective on another stream, a second model, a partitioned GPU).  "
+            "The rows it finished are NaN.  Reserve CUs (icka_lstm_set_reserved_cus) or set ICKA_FUSE_DENSE_LN=0."
+            % ((" (" + where + ")") if where else ""))
 
 
 def ln_bwd_slabs(dy, xhat, rstd, gamma, partials, *, dy2=None, dres=None, dx=None, p_drop=0.0, seed=0) -> int:

@@ -15,7 +15,7 @@
  * library is loaded; there are no tuning setters.  The only process-wide controls left are documented where they are declared:
  * the dropout nonce registration (icka_set_dropout_nonce), the error words of the persistent kernels
  * (icka_lstm_clear_error, icka_dp_clear_error), the CU reservation beside RCCL (icka_lstm_set_reserved_cus) and the test hooks
- * of the give-up paths (icka_lstm_test_hooks).
+ * of the give-up paths (icka_lstm_test_hooks, icka_gemm_ln_test_hooks).
  */
 #ifndef ICKA_HIP_H
 #define ICKA_HIP_H
@@ -43,7 +43,7 @@ extern "C" {
  * 6: round 5 -- every tuning setter is GONE (icka_gemm_set_*, icka_ln_set_rows_per_wave, icka_attn_set_whole_head,
  *    icka_lstm_set_persistent / _handoff / _batch_split): icka_gemm_desc grew `tune`; icka_attn_fwd_ex's `fp8` argument became
  *    `flags`; icka_attn_bwd, icka_lstm_fwd and icka_lstm_bwd take `flags`; the 256x256-tile and persistent 12-wave GEMM kernels
- *    those setters switched on left the library (profiles/NEGATIVE_RESULTS.md); icka_gemm_ln, icka_gemm_ln_sync_words (additive). */
+ *    those setters switched on left the library (profiles/NEGATIVE_RESULTS.md); icka_gemm_ln, icka_gemm_ln_sync_words, icka_gemm_ln_test_hooks (additive). */
 #define ICKA_ABI_VERSION 6
 int icka_abi_version(void);
 const char* icka_build_arch(void);
@@ -173,15 +173,22 @@ int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias,
  * 2 fp16; ldr), gamma / beta f32 [N], y bf16 [M, N] (ldy), y_twin contiguous f32 (twin_f16 = 0) or fp16 (1) or NULL, xhat
  * bf16 contiguous and rstd f32 [M] or NULL.  Results are BITWISE those of the two calls.
  * Eligible shapes: the aligned fast path with eight column tiles per 128-row stripe (N = 768 or 1024), M / 128 a multiple of 8
- * and M / 128 * 8 blocks <= the device's CUs (the 8 blocks of a stripe wait for each other: all must be resident; M = 4096 on a
- * whole MI355X).  Anything else returns ICKA_E_SHAPE and launches nothing: the caller takes the two calls.
+ * (the 8 blocks of a stripe wait for each other: all must be resident; M = 4096 on a whole MI355X).  Anything else returns
+ * ICKA_E_SHAPE and launches nothing: the caller takes the two calls.
+ * and M / 128 * 8 blocks <= the device's CUs MINUS the caller's reserve (icka_lstm_set_reserved_cus: dp.GradReducer reserves
+ * the CUs RCCL's workgroups may hold, so the fused form is not taken beside a collective).
  * sync_words: icka_gemm_ln_sync_words() 32-bit words of device memory, zero before the first use; every launch leaves them
- * zero again (the counters reset themselves), so one buffer serves all fused launches of a stream.  Its LAST 16 words are the
- * error word: a stripe wait that gave up (bounded spin: never a hang) stores 1 there and the launch's outputs are invalid. */
+ * zero again (the counters reset themselves, also after a failed launch), so one buffer serves all fused launches of a stream.
+ * error_word: one 32-bit word the device can write -- HOST-MAPPED memory if the host wants to poll it without a device
+ * synchronisation (icka_amd/kernels.py keeps a pinned word).  A stripe wait that gave up (bounded spin, ~7 ms: never a hang)
+ * stores 1 there and turns the rows it finished into NaN: a failed launch never passes for a result.
+ * icka_gemm_ln_test_hooks (tests of that path): polls > 0 replaces the poll budget (0 restores it); drop_block >= 0 makes
+ * that block never arrive, so its stripe's waits give up (-1: off). */
 int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const void* residual, int64_t ldr, int32_t res_kind,
                  const float* gamma, const float* beta, void* y, int64_t ldy, void* y_twin, int32_t twin_f16, void* xhat,
-                 float* rstd, float eps, float p_drop, uint64_t seed, uint32_t* sync_words, void* stream);
+                 float* rstd, float eps, float p_drop, uint64_t seed, uint32_t* sync_words, uint32_t* error_word, void* stream);
 int64_t icka_gemm_ln_sync_words(void);
+int icka_gemm_ln_test_hooks(int32_t polls, int32_t drop_block);
 /* "mixed16" form of the same call: x_kind / res_kind are 0 = bf16, 1 = f32, 2 = fp16, and the twin copy of the output is
  * fp16 (y_f16, contiguous, saturating at +-65504): it is both the fp16 MFMA operand of the next forward GEMM and the
  * residual input of the next block, while y (bf16) stays the operand of the bf16 weight-gradient GEMM in backward. */

@@ -745,10 +745,47 @@ def test_gemm_ln_one_launch_equals_the_two_launches_bitwise(M, N, K, p, res_dtyp
         assert torch.equal(o1, o0) and torch.equal(y1, y0) and torch.equal(xh1, xh0) and torch.equal(rs1, rs0), rep
         if twin is not None:
             assert torch.equal(t1, t0)
-        assert k.gemm_ln_error(sync) == 0 and int(sync[:-16].abs().sum().item()) == 0      # counters back at zero
+        k.gemm_ln_check_error("test")                                      # no stripe wait gave up
+        assert int(sync.abs().sum().item()) == 0                           # counters back at zero
     # outside the domain: not 8 column tiles / stripes not in groups of 8 / more blocks than CUs -> False, nothing launched
     for (m2, n2) in ((4096, 2304), (512, 768), (8192, 768)):
         o = torch.zeros(m2, n2, dtype=F32, device="cuda")
         assert not k.gemm_ln(rnd(m2, K, seed=7), rnd(n2, K, seed=8), o, None, None, rnd(n2, seed=9, dtype=F32), rnd(n2, seed=10, dtype=F32),
                              torch.empty(m2, n2, dtype=BF16, device="cuda"), sync)
         assert o.abs().sum().item() == 0.0
+
+
+def test_gemm_ln_stripe_wait_that_gives_up_is_never_silent(request):
+    """The blocks of a 128-row stripe wait for each other inside icka_gemm_ln: if one never arrives (test hook: block 5 skips
+    its arrival; small poll budget) the waits of that stripe give up -- bounded, no hang --, the rows finished from the
+    incomplete stripe are NaN, the pinned error word makes the NEXT host touch-point raise, the counters are back at zero, and
+    the next launch is healthy again.  (The two-launch path, icka_gemm + icka_ln_fwd, cannot fail this way; this is the price
+    of the seam inside the launch.)"""
+    k = _k()
+    lib = k._lib.load()
+    request.addfinalizer(lambda: lib.icka_gemm_ln_test_hooks(0, -1))
+    M, N, K = 4096, 768, 768
+    h, w = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5)
+    bias, gamma, beta = rnd(N, seed=3, dtype=F32), rnd(N, seed=4, dtype=F32) + 1.0, rnd(N, seed=5, dtype=F32)
+    res = rnd(M, N, seed=6, dtype=F32)
+    sync = k.gemm_ln_sync("cuda")
+    o, y = torch.empty(M, N, dtype=F32, device="cuda"), torch.empty(M, N, dtype=BF16, device="cuda")
+    assert k.gemm_ln(h, w, o, bias, res, gamma, beta, y, sync)
+    torch.cuda.synchronize()
+    good = y.clone()
+    k.gemm_ln_check_error("healthy launch")
+    lib.icka_gemm_ln_test_hooks(2000, 5)
+    y.zero_()
+    assert k.gemm_ln(h, w, o, bias, res, gamma, beta, y, sync)
+    lib.icka_gemm_ln_test_hooks(0, -1)
+    torch.cuda.synchronize()
+    bad_rows = torch.isnan(y.float()).any(1)
+    assert int(bad_rows.sum()) == 128                                       # exactly the stripe of the block that never arrived
+    assert torch.equal(y[~bad_rows], good[~bad_rows])                       # every other stripe is complete and correct
+    assert int(sync.abs().sum().item()) == 0                                # the counters reset themselves after the failure too
+    with pytest.raises(k.GemmLnHandoffError):
+        k.gemm_ln(h, w, o, bias, res, gamma, beta, y, sync)                 # next host touch-point raises (and clears the word)
+    assert k.gemm_ln(h, w, o, bias, res, gamma, beta, y, sync)
+    torch.cuda.synchronize()
+    assert torch.equal(y, good)
+    k.gemm_ln_check_error("after recovery")

@@ -38,4 +38,5 @@ for rep in range(3):
         print("rep %d %-5s launched %s  mismatches %8d  nan %8d  rows %s..%s (%d)  cols %s..%s (%d)  max|d| %.3e" % (
             rep, name, ok, int(bad.sum()), int(a.isnan().sum()), rows[:1].tolist(), rows[-1:].tolist(), rows.numel(),
             cols[:1].tolist(), cols[-1:].tolist(), cols.numel(), float((a - b).nan_to_num().abs().max())))
-    print("   error word", k.gemm_ln_error(sync), "counter residue", int(sync[:-16].abs().sum()))
+    k.gemm_ln_check_error("debug")
+    print("   counter residue", int(sync.abs().sum()))
