@@ -700,6 +700,7 @@ def main():
         arena.reducer = reducer
         torch.cuda.synchronize()
         flops, ms, launches, abytes = K.profile_gemm(False, reps=nprof)
+        fused = K.last_fused_profile
         traffic, traffic_src = None, None
         tpath = None
         for tag in ("r05", "r04", "r03", "r02", "r01"):      # the newest committed PMC passes
@@ -729,15 +730,24 @@ def main():
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma",
-                    "kernel": "all GEMM launches of a step: gemm_ws_kernel / gemm_ws2_kernel (128x128, 128x96 tiles), "
+                    "kernel": "the GEMM launches of a step: gemm_ws_kernel / gemm_ws2_kernel (128x128, 128x96 tiles), "
                               "gemm_w3_kernel (256x192), gemm_big_group_kernel (grouped weight gradients, 256x128), "
-                              "gemm_kernel (ragged shapes); NT / NN / TN, bf16 MFMA 16x16x32",
+                              "gemm_kernel (ragged shapes); NT / NN / TN, bf16 MFMA 16x16x32 (the dense GEMMs fused with their "
+                              "LayerNorm, gemm_ln_kernel, are listed under fused_dense_ln)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "mfma_busy": mfma_busy, "algorithmic_bytes_per_launch": round(abytes / launches),
                     "algorithmic_flop_per_launch": round(flops / launches),
                     "launches_per_step": launches // nprof, "avg_launch_us": round(1e3 * ms / launches, 2),
                     "gemm_ms_per_step": round(ms / nprof, 3),
+                    # the dense GEMMs whose LayerNorm runs inside the same launch (gemm_ln_kernel: the 128x96 / 128x128 tile body
+                    # + a stripe hand-off + the row phase) are timed in a bracket of their own -- their duration contains the
+                    # HBM-bound LayerNorm phase -- and are NOT part of achieved / frac above
+                    "fused_dense_ln": None if not fused else {
+                        "launches_per_step": fused["launches"] // nprof, "avg_launch_us": round(1e3 * fused["ms"] / fused["launches"], 2),
+                        "gemm_flop_per_launch": round(fused["flops"] / fused["launches"]),
+                        "ms_per_step": round(fused["ms"] / nprof, 3),
+                        "gemm_tflops_incl_layernorm_phase": round(fused["flops"] / (fused["ms"] * 1e-3) / 1e12, 2)},
                     "whole_step_tflops": round(samples_per_s / world * fl_sample / 1e12, 2),
                     "whole_step_frac": round(samples_per_s / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS, 4)}
 

@@ -1,6 +1,6 @@
 # MFMA-busy / MOPS / HBM-side counter passes over the eager bench step (run on the GPU box through gpurun).
 # usage: bash tools/profile_mfma.sh <tag> <config>     -> gpurun_out/prof_<tag>/<config>_mfma_busy.json
-TAG=${1:-r04}
+TAG=${1:-r05}
 CFG=${2:-c2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

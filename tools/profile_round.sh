@@ -1,7 +1,7 @@
 # (profiled runs skip the optimizer leg: its ATen kernels are not part of the step)
 # Round profile set (run on the GPU box through gpurun): kernel stats of the default bench, the c4 / c5 presets, and the
 # two PMC passes behind roofline.traffic.  Outputs under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +13,15 @@ python3 $GRAFT_REPO_ROOT/bench.py --config c5 --steps 50 > $OUT/bench_c5.jsonl 2
 # the other arithmetic mode of each: c2 in mixed16, c4 in pure bf16 (no CPU leg)
 python3 $GRAFT_REPO_ROOT/bench.py --precision mixed16 --no-cpu-baseline > $OUT/bench_c2_mixed16.jsonl 2>> $OUT/c2.err
 python3 $GRAFT_REPO_ROOT/bench.py --config c4 --precision bf16 --steps 30 --no-cpu-baseline > $OUT/bench_c4_bf16.jsonl 2>> $OUT/c4.err
+# SURVEY section 8(f) rows at this commit, each with its algorithmic FLOP and fraction of the bf16 MFMA peak
+python3 $GRAFT_REPO_ROOT/tools/tail_bench.py > $OUT/tail_gate1_bench.jsonl 2> $OUT/tail.err
+python3 $GRAFT_REPO_ROOT/tools/tail_bench.py --with-encoder >> $OUT/tail_gate1_bench.jsonl 2>> $OUT/tail.err
+python3 $GRAFT_REPO_ROOT/tools/cross_modal_bench.py > $OUT/cross_modal_bench.jsonl 2> $OUT/cross_modal.err
+python3 $GRAFT_REPO_ROOT/tools/resnet_bench.py > $OUT/resnet_bench.jsonl 2> $OUT/resnet.err
+python3 $GRAFT_REPO_ROOT/tools/lstm_bench.py > $OUT/lstm_bench.txt 2> $OUT/lstm.err
+# the kernels of one replayed c2 step in order
+rocprofv3 --kernel-trace --output-format csv -d $OUT/seq -o seq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --repeats 1 --no-cpu-baseline --no-roofline --no-eager-leg --no-optimizer-leg > /dev/null 2> $OUT/seq.err
+python3 $GRAFT_REPO_ROOT/tools/step_sequence.py $(find $OUT/seq -name "*kernel_trace.csv" | head -1) > $OUT/c2_step_sequence.txt 2>> $OUT/seq.err
 # counter passes: MFMA busy / MOPS / FETCH_SIZE / WRITE_SIZE per kernel (c2 also yields gemm_traffic.json), c2 and c4
 bash $GRAFT_REPO_ROOT/tools/profile_mfma.sh $TAG c2
 bash $GRAFT_REPO_ROOT/tools/profile_mfma.sh $TAG c4
