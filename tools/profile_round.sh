@@ -22,9 +22,8 @@ python3 $GRAFT_REPO_ROOT/tools/lstm_bench.py > $OUT/lstm_bench.txt 2> $OUT/lstm.
 # the kernels of one replayed c2 step in order
 rocprofv3 --kernel-trace --output-format csv -d $OUT/seq -o seq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --repeats 1 --no-cpu-baseline --no-roofline --no-eager-leg --no-optimizer-leg > /dev/null 2> $OUT/seq.err
 python3 $GRAFT_REPO_ROOT/tools/step_sequence.py $(find $OUT/seq -name "*kernel_trace.csv" | head -1) > $OUT/c2_step_sequence.txt 2>> $OUT/seq.err
-# counter passes: MFMA busy / MOPS / FETCH_SIZE / WRITE_SIZE per kernel (c2 also yields gemm_traffic.json), c2 and c4
-bash $GRAFT_REPO_ROOT/tools/profile_mfma.sh $TAG c2
-bash $GRAFT_REPO_ROOT/tools/profile_mfma.sh $TAG c4
+# counter passes (MFMA busy / MOPS / FETCH_SIZE / WRITE_SIZE per kernel; c2 also yields gemm_traffic.json): a gpurun call of
+# their own -- bash tools/profile_mfma.sh $TAG c2 && bash tools/profile_mfma.sh $TAG c4 -- the whole set exceeds one call's limit
 cd $GRAFT_REPO_ROOT
 # keep the merge-back small: stats + bench lines + traffic json only
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
