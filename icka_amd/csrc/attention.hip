@@ -861,11 +861,12 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
                 const float pv = __expf(sc[r] * a.scale + mkv[r] - lse_q);   // mask -inf (key >= Skv) -> exactly 0
                 float dm;
                 if constexpr (DROP_BITS) {
-                    // bit -> all-ones / zero by ONE signed bit-field extract (the position is a compile-time constant of the
-                    // unrolled loops), AND with the bits of 1 / (1 - p): two vector operations per element where shift, and,
-                    // compare and select took ~4 (profiles/r04_attn_bwd_stamps.txt: 7.9 k of phase A's 49 k cycles at c4)
+                    // (a sign-extending bit-field extract + AND with the bits of 1 / (1 - p) -- two operations instead of shift,
+                    //  and, compare, select -- was built in round 5 on the strength of profiles/r04_attn_bwd_stamps.txt: at the
+                    //  512-register cap of this instance it cost 305 spilled registers instead of 12 and the launch went from
+                    //  95.7 to 153.3 us: profiles/NEGATIVE_RESULTS.md)
                     const int bit = (qi * KT + kt) * 4 + r;
-                    dm = __uint_as_float(__float_as_uint(a.drop.scale) & (uint32_t)__builtin_amdgcn_sbfe((int)dbits[bit >> 5], bit & 31, 1));
+                    dm = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? a.drop.scale : 0.f;
                 } else {
                     dm = dm4[r];
                 }
@@ -950,8 +951,7 @@ __global__ __launch_bounds__(256, (QT * KT >= 36 || QT >= 4 ? 1 : 2)) void attn_
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int bit = (qi * KT + kt) * 4 + r;
-                                pd4[r] = bf2f(pb[r]) * __uint_as_float(__float_as_uint(a.drop.scale) &
-                                                                       (uint32_t)__builtin_amdgcn_sbfe((int)dbits[bit >> 5], bit & 31, 1));
+                                pd4[r] = ((dbits[bit >> 5] >> (bit & 31)) & 1u) ? bf2f(pb[r]) * a.drop.scale : 0.f;
                             }
                             val = pack4(pd4[0], pd4[1], pd4[2], pd4[3]);
                         }
