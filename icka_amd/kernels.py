@@ -362,13 +362,19 @@ class GemmLnHandoffError(RuntimeError):
 
 
 _GEMM_LN_ERR = None      # one pinned (host-mapped) error word for the process: polled by the host without a device sync
+_GEMM_LN_ERR_NP = None   # numpy view of it (a host read through it costs ~0.1 us: it sits in front of every fused launch)
+_GEMM_LN_ERR_PTR = 0
 
 
-def _gemm_ln_err_word() -> torch.Tensor:
-    global _GEMM_LN_ERR
+def _gemm_ln_err_word() -> int:
+    """Device-visible address of the pinned error word (allocated on first use: never under stream capture -- a model's first
+    forward, and every capture's warm-up, run eagerly)."""
+    global _GEMM_LN_ERR, _GEMM_LN_ERR_NP, _GEMM_LN_ERR_PTR
     if _GEMM_LN_ERR is None:
         _GEMM_LN_ERR = torch.zeros(16, dtype=torch.int32).pin_memory()
-    return _GEMM_LN_ERR
+        _GEMM_LN_ERR_NP = _GEMM_LN_ERR.numpy()
+        _GEMM_LN_ERR_PTR = _GEMM_LN_ERR.data_ptr()
+    return _GEMM_LN_ERR_PTR
 
 
 def gemm_ln_sync(device) -> torch.Tensor:
@@ -394,7 +400,7 @@ def gemm_ln(h, w, o, bias, residual, gamma, beta, y, sync, *, y_f32=None, y_f16=
         raise ValueError("twin output must be contiguous [M,N] f32 (y_f32) / fp16 (y_f16)")
     args = (d, _ptr(bias), _ptr(residual), _ld(residual), 0 if residual is None else _kind(residual), gamma.data_ptr(),
             beta.data_ptr(), y.data_ptr(), y.stride(0), _ptr(twin), int(y_f16 is not None), _ptr(xhat), _ptr(rstd), eps,
-            p_drop, seed, sync.data_ptr(), _gemm_ln_err_word().data_ptr(), _stream())
+            p_drop, seed, sync.data_ptr(), _gemm_ln_err_word(), _stream())
     rc = lib.icka_gemm_ln(*args)
     if rc == -1:        # ICKA_E_SHAPE: not a shape of the fused kernel
         return False
@@ -409,8 +415,8 @@ def gemm_ln_check_error(where: str = "") -> None:
     """Raise if a fused dense + LayerNorm launch ever reported a stripe wait that gave up.  The word is pinned host memory the
     kernel writes with a system-scope store: the check is a plain host read, no device synchronisation, so it runs at every host
     touch-point (the next fused launch, GraphedStep / GraphedModule replays).  The word is cleared when the error is raised."""
-    if _GEMM_LN_ERR is not None and int(_GEMM_LN_ERR[0]) != 0:
-        _GEMM_LN_ERR[0] = 0
+    if _GEMM_LN_ERR_NP is not None and _GEMM_LN_ERR_NP[0] != 0:
+        _GEMM_LN_ERR_NP[0] = 0
         raise GemmLnHandoffError(
             "icka_amd fused dense + LayerNorm%s: a block gave up waiting for the other blocks of its 128-row stripe -- the grid "
             "was not co-resident (another kernel held CUs: a collective on another stream, a second model, a partitioned GPU).  "
