@@ -380,6 +380,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path in icka_amd)")
     if os.environ.get("ICKA_BENCH_ONE_GPU"):   # rehearsal of the N > 1 flow on a one-GPU box (with ICKA_BENCH_BACKEND=gloo)
         local_rank = 0
+        # several ranks share the card: launches whose blocks wait for each other inside the kernel (icka_gemm_ln) cannot
+        # count on the whole chip -- from the very first step on, before any reducer has reserved CUs
+        from icka_amd import ops as _ops
+        _ops.FUSE_DENSE_LN = False
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist

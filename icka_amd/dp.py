@@ -196,7 +196,9 @@ class GradReducer(object):
         # persistent BiLSTM grids must stay co-resident beside RCCL's workgroups: reserve CUs for as long as this reducer
         # lives (close() / __del__ restore what was reserved before)
         self._prev_reserved = None
-        if (self.is_cuda and self.backend == "nccl" and self.world > 1) or lstm_reserved_cus is not None:
+        # (any backend: over gloo the ranks of a test or rehearsal usually SHARE one card, where launches whose blocks wait for each
+        #  other -- the persistent BiLSTM, the fused dense + LayerNorm -- can no longer count on the whole chip either)
+        if (self.is_cuda and self.world > 1) or lstm_reserved_cus is not None:
             from . import kernels as K
             self._prev_reserved = K.lstm_set_reserved_cus(LSTM_RESERVED_CUS if lstm_reserved_cus is None else lstm_reserved_cus)
 
