@@ -1228,9 +1228,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs gp) {
 // =====================================================================================================================
 // dense -> bias + dropout + residual -> LayerNorm in ONE launch (BertSelfOutput.forward Cross_Modal_Interaction_Module.py:
 // 561-565, BertOutput.forward :532-536): the 128 x BNT NT kernel above for shapes whose tile grid is one block per CU with
-// EIGHT column tiles per 128-row stripe (N = 768 with 96-wide tiles, N = 1024 with 128-wide ones; M / 128 stripes, a multiple
-// of 8, at most one block per CU).  tile_origin puts the 8 blocks of a stripe on one XCD (blocks b, b + 8, ... share an XCD
-// under the observed round-robin dispatch -- a speed property only, nothing below depends on it).
+// EIGHT column tiles per 128-row stripe (N = 768 with 96-wide tiles, N = 1024 with 128-wide ones; M / 128 stripes, at most one
+// block per CU).  Where M / 128 is a multiple of 8, tile_origin puts the 8 blocks of a stripe on one XCD (blocks b, b + 8, ...
+// share an XCD under the observed round-robin dispatch) -- a speed property only, nothing below depends on it: with other stripe
+// counts (the reference's test loop at batch 4: M = 512) a stripe spreads over two or three XCDs and the hand-off still holds.
 //   phase 1  the tile's f32 output is stored write-through (sc1) into the usual GEMM -> LayerNorm intermediate;
 //   seam     every wave waits for its stores (s_waitcnt vmcnt(0)), the block barrier joins them, ONE lane adds 1 to the stripe's
 //            arrival counter (agent scope) and polls it (sc1 load, bounded) until all 8 blocks of the stripe have arrived;
@@ -1845,7 +1846,9 @@ extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const vo
         return ICKA_E_SHAPE;
     const int bnt = (g.N % 96 == 0 && g.N / 96 == 8) ? 96 : ((g.N % 128 == 0 && g.N / 128 == 8) ? 128 : 0);
     const int stripes = g.M / BM;
-    if (!bnt || stripes % 8 != 0 || stripes > GEMM_LN_MAX_STRIPES || stripes * 8 > device_cus() - g_icka_reserved_cus) return ICKA_E_SHAPE;
+    // (any number of stripes: where M / 128 is not a multiple of 8 a stripe's blocks spread over two or three XCDs -- the hand-off
+    //  is write-through stores + agent-scope counter + L1-bypassing loads, correct under any placement, a little slower there)
+    if (!bnt || stripes < 1 || stripes > GEMM_LN_MAX_STRIPES || stripes * 8 > device_cus() - g_icka_reserved_cus) return ICKA_E_SHAPE;
     if (g.N % 8 || ldy % 8 || (residual && ldr % 8) || g.ldc % 4) return ICKA_E_ALIGN;
     if ((int64_t)g.M * g.ldc * 4 >= (1ll << 31) - 64) return ICKA_E_SHAPE;      // 32-bit byte offsets of the raw buffer accesses
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

@@ -172,9 +172,9 @@ int icka_ln_fwd(const void* x, int64_t ldx, int32_t x_is_f32, const float* bias,
  * icka_ln_fwd).  The remaining arguments are icka_ln_fwd's (x = d->C): residual [M, N] of kind res_kind (0 bf16, 1 f32,
  * 2 fp16; ldr), gamma / beta f32 [N], y bf16 [M, N] (ldy), y_twin contiguous f32 (twin_f16 = 0) or fp16 (1) or NULL, xhat
  * bf16 contiguous and rstd f32 [M] or NULL.  Results are BITWISE those of the two calls.
- * Eligible shapes: the aligned fast path with eight column tiles per 128-row stripe (N = 768 or 1024), M / 128 a multiple of 8
- * (the 8 blocks of a stripe wait for each other: all must be resident; M = 4096 on a whole MI355X).  Anything else returns
- * ICKA_E_SHAPE and launches nothing: the caller takes the two calls.
+ * Eligible shapes: the aligned fast path (M % 128 == 0) with eight column tiles per 128-row stripe (N = 768 or 1024) and at most
+ * one block per CU (the 8 blocks of a stripe wait for each other: all must be resident; M <= 4096 on a whole MI355X).  Anything
+ * else returns ICKA_E_SHAPE and launches nothing: the caller takes the two calls.
  * and M / 128 * 8 blocks <= the device's CUs MINUS the caller's reserve (icka_lstm_set_reserved_cus: dp.GradReducer reserves
  * the CUs RCCL's workgroups may hold, so the fused form is not taken beside a collective).
  * sync_words: icka_gemm_ln_sync_words() 32-bit words of device memory, zero before the first use; every launch leaves them

@@ -711,7 +711,11 @@ def test_embed_bwd_rows_plus_scatter_equals_embed_bwd():
 
 @pytest.mark.parametrize("M,N,K,p,res_dtype,twin", [(4096, 768, 768, 0.1, F32, "f32"), (4096, 768, 3072, 0.0, F32, "f32"),
                                                     (1024, 768, 768, 0.1, BF16, None), (4096, 1024, 1024, 0.1, F32, "f32"),
-                                                    (2048, 1024, 4096, 0.0, torch.float16, "f16")])
+                                                    (2048, 1024, 4096, 0.0, torch.float16, "f16"),
+                                                    # stripe counts that are not multiples of 8: a stripe's 8 blocks spread over
+                                                    # several XCDs (M = 512 is the reference's test loop at batch 4)
+                                                    (512, 768, 768, 0.1, F32, "f32"), (384, 768, 3072, 0.1, F32, "f32"),
+                                                    (128, 1024, 1024, 0.0, F32, None), (3200, 768, 768, 0.1, F32, "f32")])
 def test_gemm_ln_one_launch_equals_the_two_launches_bitwise(M, N, K, p, res_dtype, twin):
     """icka_gemm_ln (dense -> bias + dropout + residual -> LayerNorm in ONE launch: the 8 blocks of a 128-row stripe meet at an
     arrival counter, then finish 16 rows each through the row body shared with ln_fwd_kernel) == icka_gemm + icka_ln_fwd, BITWISE:
@@ -747,8 +751,8 @@ def test_gemm_ln_one_launch_equals_the_two_launches_bitwise(M, N, K, p, res_dtyp
             assert torch.equal(t1, t0)
         k.gemm_ln_check_error("test")                                      # no stripe wait gave up
         assert int(sync.abs().sum().item()) == 0                           # counters back at zero
-    # outside the domain: not 8 column tiles / stripes not in groups of 8 / more blocks than CUs -> False, nothing launched
-    for (m2, n2) in ((4096, 2304), (512, 768), (8192, 768)):
+    # outside the domain: not 8 column tiles / rows not in whole 128-row stripes / more blocks than CUs -> False, nothing launched
+    for (m2, n2) in ((4096, 2304), (200, 768), (8192, 768)):
         o = torch.zeros(m2, n2, dtype=F32, device="cuda")
         assert not k.gemm_ln(rnd(m2, K, seed=7), rnd(n2, K, seed=8), o, None, None, rnd(n2, seed=9, dtype=F32), rnd(n2, seed=10, dtype=F32),
                              torch.empty(m2, n2, dtype=BF16, device="cuda"), sync)
