@@ -29,6 +29,10 @@ ATTN_KEEPBITS = _os.environ.get("ICKA_ATTN_KEEPBITS", "auto")
 # dense -> bias + dropout + residual -> LayerNorm as ONE launch where the shape allows it (icka_gemm_ln: one 128-row block per CU;
 # bitwise the two launches).  "0" keeps the two launches everywhere (same-box A/B: tools/ab_env.sh).
 FUSE_DENSE_LN = _os.environ.get("ICKA_FUSE_DENSE_LN", "1") != "0"
+# ... from this many rows on: the fused launch has M / 128 * 8 blocks and its LayerNorm phase runs on exactly those CUs, where the row
+# kernel spreads the same rows over the whole chip -- at M = 512 (the reference's test loop at batch 4: 32 blocks) the replayed
+# forward is 7 % SLOWER with it (1.25 vs 1.17 ms, profiles/r05_gemm_ln_ab.txt); it pays when the GEMM's grid fills the chip
+FUSE_DENSE_LN_MIN_ROWS = 3072
 
 
 def _keepbits_on(Sq: int, Skv: int) -> bool:
@@ -290,9 +294,9 @@ def _dense_norm_fwd(A: ParamArena, mod, h, res, d: Dims, save: bool, h16=None):
     rstd = _empty(h, M, dtype=F32) if save else None
     seed_h = A.next_seed() if d.p_hidden > 0 else 0
     twin = {"y_f16": yf} if d.h16 else {"y_f32": yf}
-    if FUSE_DENSE_LN and h16 is None:
+    if FUSE_DENSE_LN and h16 is None and M >= FUSE_DENSE_LN_MIN_ROWS:
         # one launch: the GEMM's blocks finish the rows of their own stripe (icka_gemm_ln; bitwise the two launches below);
-        # shapes the fused kernel does not take (anything but one 128-row block per CU: M = 4096 on MI355X) return False
+        # shapes the fused kernel does not take (more than one 128-row block per CU: M > 4096 on MI355X) return False
         sync = A._ws.get("gemm_ln_sync")
         if sync is None:
             sync = A._ws["gemm_ln_sync"] = K.gemm_ln_sync(h.device)
