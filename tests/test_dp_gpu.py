@@ -195,6 +195,31 @@ def test_two_ranks_with_the_row_sparse_word_embedding_exchange(tmp_path, comm, b
         assert res["sparse_stats"]["sparse"] >= 2 and res["worst"] < bar, res
 
 
+def test_two_ranks_sparse_reducer_with_the_fp32_exact_embedding_backward(tmp_path):
+    """GradReducer(sparse_embeddings=True) under the fp32-exact mode, whose embedding backward does not know
+    the row path and scatters DENSELY into the word table's slot: the reducer must notice the dense write and average the slot
+    (before round 5 every rank silently kept its local word gradient).  2 ranks x half batch == 1 rank x full batch, the word
+    table among the compared tensors."""
+    port = str(_free_port())
+    outs = [str(tmp_path / ("r%d.pt" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), "2", port, outs[r], "fp32", "f32", "sparse"])
+             for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r in range(2):
+        res = torch.load(outs[r])
+        print("\n[dp 2-rank, sparse reducer, fp32-exact mode, rank %d] worst gradient rel-L2 vs single-rank full batch %.3e at %s; %s"
+              % (r, res["worst"], res["key"], res["sparse_stats"]))
+        assert res["sparse_word"] == "bert.embeddings.word_embeddings.weight", res
+        assert res["sparse_stats"].get("dense_slot", 0) >= 2 and res["sparse_stats"]["sparse"] == 0, res
+        assert res["worst"] < 1e-5, res
+
+
 @pytest.mark.parametrize("kind", ["flagged", "segmented"])
 def test_graphed_step_with_the_row_sparse_exchange_matches_eager(tmp_path, kind):
     """The row-sparse exchange behind a captured step (world 1 over RCCL): the captured embedding backward fills static row / id
