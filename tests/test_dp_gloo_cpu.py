@@ -422,3 +422,26 @@ def test_sparse_reducer_averages_a_densely_written_word_table_and_refuses_ragged
             assert abs(res["word_mean_%d" % step] - 1.5) < 1e-6 and abs(res["lin_mean_%d" % step] - 1.5) < 1e-6, res
         assert res["stats"].get("dense_slot", 0) >= 2, res
         assert res["pending_raises"] and res["ragged_raises"], res
+
+
+def _late_rank_worker(rank, world, port, tmp):
+    """A rank that never reaches an agreement point must not hang the others: all_ranks_gather raises on them after its timeout."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from icka_amd.dp import all_ranks_gather
+    out = {"raised": None}
+    if rank == 0:
+        try:
+            all_ranks_gather(True, what="a vote rank 1 skips", timeout=3.0)
+            out["raised"] = False
+        except RuntimeError as e:
+            out["raised"] = "not every rank reached the agreement point" in str(e)
+    torch.save(out, os.path.join(tmp, "q%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_never_votes_times_the_others_out_instead_of_hanging_them(tmp_path):
+    mp.spawn(_late_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "q0.pt"))["raised"] is True
