@@ -704,7 +704,7 @@ def main():
         arena.reducer = reducer
         torch.cuda.synchronize()
         flops, ms, launches, abytes = K.profile_gemm(False, reps=nprof)
-        fused = K.last_fused_profile
+        fused, fused_qa = K.last_fused_profile, K.last_fused_qkv_profile
         traffic, traffic_src = None, None
         tpath = None
         for tag in ("r05", "r04", "r03", "r02", "r01"):      # the newest committed PMC passes
@@ -737,7 +737,8 @@ def main():
                     "kernel": "the GEMM launches of a step: gemm_ws_kernel / gemm_ws2_kernel (128x128, 128x96 tiles), "
                               "gemm_w3_kernel (256x192), gemm_big_group_kernel (grouped weight gradients, 256x128), "
                               "gemm_kernel (ragged shapes); NT / NN / TN, bf16 MFMA 16x16x32 (the dense GEMMs fused with their "
-                              "LayerNorm, gemm_ln_kernel, are listed under fused_dense_ln)",
+                              "LayerNorm, gemm_ln_kernel, and the QKV projections fused with their attention, gemm_qkv_attn_kernel, are listed "
+                              "under fused_dense_ln / fused_qkv_attn)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src, "mfma_busy": mfma_busy, "algorithmic_bytes_per_launch": round(abytes / launches),
@@ -752,6 +753,14 @@ def main():
                         "gemm_flop_per_launch": round(fused["flops"] / fused["launches"]),
                         "ms_per_step": round(fused["ms"] / nprof, 3),
                         "gemm_tflops_incl_layernorm_phase": round(fused["flops"] / (fused["ms"] * 1e-3) / 1e12, 2)},
+                    # the QKV projections whose self-attention runs inside the same launch (gemm_qkv_attn_kernel: the 256x192
+                    # tile body, then the whole-head attention of the tile's two samples x one head from LDS); GEMM FLOPs only
+                    "fused_qkv_attn": None if not fused_qa else {
+                        "launches_per_step": fused_qa["launches"] // nprof,
+                        "avg_launch_us": round(1e3 * fused_qa["ms"] / fused_qa["launches"], 2),
+                        "gemm_flop_per_launch": round(fused_qa["flops"] / fused_qa["launches"]),
+                        "ms_per_step": round(fused_qa["ms"] / nprof, 3),
+                        "gemm_tflops_incl_attention_phase": round(fused_qa["flops"] / (fused_qa["ms"] * 1e-3) / 1e12, 2)},
                     "whole_step_tflops": round(samples_per_s / world * fl_sample / 1e12, 2),
                     "whole_step_frac": round(samples_per_s / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS, 4)}
 

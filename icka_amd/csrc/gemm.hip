@@ -19,6 +19,7 @@
 // LDS images are XOR-swizzled per layout (off_kc / off_km), the swizzle applied to the DMA source address.
 #include "common.h"
 #include "ln_row.h"
+#include "attn_core.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -1540,6 +1541,149 @@ __global__ __launch_bounds__(768) void gemm_w3_kernel(const GemmArgs gp) {
     }
 }
 
+// =====================================================================================================================
+// QKV projection + self-attention of a head in ONE launch (sequence length 128, head size 64 -- the reference's
+// max_seq_length 128 text: BertSelfAttention.forward, Cross_Modal_Interaction_Module.py:478-506).
+// The 12-wave kernel's 256 x 192 tile is laid over the problem so that its 192 columns are the 64 query, 64 key and 64 value
+// columns of ONE head (B rows head*64 .. +63 of each of the three stacked weight blocks: only the loader's row pointers change)
+// and its 256 rows are TWO samples: after the k-loop the block holds everything the attention of those two (sample, head) pairs
+// needs.  Epilogue: accumulators + bias -> bf16 -> six [128][64] off_t images in the dead operand ring (q, k, v of either sample);
+// then the four loader waves stream the images to the qkv activation (the attention backward and the weight gradient read it
+// later) while the eight compute waves run the whole-head attention forward of attn_core.h straight from the images -- 32 queries
+// per wave -- and store context rows and log-sum-exp.  Same bf16 q / k / v, same device function: bit for bit the result of
+// icka_gemm + icka_attn_fwd, without the attention launch, its 19 MB re-read of qkv and the kernel boundary between them.
+struct QkvAttnArgs { GemmArgs g; AttnArgs a; };
+
+template <int HALF>
+__device__ __forceinline__ void dma_init_qkv(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int head, int H,
+                                             int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave + 4 * j;                 // (piece 3 of a 96-row image is never issued)
+        const int row = (8 * p + (lane >> 3)) % 96;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const int r = 96 * HALF + row;              // tile column 0..191 = [q | k | v] of the head
+        ptr[j] = P + (int64_t)((r >> 6) * H + head * 64 + (r & 63)) * ld + 8 * lc;
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(768) void gemm_qkv_attn_kernel(const QkvAttnArgs p) {
+    const GemmArgs g = p.g;
+    __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(char, smem)));
+    constexpr int BH = 96, NB16 = 6;
+    int m0, n0;
+    w3_origin(blockIdx.x, g.w3_sn, g.w3_pnlog, 192, m0, n0);
+    const int head = n0 / 192, H = g.N / 3;
+    const int nk = g.K / BK;
+    if (wave >= 8) {
+        // loader waves: gemm_w3_kernel's ring (A two k-tiles ahead in a ring of 3, B one ahead in a ring of 2)
+        const int lw = wave - 8;
+        const bf16_t* pa0[4];
+        const bf16_t* pa1[4];
+        const bf16_t* pb0[4];
+        const bf16_t* pb1[4];
+        dma_init<false>(pa0, g.A, g.lda, m0, lw, lane);
+        dma_init<false>(pa1, g.A, g.lda, m0 + 128, lw, lane);
+        dma_init_qkv<0>(pb0, g.B, g.ldb, head, H, lw, lane);
+        dma_init_qkv<1>(pb1, g.B, g.ldb, head, H, lw, lane);
+        const int64_t sa = BK, sb = BK;
+        const uint32_t ldsB = lds0 + W3_NA * W3_A;
+#define ICKA_QA_A(SLOT)                                                          \
+    do {                                                                         \
+        dma_issue(pa0, sa, lds0 + (SLOT) * W3_A + lw * 1024);                    \
+        dma_issue(pa1, sa, lds0 + (SLOT) * W3_A + TILE_BYTES + lw * 1024);       \
+    } while (0)
+#define ICKA_QA_B(SLOT)                                                          \
+    do {                                                                         \
+        dma_issue<3>(pb0, sb, ldsB + (SLOT) * W3_B + lw * 1024);                 \
+        dma_issue<3>(pb1, sb, ldsB + (SLOT) * W3_B + TILE_BYTES + lw * 1024);    \
+    } while (0)
+        ICKA_QA_A(0);
+        ICKA_QA_B(0);
+        if (nk > 1) ICKA_QA_A(1);
+        int sa3 = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) ICKA_QA_B((kt + 1) & 1);
+            if (kt + 2 < nk) ICKA_QA_A(sa3);
+            sa3 = sa3 == 2 ? 0 : sa3 + 1;
+        }
+#undef ICKA_QA_A
+#undef ICKA_QA_B
+    }
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * BH;
+    f32x4 acc[4][NB16];
+    if (wave < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* sA = smem + (kt % W3_NA) * W3_A + (wr >> 7) * TILE_BYTES;
+            const char* sB = smem + W3_NA * W3_A + (kt & 1) * W3_B + (wave & 1) * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[NB16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t] = read_frag<false>(sA, (wr & 127) + 16 * t, ks, lane);
+#pragma unroll
+                for (int t = 0; t < NB16; ++t) fb[t] = read_frag<false>(sB, 16 * t, ks, lane);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NB16; ++ni) acc[mi][ni] = mfma16t<false>(fb[ni], fa[mi], acc[mi][ni]);
+            }
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states
+    }
+    __syncthreads();   // the operand ring is dead: it becomes the six [128][64] bf16 images, image (2 s + ...) = smem + (3 s + mat) * 16 KiB
+    constexpr int IMG = 128 * 128;
+    if (wave < 8) {
+        const int s = wave >> 2;
+#pragma unroll
+        for (int ni = 0; ni < NB16; ++ni) {
+            const int c0 = wc + 16 * ni + 4 * (lane >> 4);   // tile column of this lane's four accumulator columns
+            const int mat = c0 >> 6, cc = c0 & 63;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + mat * H + head * 64 + cc);
+            char* im = smem + (3 * s + mat) * IMG;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = (wr & 127) + 16 * mi + (lane & 15);
+                const f32x4 v = acc[mi][ni] + bv;
+                *reinterpret_cast<u32x2*>(im + off_t(r, cc >> 3) + 8 * ((cc >> 2) & 1)) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave >= 8) {
+        // the qkv activation for the backward: 6 images x 128 rows x 8 chunks of 16 B, 24 per loader thread; a row's 64 columns
+        // (128 B) are contiguous in global memory
+        bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+        const int t = tid - 512;
+#pragma unroll 4
+        for (int i = 0; i < 24; ++i) {
+            const int id = t + 256 * i;
+            const int im = id >> 10, r = (id >> 3) & 127, c = id & 7;
+            const int s = im >= 3 ? 1 : 0, mat = im - 3 * s;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + im * IMG + off_t(r, c));
+            st_main(reinterpret_cast<u32x4*>(C + (int64_t)(m0 + 128 * s + r) * g.ldc + mat * H + head * 64 + 8 * c), v, g.plain);
+        }
+        return;
+    }
+    AttnArgs a = p.a;
+    a.drop = drop_resolve(a.drop);
+    const int s = wave >> 2, b = (m0 >> 7) + s;
+    const char* sQ = smem + 3 * s * IMG;
+    attn_fwd_whole_head<2, 8, DROP, false, false>(a, sQ, sQ + IMG, sQ + 2 * IMG, 2 * (wave & 3), 0, b * a.h + head, b, head, lane);
+}
+
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
 // (forced: Tune::w3grid, where it divides the tile grid)
 static int gemm_w3_grid(int M, int N, int bnw, int forced) {
@@ -1866,6 +2010,46 @@ extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const vo
     hipStream_t st = (hipStream_t)stream;
     if (bnt == 96) hipLaunchKernelGGL((gemm_ln_kernel<96>), dim3(stripes * 8), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_ln_kernel<128>), dim3(stripes * 8), dim3(512), 0, st, p);
+    ICKA_CHECK_LAUNCH();
+    return 0;
+}
+
+// QKV projection + whole-head self-attention in one launch (gemm_qkv_attn_kernel).  d: the NT projection [M, 3 H] = x . Wqkv^T
+// with its bias and a bf16 output (the stacked [q | k | v] activation, written as by icka_gemm); the attention arguments as
+// icka_attn_fwd with Q / K / V = the three column blocks of that output.  ICKA_E_SHAPE = not a shape this launch covers (the
+// caller runs icka_gemm + icka_attn_fwd, which give the same bits): S = 128 tokens per sample, head size 64, an even number
+// of samples, a tile grid of the 12-wave kernel.
+extern "C" int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask, void* ctx, int64_t ldo, float* lse, int32_t B,
+                                  int32_t heads, int32_t S, float scale, float p_drop, uint64_t seed, void* stream) {
+    if (!d || !add_mask || !ctx) return ICKA_E_ARG;
+    if (B <= 0 || heads <= 0 || S <= 0) return ICKA_E_SHAPE;
+    GemmArgs g;
+    Tune t;
+    bool aligned = false;
+    const int rc = convert(d, g, aligned, t);
+    if (rc) return rc;
+    if (d->op != ICKA_GEMM_NT || g.f16 || !aligned || g.c_f32 || g.c_f16 || g.epi != ICKA_EPI_NONE || g.beta != 0.f || g.alpha != 1.f ||
+        !g.bias || g.bias2 || g.K1 != 0 || g.colsum || g.C3 || g.C2 || !t.w3 || !t.ws || d->tune)
+        return ICKA_E_SHAPE;
+    const int H = heads * 64;
+    if (S != 128 || g.N != 3 * H || g.M != B * S || g.M % 256 || g.K > 1024) return ICKA_E_SHAPE;
+    const int nb3 = (g.M / 256) * heads;
+    if (nb3 % 8 || nb3 < 128) return ICKA_E_SHAPE;   // (small grids: the two launches, whose attention spreads over more CUs)
+    if ((int64_t)B * heads * S * S >= (1ll << 32)) return ICKA_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(ctx) & 15) || ldo % 8 || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return ICKA_E_ALIGN;
+    { const int pm = gemm_w3_grid(g.M, g.N, 192, t.w3grid), pn = 8 / pm;
+      if ((g.M / 256) % pm || heads % pn) return ICKA_E_SHAPE;
+      g.w3_sn = heads / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
+    QkvAttnArgs p;
+    p.g = g;
+    p.a = AttnArgs{};
+    const bf16_t* C = reinterpret_cast<const bf16_t*>(g.C);
+    p.a.Q = C; p.a.ldq = g.ldc; p.a.K = C + H; p.a.ldk = g.ldc; p.a.V = C + 2 * H; p.a.ldv = g.ldc;
+    p.a.mask = add_mask; p.a.Ow = (bf16_t*)ctx; p.a.ldo = ldo; p.a.lse = lse;
+    p.a.B = B; p.a.h = heads; p.a.Sq = S; p.a.Skv = S; p.a.scale = scale; p.a.drop = make_drop(p_drop, seed);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.a.drop.thr) hipLaunchKernelGGL((gemm_qkv_attn_kernel<true>), dim3(nb3), dim3(768), 0, st, p);
+    else hipLaunchKernelGGL((gemm_qkv_attn_kernel<false>), dim3(nb3), dim3(768), 0, st, p);
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -77,8 +77,9 @@ def profile_gemm(enable: bool, reps: int = 5):
     last_fused_profile = None
     if not rec:
         return 0.0, 0.0, 0, 0.0
-    plain = [r for r in rec if r[0] != 2]
+    plain = [r for r in rec if r[0] < 2]
     fused = [r for r in rec if r[0] == 2]      # icka_gemm_ln launches: a GEMM with its LayerNorm phase in the same kernel
+    fused_qa = [r for r in rec if r[0] == 3]   # icka_gemm_qkv_attn launches: the QKV projection with its attention in the same kernel
 
     def replay(which):
         for kind, payload, n, _keep in which:
@@ -86,8 +87,10 @@ def profile_gemm(enable: bool, reps: int = 5):
                 check(lib.icka_gemm(C.byref(payload), _stream()), "icka_gemm")
             elif kind == 1:
                 check(lib.icka_gemm_grouped(payload, n, _stream()), "icka_gemm_grouped")
-            else:
+            elif kind == 2:
                 check(lib.icka_gemm_ln(*payload), "icka_gemm_ln")
+            else:
+                check(lib.icka_gemm_qkv_attn(*payload), "icka_gemm_qkv_attn")
 
     def timed(which):
         replay(which)   # warm
@@ -105,11 +108,16 @@ def profile_gemm(enable: bool, reps: int = 5):
         # the fused launches are timed in a bracket of their own: their duration contains the HBM-bound LayerNorm phase, so they
         # are reported beside the MFMA-bound class, not inside it
         last_fused_profile = {"flops": fl(fused), "ms": timed(fused), "launches": reps * len(fused)}
+    global last_fused_qkv_profile
+    last_fused_qkv_profile = None
+    if fused_qa:    # likewise: the launch contains the whole-head attention of its tiles (GEMM FLOPs only are counted)
+        last_fused_qkv_profile = {"flops": fl(fused_qa), "ms": timed(fused_qa), "launches": reps * len(fused_qa)}
     ms = timed(plain) if plain else 0.0
     nbytes = reps * sum(_gemm_bytes(d) for _, _, _, ds in plain for d in ds)
     return fl(plain), ms, reps * len(plain), nbytes
 
 
+last_fused_qkv_profile = None   # the same for the recorded icka_gemm_qkv_attn launches
 last_fused_profile = None     # profile_gemm(False): {"flops", "ms", "launches"} of the recorded icka_gemm_ln launches, or None
 
 
@@ -408,6 +416,32 @@ def gemm_ln(h, w, o, bias, residual, gamma, beta, y, sync, *, y_f32=None, y_f16=
     if _PROF is not None:   # bench.py roofline leg: the launch is re-issued later, its operands must outlive the step
         d._keep = (h, w, o, bias, residual, gamma, beta, y, twin, xhat, rstd, sync)
         _PROF.append((2, args, 1, [d]))
+    return True
+
+
+def gemm_qkv_attn(x, w, bias, qkv, add_mask, ctx, lse, B, heads, S, *, p_drop=0.0, seed=0, scale=None) -> bool:
+    """QKV projection (x @ w^T + bias -> qkv, the stacked bf16 [q | k | v]) and the whole-head self-attention of every (sample,
+    head) as ONE launch (icka_gemm_qkv_attn) -- bitwise ``gemm(NT, x, w, qkv, bias=bias)`` followed by ``attn_fwd`` on the three
+    column blocks.  Returns False (nothing launched) when the shape is not eligible: the caller then makes the two calls."""
+    lib = _lib.load()
+    d = gemm_desc(GEMM_NT, x, w, qkv, bias=bias)
+    _mat(ctx, "ctx")
+    H = heads * 64
+    if tuple(qkv.shape) != (B * S, 3 * H) or tuple(ctx.shape) != (B * S, H):
+        return False
+    if add_mask.dtype != F32 or not add_mask.is_contiguous() or add_mask.numel() != B * S:
+        raise ValueError("add_mask must be contiguous f32 [B, S]")
+    if lse is not None and (lse.dtype != F32 or not lse.is_contiguous() or lse.numel() != B * heads * S):
+        raise ValueError("lse must be contiguous f32 [B, heads, S]")
+    args = (d, add_mask.data_ptr(), ctx.data_ptr(), ctx.stride(0), _ptr(lse), B, heads, S,
+            (1.0 / 8.0) if scale is None else scale, p_drop, seed, _stream())
+    rc = lib.icka_gemm_qkv_attn(*args)
+    if rc == -1:        # ICKA_E_SHAPE
+        return False
+    check(rc, "icka_gemm_qkv_attn")
+    if _PROF is not None:
+        d._keep = (x, w, bias, qkv, add_mask, ctx, lse)
+        _PROF.append((3, args, 1, [d]))
     return True
 
 

@@ -33,6 +33,10 @@ FUSE_DENSE_LN = _os.environ.get("ICKA_FUSE_DENSE_LN", "1") != "0"
 # kernel spreads the same rows over the whole chip -- at M = 512 (the reference's test loop at batch 4: 32 blocks) the replayed
 # forward is 7 % SLOWER with it (1.25 vs 1.17 ms, profiles/r05_gemm_ln_ab.txt); it pays when the GEMM's grid fills the chip
 FUSE_DENSE_LN_MIN_ROWS = 3072
+# QKV projection + self-attention as ONE launch where the shape allows it (icka_gemm_qkv_attn: 128 tokens per sample, head size 64;
+# bitwise the two launches).  "0" keeps the two launches.  The library itself declines grids below 128 tiles.
+FUSE_QKV_ATTN = _os.environ.get("ICKA_FUSE_QKV_ATTN", "1") != "0"
+FUSE_QKV_ATTN_MIN_ROWS = 3072
 
 
 def _keepbits_on(Sq: int, Skv: int) -> bool:
@@ -202,11 +206,23 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     if kv_src is None:
         qkv = _empty(x, M, 3 * H)
         wq = (sa.query.weight, sa.key.weight, sa.value.weight)
-        K.gemm(K.GEMM_NT, xa, A.w16_cat(wq) if h16 else A.w_cat(wq), qkv,
-               bias=A.f_cat((sa.query.bias, sa.key.bias, sa.value.bias)))
+        bq = A.f_cat((sa.query.bias, sa.key.bias, sa.value.bias))
+        pre = None
+        if (FUSE_QKV_ATTN and not h16 and d.S == 128 and Skv == 128 and H == 64 * d.heads and M >= FUSE_QKV_ATTN_MIN_ROWS
+                and not (save and d.p_attn > 0 and _keepbits_on(d.S, Skv))):
+            # projection + whole-head attention in ONE launch (icka_gemm_qkv_attn): every 256 x 192 tile = two samples x one
+            # head's q | k | v, the attention runs from the tile's LDS images; bitwise the two launches below
+            ctx = _empty(x, M, H)
+            seed_a = A.next_seed() if d.p_attn > 0 else 0
+            lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
+            if K.gemm_qkv_attn(xa, A.w_cat(wq), bq, qkv, add_mask, ctx, lse, d.B, d.heads, d.S, p_drop=d.p_attn, seed=seed_a):
+                return ctx, None, ((qkv, None, lse, seed_a, None) if save else None)
+            pre = (ctx, seed_a, lse)      # not a shape of the fused launch: the two launches below, same seed and buffers
+        K.gemm(K.GEMM_NT, xa, A.w16_cat(wq) if h16 else A.w_cat(wq), qkv, bias=bq)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
         kvbuf = None
     else:
+        pre = None
         qkv = _empty(x, M, H)
         K.gemm(K.GEMM_NT, xa, A.w16(sa.query.weight) if h16 else A.w(sa.query.weight), qkv, bias=sa.query.bias)
         kvbuf = _empty(x, kv_src.shape[0], 2 * H)
@@ -216,9 +232,9 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         else:
             K.gemm(K.GEMM_NT, kv_src, A.w_cat(wkv), kvbuf, bias=A.f_cat((sa.key.bias, sa.value.bias)))
         q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
-    ctx = _empty(x, M, H)
+    ctx = pre[0] if pre else _empty(x, M, H)
     ctx16 = _empty(x, M, H, dtype=F16) if h16 else None
-    seed_a = A.next_seed() if d.p_attn > 0 else 0
+    seed_a = pre[1] if pre else (A.next_seed() if d.p_attn > 0 else 0)
     if H // d.heads != 64:
         if (kv_src is not None) and bool(getattr(sa, "fp8_scores", False)):
             raise ValueError("the fp8 cross-attention kernels are built for head size 64, got %d" % (H // d.heads))
@@ -227,7 +243,7 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         # fp32 mode (probabilities materialised as the reference does, same dropout hash)
         gen = _attn_generic_fwd(qkv, kvbuf, kv_src is None, add_mask, d, Skv, seed_a, ctx, ctx16, save)
         return ctx, ctx16, ((qkv, kvbuf, gen, seed_a, None) if save else None)
-    lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
+    lse = pre[2] if pre else (_empty(x, d.B, d.heads, d.S, dtype=F32) if save else None)
     # BASELINE config c5: a co-attention module flagged fp8_scores runs QK^T / PV on the fp8 matrix cores
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
     # optional (ATTN_KEEPBITS): the forward leaves the keep decisions of its probability dropout as bits and the backward reads

@@ -103,7 +103,7 @@ def main():
                 row["hbm_side_GBps"] = round(per / (ns / nd), 1)      # bytes / ns = GB/s
                 row["hbm_frac_of_8TBps"] = round(per / (ns / nd) / 8000.0, 3)
         rows[short(k)] = row
-        kind = ("gemm+layernorm (one launch)" if "gemm_ln" in k else "gemm" if "gemm" in k else "attention" if "attn" in k else "layernorm" if ("ln_" in k or "embed" in k) else
+        kind = ("gemm+layernorm (one launch)" if "gemm_ln" in k else "qkv gemm+attention (one launch)" if "gemm_qkv_attn" in k else "gemm" if "gemm" in k else "attention" if "attn" in k else "layernorm" if ("ln_" in k or "embed" in k) else
                 "lstm" if "lstm" in k else "other")
         cc = cls.setdefault(kind, [0.0, 0.0, 0.0])
         cc[0] += b

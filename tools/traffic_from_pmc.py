@@ -27,8 +27,10 @@ def main():
     write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
     # (gemm_ln_kernel -- a dense GEMM with its LayerNorm phase in the same launch -- is listed per kernel below but kept out of the
     #  class: its bytes contain the LayerNorm's row traffic; bench.py reports it under roofline.fused_dense_ln)
-    gemm = [k for k in fetch if "gemm" in k and "gemm_ln" not in k]
+    #  gemm_qkv_attn_kernel -- the QKV projection with its attention -- likewise: roofline.fused_qkv_attn)
+    gemm = [k for k in fetch if "gemm" in k and "gemm_ln" not in k and "gemm_qkv_attn" not in k]
     fused = [k for k in fetch if "gemm_ln" in k]
+    fused_qa = [k for k in fetch if "gemm_qkv_attn" in k]
     launches = sum(nf[k] for k in gemm)
     fb = sum(fetch[k] for k in gemm) * 1024.0 * 2.0
     wb = sum(write.get(k, 0.0) for k in gemm) * 1024.0
@@ -45,6 +47,8 @@ def main():
                                 "write_MB": write.get(k, 0.0) * 1024.0 / 1e6} for k in sorted(gemm)},
         "fused_dense_ln": {k[:90]: {"launches": nf[k], "fetch_MB_corrected": fetch[k] * 2048.0 / 1e6,
                                     "write_MB": write.get(k, 0.0) * 1024.0 / 1e6} for k in sorted(fused)},
+        "fused_qkv_attn": {k[:90]: {"launches": nf[k], "fetch_MB_corrected": fetch[k] * 2048.0 / 1e6,
+                                    "write_MB": write.get(k, 0.0) * 1024.0 / 1e6} for k in sorted(fused_qa)},
     }
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("launches", "fetch_bytes_per_launch_corrected_x2", "write_bytes_per_launch",
