@@ -45,10 +45,13 @@ def test_default_bench_line_keeps_the_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4) and 0.02 < r["frac"] < 1.0
     assert r["achieved"] == pytest.approx(r["algorithmic_flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12, rel=2e-2)
-    # 125 GEMM launches per step: 26 of them (out-proj and ffn-down of the 12 + 1 layers) carry their LayerNorm in the same launch
-    f = r["fused_dense_ln"]
-    assert r["launches_per_step"] + f["launches_per_step"] == 125 and f["launches_per_step"] == 26
-    assert r["gemm_ms_per_step"] + f["ms_per_step"] < d["ms_per_step"] and 10.0 < f["avg_launch_us"] < 80.0
+    # 125 GEMM launches per step: 26 of them (out-proj and ffn-down of the 12 + 1 layers) carry their LayerNorm in the same launch,
+    # 12 (the QKV projections of the BERT layers) their self-attention
+    f, fq = r["fused_dense_ln"], r["fused_qkv_attn"]
+    assert r["launches_per_step"] + f["launches_per_step"] + fq["launches_per_step"] == 125
+    assert f["launches_per_step"] == 26 and fq["launches_per_step"] == 12
+    assert r["gemm_ms_per_step"] + f["ms_per_step"] + fq["ms_per_step"] < d["ms_per_step"]
+    assert 10.0 < f["avg_launch_us"] < 80.0 and 10.0 < fq["avg_launch_us"] < 80.0
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
     assert r["mfma_busy"] is None or 0.0 < r["mfma_busy"]["gemm_class_busy_frac_of_nominal_peak"] < 1.0
     c = d["cpu_baseline"]
