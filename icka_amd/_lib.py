@@ -69,7 +69,7 @@ PROTOTYPES = {
     "icka_gemm_grouped_ex": (c_i32, [C.POINTER(GemmDesc), c_i32, C.POINTER(SlabReduction), c_i32, c_vp]),
     "icka_gemm_ln": (c_i32, [C.POINTER(GemmDesc), c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_f32,
                              c_f32, c_u64, c_vp, c_vp, c_vp]),
-    "icka_gemm_qkv_attn": (c_i32, [C.POINTER(GemmDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp]),
+    "icka_gemm_qkv_attn": (c_i32, [C.POINTER(GemmDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp, c_vp]),
     "icka_gemm_ln_sync_words": (c_i64, []),
     "icka_gemm_ln_test_hooks": (c_i32, [c_i32, c_i32]),
     "icka_ln_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,

@@ -1567,8 +1567,12 @@ __device__ __forceinline__ void dma_init_qkv(const bf16_t* (&ptr)[4], const bf16
     }
 }
 
-template <bool DROP>
+// SEQ = tokens per sample: 128 (the tile's 256 rows = two samples, 32 queries per compute wave in one pass) or 256 (one sample,
+// bert-large at BASELINE config c4: 32 queries per wave as two passes of 16 against the 256 keys).  F16: fp16 operands of the
+// projection (the "mixed16" forward GEMMs; q / k / v stay bf16).  KB: the attention leaves its keep bits (SEQ = 256 only).
+template <bool DROP, bool F16, int SEQ, bool KB>
 __global__ __launch_bounds__(768) void gemm_qkv_attn_kernel(const QkvAttnArgs p) {
+    static_assert(SEQ == 128 || SEQ == 256, "tokens per sample");
     const GemmArgs g = p.g;
     __shared__ __attribute__((aligned(16))) char smem[W3_NA * W3_A + W3_NB * W3_B];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1638,15 +1642,15 @@ __global__ __launch_bounds__(768) void gemm_qkv_attn_kernel(const QkvAttnArgs p)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NB16; ++ni) acc[mi][ni] = mfma16t<false>(fb[ni], fa[mi], acc[mi][ni]);
+                    for (int ni = 0; ni < NB16; ++ni) acc[mi][ni] = mfma16t<F16>(fb[ni], fa[mi], acc[mi][ni]);
             }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA -> VALU read wait states
     }
-    __syncthreads();   // the operand ring is dead: it becomes the six [128][64] bf16 images, image (2 s + ...) = smem + (3 s + mat) * 16 KiB
-    constexpr int IMG = 128 * 128;
+    __syncthreads();   // the operand ring is dead: it becomes the bf16 images [SEQ][64] of q, k, v (of either sample): smem + (3 s + mat) * IMG
+    constexpr int IMG = SEQ * 128;
     if (wave < 8) {
-        const int s = wave >> 2;
+        const int s = SEQ == 128 ? wave >> 2 : 0;
 #pragma unroll
         for (int ni = 0; ni < NB16; ++ni) {
             const int c0 = wc + 16 * ni + 4 * (lane >> 4);   // tile column of this lane's four accumulator columns
@@ -1655,7 +1659,7 @@ __global__ __launch_bounds__(768) void gemm_qkv_attn_kernel(const QkvAttnArgs p)
             char* im = smem + (3 * s + mat) * IMG;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int r = (wr & 127) + 16 * mi + (lane & 15);
+                const int r = (wr & (SEQ - 1)) + 16 * mi + (lane & 15);
                 const f32x4 v = acc[mi][ni] + bv;
                 *reinterpret_cast<u32x2*>(im + off_t(r, cc >> 3) + 8 * ((cc >> 2) & 1)) = pack4(v[0], v[1], v[2], v[3]);
             }
@@ -1663,25 +1667,34 @@ __global__ __launch_bounds__(768) void gemm_qkv_attn_kernel(const QkvAttnArgs p)
     }
     __syncthreads();
     if (wave >= 8) {
-        // the qkv activation for the backward: 6 images x 128 rows x 8 chunks of 16 B, 24 per loader thread; a row's 64 columns
+        // the qkv activation for the backward: 256 rows x 3 matrices x 8 chunks of 16 B, 24 per loader thread; a row's 64 columns
         // (128 B) are contiguous in global memory
         bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
         const int t = tid - 512;
 #pragma unroll 4
         for (int i = 0; i < 24; ++i) {
             const int id = t + 256 * i;
-            const int im = id >> 10, r = (id >> 3) & 127, c = id & 7;
+            const int im = id / (SEQ * 8), r = (id >> 3) & (SEQ - 1), c = id & 7;
             const int s = im >= 3 ? 1 : 0, mat = im - 3 * s;
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + im * IMG + off_t(r, c));
-            st_main(reinterpret_cast<u32x4*>(C + (int64_t)(m0 + 128 * s + r) * g.ldc + mat * H + head * 64 + 8 * c), v, g.plain);
+            st_main(reinterpret_cast<u32x4*>(C + (int64_t)(m0 + SEQ * s + r) * g.ldc + mat * H + head * 64 + 8 * c), v, g.plain);
         }
         return;
     }
     AttnArgs a = p.a;
     a.drop = drop_resolve(a.drop);
-    const int s = wave >> 2, b = (m0 >> 7) + s;
+    a.Sq = a.Skv = SEQ;   // (the host checked it: as constants they fold the core's end-of-sequence clamps and selects away)
+    const int s = SEQ == 128 ? wave >> 2 : 0, b = m0 / SEQ + s;
     const char* sQ = smem + 3 * s * IMG;
-    attn_fwd_whole_head<2, 8, DROP, false, false>(a, sQ, sQ + IMG, sQ + 2 * IMG, 2 * (wave & 3), 0, b * a.h + head, b, head, lane);
+    if constexpr (SEQ == 128) {
+        attn_fwd_whole_head<2, 8, DROP, false, KB>(a, sQ, sQ + IMG, sQ + 2 * IMG, 2 * (wave & 3), 0, b * a.h + head, b, head, lane);
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            asm volatile("" ::: "memory");   // (keeps the pass's LDS reads -- K fragments, mask -- inside the pass: hoisted they spill)
+            attn_fwd_whole_head<1, 16, DROP, false, KB>(a, sQ, sQ + IMG, sQ + 2 * IMG, 2 * wave + t, 0, b * a.h + head, b, head, lane);
+        }
+    }
 }
 
 // rows pm of the pm x pn XCD cut of a 256 x bnw tile grid that fetches least: min pn * M + pm * N over the cuts that divide it
@@ -2015,12 +2028,20 @@ extern "C" int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const vo
 }
 
 // QKV projection + whole-head self-attention in one launch (gemm_qkv_attn_kernel).  d: the NT projection [M, 3 H] = x . Wqkv^T
-// with its bias and a bf16 output (the stacked [q | k | v] activation, written as by icka_gemm); the attention arguments as
-// icka_attn_fwd with Q / K / V = the three column blocks of that output.  ICKA_E_SHAPE = not a shape this launch covers (the
-// caller runs icka_gemm + icka_attn_fwd, which give the same bits): S = 128 tokens per sample, head size 64, an even number
-// of samples, a tile grid of the 12-wave kernel.
-extern "C" int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask, void* ctx, int64_t ldo, float* lse, int32_t B,
-                                  int32_t heads, int32_t S, float scale, float p_drop, uint64_t seed, void* stream) {
+// with its bias and a bf16 output (the stacked [q | k | v] activation, written as by icka_gemm); operands bf16, or both fp16
+// ("mixed16").  The attention arguments as icka_attn_fwd_ex with Q / K / V = the three column blocks of that output.
+// ICKA_E_SHAPE = not a shape this launch covers (the caller runs icka_gemm + icka_attn_fwd_ex, which give the same bits):
+// S = 128 or 256 tokens per sample, head size 64, whole 256-row tiles, a tile grid of the 12-wave kernel.
+template <bool F16, int SEQ>
+static void launch_qkv_attn(const QkvAttnArgs& p, int nb3, hipStream_t st) {
+    if (p.a.drop.thr && p.a.keepbits) {
+        if constexpr (SEQ == 256) hipLaunchKernelGGL((gemm_qkv_attn_kernel<true, F16, 256, true>), dim3(nb3), dim3(768), 0, st, p);
+    } else if (p.a.drop.thr) hipLaunchKernelGGL((gemm_qkv_attn_kernel<true, F16, SEQ, false>), dim3(nb3), dim3(768), 0, st, p);
+    else hipLaunchKernelGGL((gemm_qkv_attn_kernel<false, F16, SEQ, false>), dim3(nb3), dim3(768), 0, st, p);
+}
+extern "C" int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask, void* ctx, void* ctx_f16, int64_t ldo, float* lse,
+                                  int32_t B, int32_t heads, int32_t S, float scale, float p_drop, uint64_t seed, void* keep_bits,
+                                  void* stream) {
     if (!d || !add_mask || !ctx) return ICKA_E_ARG;
     if (B <= 0 || heads <= 0 || S <= 0) return ICKA_E_SHAPE;
     GemmArgs g;
@@ -2028,15 +2049,18 @@ extern "C" int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask
     bool aligned = false;
     const int rc = convert(d, g, aligned, t);
     if (rc) return rc;
-    if (d->op != ICKA_GEMM_NT || g.f16 || !aligned || g.c_f32 || g.c_f16 || g.epi != ICKA_EPI_NONE || g.beta != 0.f || g.alpha != 1.f ||
+    if (d->op != ICKA_GEMM_NT || !aligned || g.c_f32 || g.c_f16 || g.epi != ICKA_EPI_NONE || g.beta != 0.f || g.alpha != 1.f ||
         !g.bias || g.bias2 || g.K1 != 0 || g.colsum || g.C3 || g.C2 || !t.w3 || !t.ws || d->tune)
         return ICKA_E_SHAPE;
     const int H = heads * 64;
-    if (S != 128 || g.N != 3 * H || g.M != B * S || g.M % 256 || g.K > 1024) return ICKA_E_SHAPE;
+    if ((S != 128 && S != 256) || g.N != 3 * H || g.M != B * S || g.M % 256 || g.K > 1024) return ICKA_E_SHAPE;
     const int nb3 = (g.M / 256) * heads;
     if (nb3 % 8 || nb3 < 128) return ICKA_E_SHAPE;   // (small grids: the two launches, whose attention spreads over more CUs)
     if ((int64_t)B * heads * S * S >= (1ll << 32)) return ICKA_E_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(ctx) & 15) || ldo % 8 || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return ICKA_E_ALIGN;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(ctx) || (ctx_f16 && !al16(ctx_f16)) || ldo % 8 || !al16(g.bias)) return ICKA_E_ALIGN;
+    const bool keep = keep_bits && p_drop > 0.f;
+    if (keep && S != 256) return ICKA_E_SHAPE;       // (keep bits are left by the 256-token instance only: ops.ATTN_KEEPBITS "auto")
     { const int pm = gemm_w3_grid(g.M, g.N, 192, t.w3grid), pn = 8 / pm;
       if ((g.M / 256) % pm || heads % pn) return ICKA_E_SHAPE;
       g.w3_sn = heads / pn; g.w3_pnlog = pn == 1 ? 0 : (pn == 2 ? 1 : (pn == 4 ? 2 : 3)); }
@@ -2045,11 +2069,12 @@ extern "C" int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask
     p.a = AttnArgs{};
     const bf16_t* C = reinterpret_cast<const bf16_t*>(g.C);
     p.a.Q = C; p.a.ldq = g.ldc; p.a.K = C + H; p.a.ldk = g.ldc; p.a.V = C + 2 * H; p.a.ldv = g.ldc;
-    p.a.mask = add_mask; p.a.Ow = (bf16_t*)ctx; p.a.ldo = ldo; p.a.lse = lse;
+    p.a.mask = add_mask; p.a.Ow = (bf16_t*)ctx; p.a.Ow16 = (_Float16*)ctx_f16; p.a.ldo = ldo; p.a.lse = lse;
     p.a.B = B; p.a.h = heads; p.a.Sq = S; p.a.Skv = S; p.a.scale = scale; p.a.drop = make_drop(p_drop, seed);
+    p.a.keepbits = p.a.drop.thr ? (uint32_t*)keep_bits : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (p.a.drop.thr) hipLaunchKernelGGL((gemm_qkv_attn_kernel<true>), dim3(nb3), dim3(768), 0, st, p);
-    else hipLaunchKernelGGL((gemm_qkv_attn_kernel<false>), dim3(nb3), dim3(768), 0, st, p);
+    if (g.f16) { if (S == 128) launch_qkv_attn<true, 128>(p, nb3, st); else launch_qkv_attn<true, 256>(p, nb3, st); }
+    else { if (S == 128) launch_qkv_attn<false, 128>(p, nb3, st); else launch_qkv_attn<false, 256>(p, nb3, st); }
     ICKA_CHECK_LAUNCH();
     return 0;
 }

@@ -419,10 +419,12 @@ def gemm_ln(h, w, o, bias, residual, gamma, beta, y, sync, *, y_f32=None, y_f16=
     return True
 
 
-def gemm_qkv_attn(x, w, bias, qkv, add_mask, ctx, lse, B, heads, S, *, p_drop=0.0, seed=0, scale=None) -> bool:
-    """QKV projection (x @ w^T + bias -> qkv, the stacked bf16 [q | k | v]) and the whole-head self-attention of every (sample,
-    head) as ONE launch (icka_gemm_qkv_attn) -- bitwise ``gemm(NT, x, w, qkv, bias=bias)`` followed by ``attn_fwd`` on the three
-    column blocks.  Returns False (nothing launched) when the shape is not eligible: the caller then makes the two calls."""
+def gemm_qkv_attn(x, w, bias, qkv, add_mask, ctx, lse, B, heads, S, *, p_drop=0.0, seed=0, scale=None, out16=None,
+                  keepbits=None) -> bool:
+    """QKV projection (x @ w^T + bias -> qkv, the stacked bf16 [q | k | v]; x / w bf16 or both fp16) and the whole-head
+    self-attention of every (sample, head) as ONE launch (icka_gemm_qkv_attn) -- bitwise ``gemm(NT, x, w, qkv, bias=bias)``
+    followed by ``attn_fwd`` on the three column blocks (``out16`` / ``keepbits`` as there).  Returns False (nothing launched)
+    when the shape is not eligible: the caller then makes the two calls."""
     lib = _lib.load()
     d = gemm_desc(GEMM_NT, x, w, qkv, bias=bias)
     _mat(ctx, "ctx")
@@ -433,14 +435,21 @@ def gemm_qkv_attn(x, w, bias, qkv, add_mask, ctx, lse, B, heads, S, *, p_drop=0.
         raise ValueError("add_mask must be contiguous f32 [B, S]")
     if lse is not None and (lse.dtype != F32 or not lse.is_contiguous() or lse.numel() != B * heads * S):
         raise ValueError("lse must be contiguous f32 [B, heads, S]")
-    args = (d, add_mask.data_ptr(), ctx.data_ptr(), ctx.stride(0), _ptr(lse), B, heads, S,
-            (1.0 / 8.0) if scale is None else scale, p_drop, seed, _stream())
+    if out16 is not None:
+        _mat(out16, "out16", F16)
+        if tuple(out16.shape) != tuple(ctx.shape) or out16.stride(0) != ctx.stride(0):
+            raise ValueError("out16 must have the shape and row stride of ctx")
+    if keepbits is not None and (not keepbits.is_cuda or keepbits.element_size() != 4 or not keepbits.is_contiguous()
+                                 or keepbits.numel() < lib.icka_attn_keepbits_words(B, heads, S, S)):
+        raise ValueError("keepbits: contiguous 32-bit device buffer of icka_attn_keepbits_words words (attn_keepbits)")
+    args = (d, add_mask.data_ptr(), ctx.data_ptr(), _ptr(out16), ctx.stride(0), _ptr(lse), B, heads, S,
+            (1.0 / 8.0) if scale is None else scale, p_drop, seed, _ptr(keepbits), _stream())
     rc = lib.icka_gemm_qkv_attn(*args)
     if rc == -1:        # ICKA_E_SHAPE
         return False
     check(rc, "icka_gemm_qkv_attn")
     if _PROF is not None:
-        d._keep = (x, w, bias, qkv, add_mask, ctx, lse)
+        d._keep = (x, w, bias, qkv, add_mask, ctx, lse, out16, keepbits)
         _PROF.append((3, args, 1, [d]))
     return True
 

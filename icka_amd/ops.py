@@ -208,16 +208,20 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
         wq = (sa.query.weight, sa.key.weight, sa.value.weight)
         bq = A.f_cat((sa.query.bias, sa.key.bias, sa.value.bias))
         pre = None
-        if (FUSE_QKV_ATTN and not h16 and d.S == 128 and Skv == 128 and H == 64 * d.heads and M >= FUSE_QKV_ATTN_MIN_ROWS
-                and not (save and d.p_attn > 0 and _keepbits_on(d.S, Skv))):
-            # projection + whole-head attention in ONE launch (icka_gemm_qkv_attn): every 256 x 192 tile = two samples x one
+        want_kb = save and d.p_attn > 0 and _keepbits_on(d.S, Skv)
+        if (FUSE_QKV_ATTN and d.S in (128, 256) and Skv == d.S and H == 64 * d.heads and M >= FUSE_QKV_ATTN_MIN_ROWS
+                and not (want_kb and d.S != 256)):
+            # projection + whole-head attention in ONE launch (icka_gemm_qkv_attn): every 256 x 192 tile = 256 / S samples x one
             # head's q | k | v, the attention runs from the tile's LDS images; bitwise the two launches below
             ctx = _empty(x, M, H)
+            ctx16 = _empty(x, M, H, dtype=F16) if h16 else None
             seed_a = A.next_seed() if d.p_attn > 0 else 0
             lse = _empty(x, d.B, d.heads, d.S, dtype=F32) if save else None
-            if K.gemm_qkv_attn(xa, A.w_cat(wq), bq, qkv, add_mask, ctx, lse, d.B, d.heads, d.S, p_drop=d.p_attn, seed=seed_a):
-                return ctx, None, ((qkv, None, lse, seed_a, None) if save else None)
-            pre = (ctx, seed_a, lse)      # not a shape of the fused launch: the two launches below, same seed and buffers
+            kb = K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if want_kb else None
+            if K.gemm_qkv_attn(xa, A.w16_cat(wq) if h16 else A.w_cat(wq), bq, qkv, add_mask, ctx, lse, d.B, d.heads, d.S,
+                               p_drop=d.p_attn, seed=seed_a, out16=ctx16, keepbits=kb):
+                return ctx, ctx16, ((qkv, None, lse, seed_a, kb) if save else None)
+            pre = (ctx, seed_a, lse, ctx16, kb)      # not a shape of the fused launch: the two launches below, same seed and buffers
         K.gemm(K.GEMM_NT, xa, A.w16_cat(wq) if h16 else A.w_cat(wq), qkv, bias=bq)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
         kvbuf = None
@@ -233,7 +237,7 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
             K.gemm(K.GEMM_NT, kv_src, A.w_cat(wkv), kvbuf, bias=A.f_cat((sa.key.bias, sa.value.bias)))
         q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
     ctx = pre[0] if pre else _empty(x, M, H)
-    ctx16 = _empty(x, M, H, dtype=F16) if h16 else None
+    ctx16 = pre[3] if pre else (_empty(x, M, H, dtype=F16) if h16 else None)
     seed_a = pre[1] if pre else (A.next_seed() if d.p_attn > 0 else 0)
     if H // d.heads != 64:
         if (kv_src is not None) and bool(getattr(sa, "fp8_scores", False)):
@@ -248,7 +252,7 @@ def _attn_core_fwd(A: ParamArena, sa, x, kv_src, add_mask, d: Dims, Skv: int, sa
     fp8 = (kv_src is not None) and bool(getattr(sa, "fp8_scores", False))
     # optional (ATTN_KEEPBITS): the forward leaves the keep decisions of its probability dropout as bits and the backward reads
     # them instead of hashing every (query, key) element a second time
-    kb = K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if (save and d.p_attn > 0 and _keepbits_on(d.S, Skv)) else None
+    kb = pre[4] if pre else (K.attn_keepbits(d.B, d.heads, d.S, Skv, x.device) if (save and d.p_attn > 0 and _keepbits_on(d.S, Skv)) else None)
     K.attn_fwd(q, k, v, add_mask, ctx, lse, d.B, d.heads, d.S, Skv, p_drop=d.p_attn, seed=seed_a, fp8=fp8, out16=ctx16,
                keepbits=kb)
     return ctx, ctx16, ((qkv, kvbuf, lse, seed_a, kb) if save else None)

@@ -190,18 +190,20 @@ int icka_gemm_ln(const icka_gemm_desc* d, const float* bias, const void* residua
 int64_t icka_gemm_ln_sync_words(void);
 int icka_gemm_ln_test_hooks(int32_t polls, int32_t drop_block);
 /* The fused QKV projection and the self-attention of BertSelfAttention.forward (Cross_Modal_Interaction_Module.py:478-506:
- * query / key / value Linear, transpose_for_scores, scores / sqrt(d) + mask, softmax, dropout, context) as ONE launch, for the
- * reference's max_seq_length of 128 tokens and head size 64.  `d` is the projection exactly as icka_gemm takes it: op NT,
- * A = hidden states bf16 [B * 128, K], B = the stacked [Wq; Wk; Wv] bf16 [3 H, K], bias = the stacked f32 bias, C = the bf16
- * [B * 128, 3 H] activation [q | k | v] (WRITTEN as by icka_gemm: the backward reads it), no epilogue / accumulate / copies.
- * The rest is icka_attn_fwd's with Q / K / V = the three column blocks of C: add_mask f32 [B, 128], ctx bf16 [B * 128, H] (ldo),
- * lse f32 [B, heads, 128] or NULL, scale, p_drop, seed (same dropout counters: icka_attn_bwd regenerates the same mask).
- * Each 256 x 192 tile of the 12-wave GEMM kernel is laid over TWO samples x ONE head's 64 + 64 + 64 columns, so the block
- * that produced q, k, v of a head runs that head's attention from LDS.  Results are BITWISE those of icka_gemm + icka_attn_fwd.
- * Eligible: S == 128, H = 64 * heads, B even, K % 64 == 0 and <= 1024, (B / 2) * heads a multiple of 8 and >= 128; anything
- * else returns ICKA_E_SHAPE and launches nothing: the caller makes the two calls. */
-int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask, void* ctx, int64_t ldo, float* lse, int32_t B,
-                       int32_t heads, int32_t S, float scale, float p_drop, uint64_t seed, void* stream);
+ * query / key / value Linear, transpose_for_scores, scores / sqrt(d) + mask, softmax, dropout, context) as ONE launch, for
+ * sequences of 128 tokens (the reference's max_seq_length) or 256 (BASELINE config c4) and head size 64.  `d` is the projection
+ * exactly as icka_gemm takes it: op NT, A = hidden states [B * S, K], B = the stacked [Wq; Wk; Wv] [3 H, K] (both bf16, or both
+ * fp16: the "mixed16" forward operands), bias = the stacked f32 bias, C = the bf16 [B * S, 3 H] activation [q | k | v] (WRITTEN
+ * as by icka_gemm: the backward reads it), no epilogue / accumulate / copies.  The rest is icka_attn_fwd_ex's with Q / K / V = the
+ * three column blocks of C: add_mask f32 [B, S], ctx bf16 [B * S, H] (ldo) and its optional fp16 copy ctx_f16 (same ldo), lse
+ * f32 [B, heads, S] or NULL, scale, p_drop, seed (same dropout counters: icka_attn_bwd regenerates the same mask), keep_bits
+ * (icka_attn_keepbits_words words or NULL; S = 256 only).
+ * Each 256 x 192 tile of the 12-wave GEMM kernel is laid over 256 / S samples x ONE head's 64 + 64 + 64 columns, so the block
+ * that produced q, k, v of a head runs that head's attention from LDS.  Results are BITWISE those of icka_gemm +
+ * icka_attn_fwd_ex.  Eligible: S == 128 or 256, H = 64 * heads, B * S % 256 == 0, K % 64 == 0 and <= 1024, (B * S / 256) * heads
+ * a multiple of 8 and >= 128; anything else returns ICKA_E_SHAPE and launches nothing: the caller makes the two calls. */
+int icka_gemm_qkv_attn(const icka_gemm_desc* d, const float* add_mask, void* ctx, void* ctx_f16, int64_t ldo, float* lse,
+                       int32_t B, int32_t heads, int32_t S, float scale, float p_drop, uint64_t seed, void* keep_bits, void* stream);
 /* "mixed16" form of the same call: x_kind / res_kind are 0 = bf16, 1 = f32, 2 = fp16, and the twin copy of the output is
  * fp16 (y_f16, contiguous, saturating at +-65504): it is both the fp16 MFMA operand of the next forward GEMM and the
  * residual input of the next block, while y (bf16) stays the operand of the bf16 weight-gradient GEMM in backward. */

@@ -759,41 +759,50 @@ def test_gemm_ln_one_launch_equals_the_two_launches_bitwise(M, N, K, p, res_dtyp
         assert o.abs().sum().item() == 0.0
 
 
-@pytest.mark.parametrize("B,heads,K,p", [(32, 12, 768, 0.1), (32, 12, 768, 0.0), (64, 12, 768, 0.1), (32, 16, 1024, 0.1),
-                                         (24, 12, 768, 0.1)])
-def test_gemm_qkv_attn_one_launch_equals_the_two_launches_bitwise(B, heads, K, p):
+@pytest.mark.parametrize("B,S,heads,K,p,f16,kb", [(32, 128, 12, 768, 0.1, False, False), (32, 128, 12, 768, 0.0, False, False),
+                                                  (64, 128, 12, 768, 0.1, False, False), (32, 128, 16, 1024, 0.1, False, False),
+                                                  (24, 128, 12, 768, 0.1, False, False), (32, 128, 12, 768, 0.1, True, False),
+                                                  (32, 256, 16, 1024, 0.1, True, True), (32, 256, 16, 1024, 0.1, False, False),
+                                                  (16, 256, 12, 768, 0.0, False, False)])
+def test_gemm_qkv_attn_one_launch_equals_the_two_launches_bitwise(B, S, heads, K, p, f16, kb):
     """icka_gemm_qkv_attn (QKV projection + whole-head self-attention in ONE launch: every 256 x 192 tile of the 12-wave GEMM
-    kernel = two samples x one head's q | k | v, the attention runs from the tile's LDS images) == icka_gemm + icka_attn_fwd,
-    BITWISE: the stacked qkv activation (the backward reads it), the context and the log-sum-exp; with masked keys and with
-    dropout (same counters: icka_attn_bwd regenerates the mask).  Shapes outside its domain return False and launch nothing.
-    (reference: BertSelfAttention.forward Cross_Modal_Interaction_Module.py:478-506)"""
+    kernel = 256 / S samples x one head's q | k | v, the attention runs from the tile's LDS images) == icka_gemm +
+    icka_attn_fwd_ex, BITWISE: the stacked qkv activation (the backward reads it), the context (and its fp16 copy), the
+    log-sum-exp and the keep bits; with masked keys and with dropout (same counters: icka_attn_bwd regenerates the mask); bf16 and
+    fp16 ("mixed16") operands; 128 and 256 tokens per sample.  (reference: BertSelfAttention.forward
+    Cross_Modal_Interaction_Module.py:478-506)"""
     k = _k()
-    S, H = 128, 64 * heads
+    H = 64 * heads
     M = B * S
-    x, w = rnd(M, K, seed=1, scale=0.5), rnd(3 * H, K, seed=2, scale=0.08)
+    odt = torch.float16 if f16 else BF16
+    x, w = rnd(M, K, seed=1, scale=0.5, dtype=odt), rnd(3 * H, K, seed=2, scale=0.08, dtype=odt)
     bias = rnd(3 * H, seed=3, dtype=F32)
     mask = torch.zeros(B, S, dtype=F32, device="cuda")
     for b in range(B):                       # ragged lengths: keys past the sample's length are masked
-        mask[b, 20 + (37 * b) % 108:] = -10000.0
+        mask[b, 20 + (37 * b) % (S - 20):] = -10000.0
     seed = 0x9876543210
 
     def outs():
         return (torch.full((M, 3 * H), float("nan"), dtype=BF16, device="cuda"), torch.full((M, H), float("nan"), dtype=BF16, device="cuda"),
-                torch.full((B, heads, S), float("nan"), dtype=F32, device="cuda"))
+                torch.full((B, heads, S), float("nan"), dtype=F32, device="cuda"),
+                torch.full((M, H), float("nan"), dtype=torch.float16, device="cuda") if f16 else None,
+                k.attn_keepbits(B, heads, S, S, "cuda").fill_(-1) if kb else None)
 
-    q0, c0, l0 = outs()
+    q0, c0, l0, h0, b0 = outs()
     k.gemm(k.GEMM_NT, x, w, q0, bias=bias)
-    k.attn_fwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], mask, c0, l0, B, heads, S, S, p_drop=p, seed=seed)
+    k.attn_fwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], mask, c0, l0, B, heads, S, S, p_drop=p, seed=seed, out16=h0, keepbits=b0)
     for rep in range(2):
-        q1, c1, l1 = outs()
-        assert k.gemm_qkv_attn(x, w, bias, q1, mask, c1, l1, B, heads, S, p_drop=p, seed=seed)
+        q1, c1, l1, h1, b1 = outs()
+        assert k.gemm_qkv_attn(x, w, bias, q1, mask, c1, l1, B, heads, S, p_drop=p, seed=seed, out16=h1, keepbits=b1)
         torch.cuda.synchronize()
         assert torch.equal(q1, q0), rep
         assert torch.equal(l1, l0), rep
         assert torch.equal(c1, c0), rep
+        assert h0 is None or torch.equal(h1, h0)
+        assert b0 is None or torch.equal(b1, b0)
     # eval form: no log-sum-exp wanted
-    q1, c1, _ = outs()
-    assert k.gemm_qkv_attn(x, w, bias, q1, mask, c1, None, B, heads, S, p_drop=p, seed=seed)
+    q1, c1, _, h1, _ = outs()
+    assert k.gemm_qkv_attn(x, w, bias, q1, mask, c1, None, B, heads, S, p_drop=p, seed=seed, out16=h1)
     assert torch.equal(c1, c0) and torch.equal(q1, q0)
     # the backward takes what the fused forward left
     if p > 0:
@@ -807,10 +816,10 @@ def test_gemm_qkv_attn_one_launch_equals_the_two_launches_bitwise(B, heads, K, p
 
 
 def test_gemm_qkv_attn_declines_what_it_does_not_cover():
-    """Outside the fused launch's domain (sequence length other than 128, an odd number of samples, a grid of fewer than 128
-    tiles, fp16 operands, a per-call tune word) the call returns False and writes nothing."""
+    """Outside the fused launch's domain (sequence length other than 128 / 256, rows that do not fill 256-row tiles, a grid of
+    fewer than 128 tiles) the call returns False and writes nothing."""
     k = _k()
-    for (B, S, heads) in ((64, 64, 12), (31, 128, 12), (4, 128, 12), (16, 256, 12)):
+    for (B, S, heads) in ((64, 64, 12), (31, 128, 12), (4, 128, 12), (8, 384, 12)):
         H, M = 64 * heads, B * S
         x, w, bias = rnd(M, 768, seed=1), rnd(3 * H, 768, seed=2), rnd(3 * H, seed=3, dtype=F32)
         qkv, ctx = torch.zeros(M, 3 * H, dtype=BF16, device="cuda"), torch.zeros(M, H, dtype=BF16, device="cuda")
